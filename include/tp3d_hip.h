@@ -1,0 +1,104 @@
+/*
+ * tp3d_hip.h -- C-ABI of libtp3d_hip.so, the MI355X (gfx950) implementation of the
+ * torch_points_kernels hot path used by torch-points3d.
+ *
+ * The reference has no FFI table for this path: it binds the third-party Python package
+ * `torch_points_kernels` by import name (reference torch_points3d/core/spatial_ops/sampling.py:7,
+ * core/spatial_ops/neighbour_finder.py:5, core/base_conv/dense.py:19, modules/pointnet2/dense.py:4).
+ * Each entry point below is what that package's Python function would bind for one call; the
+ * Python wrapper lives in torch_points3d_amd/torchpoints.py and INTEGRATION.md shows the ctypes stub.
+ *
+ * Conventions
+ *  - plain pointers and sizes only; every pointer is DEVICE memory owned by the caller
+ *    (the library never allocates, frees or synchronises);
+ *  - all tensors are dense, row-major, contiguous; float = IEEE fp32; indices are int64 (the
+ *    reference feeds them to torch.gather, core/base_conv/dense.py:75-76);
+ *  - `stream` is a hipStream_t passed as void* (NULL = the null stream); work is enqueued, not awaited;
+ *  - return 0 on success, a negative TP3D_E_* code otherwise (no exception crosses the boundary);
+ *    tp3d_strerror() gives text, tp3d_last_hip_error() the hipError_t of a failed launch;
+ *  - squared distances are evaluated as (dx*dx + dy*dy) + dz*dz, fp32, no fused multiply-add, so that
+ *    index outputs are bit-exact against the CPU oracle (oracle/tpk_ref_cpu.c).
+ */
+#ifndef TP3D_HIP_H
+#define TP3D_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TP3D_OK 0
+#define TP3D_E_BADARG (-1)   /* negative / inconsistent sizes, null pointer with non-empty work */
+#define TP3D_E_LAUNCH (-2)   /* hipGetLastError() != hipSuccess after the launch */
+#define TP3D_E_UNSORTED (-3) /* reserved: batch vector not sorted (checked by the host wrapper) */
+#define TP3D_E_TOOBIG (-4)   /* size exceeds what the kernel's index arithmetic supports */
+
+#define TP3D_ABI_VERSION 1
+
+int tp3d_abi_version(void);
+const char *tp3d_strerror(int code);
+int tp3d_last_hip_error(void);
+
+/*
+ * furthest_point_sample(xyz, npoint)            [reference call: core/spatial_ops/sampling.py:100]
+ *   xyz (B,N,3) f32 -> out_idx (B,npoint) int64.  sel[0]=0, then argmax of the running min squared
+ *   distance, ties -> lowest index.  scratch: B*N floats (used only when N > TP3D_FPS_MAX_REG_POINTS).
+ */
+#define TP3D_FPS_MAX_REG_POINTS 32768
+int tp3d_fps_f32(const float *xyz, int B, int N, int npoint, float *scratch, int64_t *out_idx, void *stream);
+
+/*
+ * ball_query(radius, nsample, x, y, mode="dense", sort)
+ *                                               [reference call: core/spatial_ops/neighbour_finder.py:164,
+ *                                                core/losses/dirichlet_loss.py:52]
+ *   x (B,N,3), y (B,np,3) -> idx (B,np,nsample) int64, dist2 (B,np,nsample) f32.
+ *   sort=0: hits (d2 < r*r, strict) in ascending index order, first nsample; remaining slots repeat the
+ *           first hit (0 if none); dist2 = -1 in padded slots.
+ *   sort=1: the nsample closest hits, closest first (ties by index), padded with the closest.
+ */
+int tp3d_ball_query_dense_f32(const float *x, const float *y, int B, int N, int np, float radius, int nsample,
+                              int sort, int64_t *idx, float *dist2, void *stream);
+
+/*
+ * ball_query(..., mode="partial_dense", batch_x, batch_y)
+ *                                               [reference call: core/spatial_ops/neighbour_finder.py:31-37]
+ *   x (M,3) with ascending batch_x (M) int64, y (Nq,3) with batch_y (Nq) int64.
+ *   idx (Nq,nsample) int64 = global rows of x, padded with -1; dist2 padded with -1.
+ */
+int tp3d_ball_query_partial_dense_f32(const float *x, const float *y, const int64_t *batch_x,
+                                      const int64_t *batch_y, int64_t M, int64_t Nq, float radius, int nsample,
+                                      int sort, int64_t *idx, float *dist2, void *stream);
+
+/*
+ * three_nn(unknown, known) -> (dist, idx)       [reference call: core/base_conv/dense.py:136]
+ *   unknown (B,n,3), known (B,m,3), m >= 3 -> dist (B,n,3) f32 Euclidean (sqrt), idx (B,n,3) int64;
+ *   ascending distance, ties -> lowest index.
+ */
+int tp3d_three_nn_f32(const float *unknown, const float *known, int B, int n, int m, float *dist, int64_t *idx,
+                      void *stream);
+
+/*
+ * three_interpolate(features, idx, weight)      [reference call: core/base_conv/dense.py:140]
+ *   features (B,C,m), idx (B,n,3) int64, weight (B,n,3) -> out (B,C,n) = (w0*f0 + w1*f1) + w2*f2.
+ *   bwd: grad_out (B,C,n) -> grad_features (B,C,m) (overwritten, not accumulated).
+ */
+int tp3d_three_interpolate_fwd_f32(const float *features, const int64_t *idx, const float *weight, int B, int C,
+                                   int m, int n, float *out, void *stream);
+int tp3d_three_interpolate_bwd_f32(const float *grad_out, const int64_t *idx, const float *weight, int B, int C,
+                                   int m, int n, float *grad_features, void *stream);
+
+/*
+ * grouping_operation(features, idx)             [reference call: modules/pointnet2/dense.py:38,45]
+ *   features (B,C,N), idx (B,np,ns) int64 -> out (B,C,np,ns); bwd scatters grad_out into (B,C,N)
+ *   (overwritten, not accumulated).
+ */
+int tp3d_group_fwd_f32(const float *features, const int64_t *idx, int B, int C, int N, int np, int ns, float *out,
+                       void *stream);
+int tp3d_group_bwd_f32(const float *grad_out, const int64_t *idx, int B, int C, int N, int np, int ns,
+                       float *grad_features, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TP3D_HIP_H */

@@ -1,0 +1,349 @@
+/*
+ * tpk_ref_cpu.c -- CPU ORACLE for the torch_points_kernels hot path.
+ *
+ * THIS IS TEST INFRASTRUCTURE, NOT PRODUCT CODE.  Only tests/, __graft_entry__.smoke()
+ * and bench.py's cpu_baseline leg may load it.  The product path (torch_points3d_amd)
+ * never imports, links or executes anything under oracle/.
+ *
+ * What it restates: the arithmetic that torch-points3d delegates to the third-party,
+ * un-vendored package torch-points-kernels==0.7.0 (reference poetry.lock:2451-2462).
+ * That package's source is NOT under /root/reference, so each function below follows
+ * the contract proven by the reference's own call sites and tests (cited per function)
+ * and the canonical semantics fixed in SURVEY.md section 8a.
+ *
+ * Parity status: ball_query(dense, sort=True) is pinned by the reference's known-answer
+ * test test/test_losses.py:16-24; FPS start/argmax rule is pinned by test/test_fps.py:35-42
+ * (torch_cluster fps(random_start=False) -- same rule); pad-with-first for unsorted dense
+ * queries by core/spatial_ops/neighbour_finder.py:166-172; -1 shadow padding for
+ * partial_dense by core/common_modules/gathering.py:10 and datasets/multiscale_data.py:104-130.
+ * For three_nn / three_interpolate / grouping the reference holds no numeric fixture:
+ * "parity unpinned" at the kernel boundary; they are pinned one level up by running the
+ * reference's own DenseFPModule / PointNetMSGDown on top of this oracle (tests/golden/).
+ *
+ * Floating point: every squared distance is evaluated as (dx*dx + dy*dy) + dz*dz in fp32
+ * with contraction OFF (build with -ffp-contract=off), the order nanoflann's L2 adaptor
+ * accumulates in on the reference's CPU path.  The HIP kernels use the same order so that
+ * index outputs are bit-exact.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define TPK_API __attribute__((visibility("default")))
+
+static inline float sqdist3(const float *a, const float *b)
+{
+    float dx = a[0] - b[0];
+    float dy = a[1] - b[1];
+    float dz = a[2] - b[2];
+    return (dx * dx + dy * dy) + dz * dz;
+}
+
+TPK_API int tpk_ref_num_threads(void)
+{
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+
+TPK_API void tpk_ref_set_num_threads(int n)
+{
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
+
+/*
+ * H1  furthest_point_sample(xyz, npoint)
+ * Call site: reference core/spatial_ops/sampling.py:100 (DenseFPSSampler.sample),
+ * consumer core/base_conv/dense.py:74-76 (.long() then gather).
+ * Rule (same as test/test_fps.py:35-42): sel[0]=0; mind[j]=1e10;
+ * mind[j]=min(mind[j], |p_j-p_last|^2); next = argmax_j mind[j], ties -> lowest j.
+ * scratch: B*N floats (running min distance), caller-provided like the HIP entry point.
+ */
+TPK_API int tpk_ref_fps_f32(const float *xyz, int B, int N, int npoint, float *scratch, int64_t *out_idx)
+{
+    if (B < 0 || N <= 0 || npoint < 0 || npoint > N) return -1;
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int b = 0; b < B; ++b) {
+        const float *p = xyz + (size_t)b * N * 3;
+        float *mind = scratch + (size_t)b * N;
+        int64_t *out = out_idx + (size_t)b * npoint;
+        for (int j = 0; j < N; ++j) mind[j] = 1e10f;
+        int last = 0;
+        if (npoint > 0) out[0] = 0;
+        for (int i = 1; i < npoint; ++i) {
+            const float *q = p + (size_t)last * 3;
+            float best = -1.0f;
+            int besti = 0;
+            for (int j = 0; j < N; ++j) {
+                float d = sqdist3(p + (size_t)j * 3, q);
+                float m = mind[j] < d ? mind[j] : d;
+                mind[j] = m;
+                if (m > best) {
+                    best = m;
+                    besti = j;
+                }
+            }
+            last = besti;
+            out[i] = besti;
+        }
+    }
+    return 0;
+}
+
+/* insertion of (d, k) into a list sorted by (d asc, k asc), capped at cap entries */
+static inline void sorted_insert(float *dl, int64_t *kl, int *cnt, int cap, float d, int64_t k)
+{
+    int n = *cnt;
+    if (n == cap) {
+        /* k ascends during the scan, so an equal distance never displaces an earlier index */
+        if (!(d < dl[n - 1])) return;
+        n = n - 1;
+    }
+    int pos = n;
+    while (pos > 0 && d < dl[pos - 1]) {
+        dl[pos] = dl[pos - 1];
+        kl[pos] = kl[pos - 1];
+        --pos;
+    }
+    dl[pos] = d;
+    kl[pos] = k;
+    *cnt = n + 1;
+}
+
+/*
+ * One query of a radius search over support rows [lo, hi).
+ * sort==0: hits in ascending index order, first nsample kept (upstream device-kernel rule;
+ *          padding evidence core/spatial_ops/neighbour_finder.py:166-172).
+ * sort!=0: the nsample CLOSEST hits, closest first, ties by index (nanoflann radiusSearch
+ *          with sorted results then truncation; pinned by test/test_losses.py:16-24).
+ * Returns the number of real hits written (<= nsample).
+ */
+static int radius_one(const float *x, int64_t lo, int64_t hi, const float *q, float r2, int nsample, int sort,
+                      int64_t *idx, float *d2)
+{
+    int cnt = 0;
+    if (!sort) {
+        for (int64_t k = lo; k < hi && cnt < nsample; ++k) {
+            float d = sqdist3(x + (size_t)k * 3, q);
+            if (d < r2) {
+                idx[cnt] = k;
+                d2[cnt] = d;
+                ++cnt;
+            }
+        }
+    } else {
+        for (int64_t k = lo; k < hi; ++k) {
+            float d = sqdist3(x + (size_t)k * 3, q);
+            if (d < r2) sorted_insert(d2, idx, &cnt, nsample, d, k);
+        }
+    }
+    return cnt;
+}
+
+/*
+ * H2  ball_query(radius, nsample, x, y, mode="dense", sort)
+ * Call sites: core/spatial_ops/neighbour_finder.py:164, core/losses/dirichlet_loss.py:52.
+ * idx (B,np,nsample) int64: hits, then the FIRST hit repeated; no hit -> all 0.
+ * dist2 (B,np,nsample) f32: squared distance of hits, -1 in padded slots.
+ */
+TPK_API int tpk_ref_ball_query_dense_f32(const float *x, const float *y, int B, int N, int np, float radius,
+                                         int nsample, int sort, int64_t *idx, float *dist2)
+{
+    if (B < 0 || N < 0 || np < 0 || nsample <= 0) return -1;
+    const float r2 = radius * radius;
+    const int64_t total = (int64_t)B * np;
+#pragma omp parallel for schedule(static)
+    for (int64_t t = 0; t < total; ++t) {
+        int b = (int)(t / np);
+        const float *xb = x + (size_t)b * N * 3;
+        int64_t *io = idx + (size_t)t * nsample;
+        float *dd = dist2 + (size_t)t * nsample;
+        int cnt = radius_one(xb, 0, N, y + (size_t)t * 3, r2, nsample, sort, io, dd);
+        int64_t pad = cnt > 0 ? io[0] : 0;
+        for (int s = cnt; s < nsample; ++s) {
+            io[s] = pad;
+            dd[s] = -1.0f;
+        }
+    }
+    return 0;
+}
+
+/*
+ * H3  ball_query(..., mode="partial_dense", batch_x, batch_y)
+ * Call site: core/spatial_ops/neighbour_finder.py:31-37 (KPConv blocks.py:52-53,84).
+ * x (M,3) with sorted batch_x (M), y (Nq,3) with sorted batch_y (Nq).  Indices are global
+ * rows of x; padding is -1 (shadow point, core/common_modules/gathering.py:10), dist2 -1.
+ */
+TPK_API int tpk_ref_ball_query_partial_dense_f32(const float *x, const float *y, const int64_t *batch_x,
+                                                 const int64_t *batch_y, int64_t M, int64_t Nq, float radius,
+                                                 int nsample, int sort, int64_t *idx, float *dist2)
+{
+    if (M < 0 || Nq < 0 || nsample <= 0) return -1;
+    for (int64_t i = 1; i < M; ++i)
+        if (batch_x[i] < batch_x[i - 1]) return -2;
+    const float r2 = radius * radius;
+#pragma omp parallel for schedule(static)
+    for (int64_t j = 0; j < Nq; ++j) {
+        int64_t bq = batch_y[j];
+        /* segment [lo,hi) of x rows whose batch id equals bq (batch_x sorted) */
+        int64_t lo = 0, hi = M;
+        {
+            int64_t a = 0, c = M;
+            while (a < c) {
+                int64_t m = (a + c) / 2;
+                if (batch_x[m] < bq) a = m + 1; else c = m;
+            }
+            lo = a;
+            c = M;
+            while (a < c) {
+                int64_t m = (a + c) / 2;
+                if (batch_x[m] <= bq) a = m + 1; else c = m;
+            }
+            hi = a;
+        }
+        int64_t *io = idx + (size_t)j * nsample;
+        float *dd = dist2 + (size_t)j * nsample;
+        int cnt = radius_one(x, lo, hi, y + (size_t)j * 3, r2, nsample, sort, io, dd);
+        for (int s = cnt; s < nsample; ++s) {
+            io[s] = -1;
+            dd[s] = -1.0f;
+        }
+    }
+    return 0;
+}
+
+/*
+ * H8  three_nn(unknown, known) -> (dist, idx)
+ * Call site: core/base_conv/dense.py:136; dist is consumed as a Euclidean distance
+ * (1/(dist+1e-8), dense.py:137) so the sqrt of the squared distance is returned.
+ * Three nearest known points, ascending distance, ties -> lowest index (strict '<' insert).
+ */
+TPK_API int tpk_ref_three_nn_f32(const float *unknown, const float *known, int B, int n, int m, float *dist,
+                                 int64_t *idx)
+{
+    if (B < 0 || n < 0 || m < 3) return -1;
+    const int64_t total = (int64_t)B * n;
+#pragma omp parallel for schedule(static)
+    for (int64_t t = 0; t < total; ++t) {
+        int b = (int)(t / n);
+        const float *q = unknown + (size_t)t * 3;
+        const float *kb = known + (size_t)b * m * 3;
+        float b1 = INFINITY, b2 = INFINITY, b3 = INFINITY;
+        int i1 = 0, i2 = 0, i3 = 0;
+        for (int k = 0; k < m; ++k) {
+            float d = sqdist3(kb + (size_t)k * 3, q);
+            if (d < b1) {
+                b3 = b2; i3 = i2;
+                b2 = b1; i2 = i1;
+                b1 = d;  i1 = k;
+            } else if (d < b2) {
+                b3 = b2; i3 = i2;
+                b2 = d;  i2 = k;
+            } else if (d < b3) {
+                b3 = d;  i3 = k;
+            }
+        }
+        dist[t * 3 + 0] = sqrtf(b1);
+        dist[t * 3 + 1] = sqrtf(b2);
+        dist[t * 3 + 2] = sqrtf(b3);
+        idx[t * 3 + 0] = i1;
+        idx[t * 3 + 1] = i2;
+        idx[t * 3 + 2] = i3;
+    }
+    return 0;
+}
+
+/*
+ * H9  three_interpolate(features (B,C,m), idx (B,n,3), weight (B,n,3)) -> (B,C,n)
+ * Call site: core/base_conv/dense.py:140.  out = (w0*f0 + w1*f1) + w2*f2 (fixed order).
+ */
+TPK_API int tpk_ref_three_interpolate_fwd_f32(const float *feat, const int64_t *idx, const float *w, int B, int C,
+                                              int m, int n, float *out)
+{
+    if (B < 0 || C < 0 || m <= 0 || n < 0) return -1;
+    const int64_t total = (int64_t)B * C;
+#pragma omp parallel for schedule(static)
+    for (int64_t t = 0; t < total; ++t) {
+        int b = (int)(t / C);
+        const float *f = feat + (size_t)t * m;
+        const int64_t *ib = idx + (size_t)b * n * 3;
+        const float *wb = w + (size_t)b * n * 3;
+        float *o = out + (size_t)t * n;
+        for (int i = 0; i < n; ++i) {
+            float a0 = wb[i * 3 + 0] * f[ib[i * 3 + 0]];
+            float a1 = wb[i * 3 + 1] * f[ib[i * 3 + 1]];
+            float a2 = wb[i * 3 + 2] * f[ib[i * 3 + 2]];
+            o[i] = (a0 + a1) + a2;
+        }
+    }
+    return 0;
+}
+
+/* backward wrt features: grad_feat[b,c,idx[b,i,t]] += w[b,i,t]*grad_out[b,c,i], i then t ascending */
+TPK_API int tpk_ref_three_interpolate_bwd_f32(const float *grad_out, const int64_t *idx, const float *w, int B,
+                                              int C, int m, int n, float *grad_feat)
+{
+    if (B < 0 || C < 0 || m <= 0 || n < 0) return -1;
+    const int64_t total = (int64_t)B * C;
+#pragma omp parallel for schedule(static)
+    for (int64_t t = 0; t < total; ++t) {
+        int b = (int)(t / C);
+        float *g = grad_feat + (size_t)t * m;
+        const int64_t *ib = idx + (size_t)b * n * 3;
+        const float *wb = w + (size_t)b * n * 3;
+        const float *go = grad_out + (size_t)t * n;
+        for (int k = 0; k < m; ++k) g[k] = 0.0f;
+        for (int i = 0; i < n; ++i)
+            for (int s = 0; s < 3; ++s) g[ib[i * 3 + s]] += wb[i * 3 + s] * go[i];
+    }
+    return 0;
+}
+
+/*
+ * H5  grouping_operation(features (B,C,N), idx (B,np,ns)) -> (B,C,np,ns)
+ * Call sites: modules/pointnet2/dense.py:38,45.  Pure gather; backward = scatter-add.
+ */
+TPK_API int tpk_ref_group_fwd_f32(const float *feat, const int64_t *idx, int B, int C, int N, int np, int ns,
+                                  float *out)
+{
+    if (B < 0 || C < 0 || N <= 0 || np < 0 || ns < 0) return -1;
+    const int64_t total = (int64_t)B * C;
+    const int64_t L = (int64_t)np * ns;
+#pragma omp parallel for schedule(static)
+    for (int64_t t = 0; t < total; ++t) {
+        int b = (int)(t / C);
+        const float *f = feat + (size_t)t * N;
+        const int64_t *ib = idx + (size_t)b * L;
+        float *o = out + (size_t)t * L;
+        for (int64_t l = 0; l < L; ++l) o[l] = f[ib[l]];
+    }
+    return 0;
+}
+
+TPK_API int tpk_ref_group_bwd_f32(const float *grad_out, const int64_t *idx, int B, int C, int N, int np, int ns,
+                                  float *grad_feat)
+{
+    if (B < 0 || C < 0 || N <= 0 || np < 0 || ns < 0) return -1;
+    const int64_t total = (int64_t)B * C;
+    const int64_t L = (int64_t)np * ns;
+#pragma omp parallel for schedule(static)
+    for (int64_t t = 0; t < total; ++t) {
+        int b = (int)(t / C);
+        float *g = grad_feat + (size_t)t * N;
+        const int64_t *ib = idx + (size_t)b * L;
+        const float *go = grad_out + (size_t)t * L;
+        for (int k = 0; k < N; ++k) g[k] = 0.0f;
+        for (int64_t l = 0; l < L; ++l) g[ib[l]] += go[l];
+    }
+    return 0;
+}

@@ -1,0 +1,51 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def pytest_collection_modifyitems(config, items):
+    if torch.cuda.is_available():
+        return
+    skip = pytest.mark.skip(reason="no GPU in this container")
+    for item in items:
+        if "gpu" in item.keywords:
+            item.add_marker(skip)
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    """The CPU oracle (test infrastructure): oracle/tpk_ref.py over oracle/libtpk_ref_cpu.so."""
+    from oracle import tpk_ref
+    tpk_ref.build()
+    return tpk_ref
+
+
+@pytest.fixture(scope="session")
+def hip():
+    """The product kernels; importing never falls back to anything else."""
+    from torch_points3d_amd import torchpoints
+    return torchpoints
+
+
+def load_golden(name):
+    z = np.load(os.path.join(GOLDEN, name + ".npz"))
+    out = {}
+    for k in z.files:
+        v = z[k]
+        if v.dtype == np.int16:
+            v = v.astype(np.int64)
+        out[k] = torch.from_numpy(v) if v.dtype != np.float64 else v
+    return out

@@ -1,0 +1,224 @@
+#!/usr/bin/env python
+"""Generates the golden fixtures under tests/golden/ by running the REFERENCE's own Python modules.
+
+Runs only in the build container (needs /root/reference); the fixtures it writes are plain data (inputs,
+indices, per-stage outputs, gradients) and are what travels to the GPU box.
+
+How: torch-points3d's dense PointNet++ modules (PointNetMSGDown, DenseFPModule, GlobalDenseBaseModule, Conv1D)
+are imported from /root/reference unmodified.  Their third-party imports that are not installed here
+(torch_geometric, torch_scatter, omegaconf) are replaced by empty stand-in modules in sys.modules -- none of
+them is called on this path -- and `torch_points_kernels` (torch-points-kernels 0.7.0, not installed, source
+not in the reference tree) is bound to the CPU oracle oracle/tpk_ref.py.  So the fixtures pin
+"reference modules + oracle kernels"; the kernel boundary itself is pinned by the reference's known-answer
+tests restated in tests/test_oracle_kat.py.
+
+The U-Net assembly of applications/pointnet2.py needs a real OmegaConf and cannot be imported; the script
+assembles the reference modules by hand in the order unet.py:400-487 / pointnet2.py:154-191 prescribe.
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+sys.path.insert(0, ROOT)
+
+from oracle import tpk_ref  # noqa: E402
+
+
+class _Bag(object):
+    def __init__(self, **kw):
+        for k, v in kw.items():
+            setattr(self, k, v)
+
+    @property
+    def keys(self):
+        return [k for k, v in self.__dict__.items() if v is not None]
+
+
+def _stub(name, **attrs):
+    m = types.ModuleType(name)
+    for k, v in attrs.items():
+        setattr(m, k, v)
+    sys.modules[name] = m
+    return m
+
+
+def install_stubs():
+    def _na(*a, **k):
+        raise RuntimeError("stubbed third-party function called")
+
+    class _MP(torch.nn.Module):
+        def __init__(self, *a, **k):
+            super().__init__()
+
+    tg = _stub("torch_geometric")
+    tg.nn = _stub("torch_geometric.nn", knn_interpolate=_na, fps=_na, radius=_na, global_max_pool=_na,
+                  global_mean_pool=_na, knn=_na, voxel_grid=_na, PointConv=_MP, MessagePassing=_MP)
+    tg.nn.pool = _stub("torch_geometric.nn.pool")
+    _stub("torch_geometric.nn.pool.consecutive", consecutive_cluster=_na)
+    _stub("torch_geometric.nn.pool.pool", pool_pos=_na, pool_batch=_na)
+    tg.data = _stub("torch_geometric.data", Data=_Bag, Batch=_Bag)
+    _stub("torch_scatter", scatter_add=_na, scatter_mean=_na, scatter_max=_na)
+    oc = _stub("omegaconf", OmegaConf=object, DictConfig=dict, ListConfig=list)
+    oc.listconfig = _stub("omegaconf.listconfig", ListConfig=type("ListConfig", (list,), {}))
+    oc.dictconfig = _stub("omegaconf.dictconfig", DictConfig=type("DictConfig", (dict,), {}))
+    _stub("torch_points_kernels", furthest_point_sample=tpk_ref.furthest_point_sample,
+          ball_query=tpk_ref.ball_query, three_nn=tpk_ref.three_nn, three_interpolate=tpk_ref.three_interpolate,
+          grouping_operation=tpk_ref.grouping_operation)
+    sys.path.insert(0, REF)
+
+
+def build_reference_unet(cfg, output_nc):
+    """Reference modules assembled in the reference's order (down, inner, up, head)."""
+    from torch_points3d.core.base_conv.dense import DenseFPModule, GlobalDenseBaseModule
+    from torch_points3d.core.common_modules.base_modules import Seq
+    from torch_points3d.core.common_modules.dense_modules import Conv1D
+    from torch_points3d.modules.pointnet2.dense import PointNetMSGDown
+
+    net = torch.nn.Module()
+    net.down_modules = torch.nn.ModuleList()
+    for i in range(len(cfg["down_conv_nn"])):
+        net.down_modules.append(PointNetMSGDown(
+            npoint=cfg["npoint"][i], radii=cfg["radii"][i], nsample=cfg["nsample"][i],
+            down_conv_nn=cfg["down_conv_nn"][i], normalize_xyz=cfg["normalize_xyz"][i], index=i))
+    net.inner_modules = torch.nn.ModuleList([GlobalDenseBaseModule(nn=cfg["innermost"])])
+    net.up_modules = torch.nn.ModuleList([DenseFPModule(up_conv_nn=c, index=i)
+                                          for i, c in enumerate(cfg["up_conv_nn"])])
+    net.mlp = Seq()
+    net.mlp.append(Conv1D(cfg["up_conv_nn"][-1][-1], output_nc, bn=True, bias=False))
+    return net
+
+
+def run_reference_unet(net, pos, x, record):
+    """PointNet2Unet.forward (applications/pointnet2.py:154-191) over the reference modules."""
+    data = _Bag(pos=pos, x=x.transpose(1, 2).contiguous())
+    stack = [data]
+    for i in range(len(net.down_modules) - 1):
+        data = net.down_modules[i](data)
+        record["down%d_x" % i] = data.x
+        record["down%d_pos" % i] = data.pos
+        stack.append(data)
+    data = net.down_modules[-1](data)
+    last = len(net.down_modules) - 1
+    record["down%d_x" % last] = data.x
+    record["down%d_pos" % last] = data.pos
+    stack.append(data)
+    data = net.inner_modules[0](data)
+    record["inner_x"] = data.x
+    for i in range(len(net.up_modules)):
+        data = net.up_modules[i]((data, stack.pop()))
+        record["up%d_x" % i] = data.x
+    data.x = net.mlp(data.x)
+    record["out_x"] = data.x
+    return data
+
+
+def state_checksums(sd):
+    out = {}
+    for k, v in sd.items():
+        v = v.double()
+        out[k] = np.array([float(v.sum()), float(v.abs().sum())])
+    return out
+
+
+def kernel_level_records(cfg, pos):
+    """Indices the reference modules obtained from the kernel boundary, recomputed stage by stage."""
+    rec = {}
+    cur = pos
+    for i in range(len(cfg["down_conv_nn"])):
+        fps = tpk_ref.furthest_point_sample(cur, cfg["npoint"][i])
+        new = cur.gather(1, fps.unsqueeze(-1).repeat(1, 1, 3))
+        rec["fps%d" % i] = fps
+        for s, (r, ns) in enumerate(zip(cfg["radii"][i], cfg["nsample"][i])):
+            idx, d2 = tpk_ref.ball_query(r, ns, cur, new)
+            rec["ball%d_%d_idx" % (i, s)] = idx
+            rec["ball%d_%d_d2" % (i, s)] = d2
+        cur = new
+    return rec
+
+
+def to_np(rec):
+    out = {}
+    for k, v in rec.items():
+        v = v.detach().cpu().numpy() if torch.is_tensor(v) else np.asarray(v)
+        if v.dtype == np.int64 and v.size and v.max() < 32767 and v.min() > -32768:
+            v = v.astype(np.int16)  # indices are small; the tests widen them again
+        out[k] = v
+    return out
+
+
+def make_case(name, cfg, feat, output_nc, pos, x, seed, store_weights):
+    torch.manual_seed(seed)
+    net = build_reference_unet(cfg, output_nc)
+    net.train()  # the example never calls .eval(): BatchNorm uses batch statistics
+    sd = {k: v.detach().clone() for k, v in net.state_dict().items()}  # weights BEFORE the forward pass
+    x_in = x.clone().requires_grad_(True)
+    rec = {}
+    out = run_reference_unet(net, pos, x_in, rec)
+    # one backward through three_interpolate / grouping / conv / BN for the gradient goldens
+    gen = torch.Generator().manual_seed(seed + 1)
+    cot = torch.randn(out.x.shape, generator=gen)
+    (out.x * cot).sum().backward()
+    rec["cotangent"] = cot
+    rec["grad_x_in"] = x_in.grad
+    rec["grad_first_conv"] = net.down_modules[0].mlps[0][0][0].weight.grad
+    rec["grad_last_fp_conv"] = net.up_modules[-1].nn[0][0].weight.grad
+    rec["pos"] = pos
+    rec["x"] = x
+    rec.update(kernel_level_records(cfg, pos))
+    arrays = to_np(rec)
+    # running statistics after one train-mode forward (BatchNorm momentum 0.1)
+    arrays["bn_after/first_running_mean"] = net.down_modules[0].mlps[0][0][1].running_mean.detach().numpy()
+    arrays["bn_after/first_running_var"] = net.down_modules[0].mlps[0][0][1].running_var.detach().numpy()
+    for k, v in state_checksums(sd).items():
+        arrays["cksum/" + k] = v
+    if store_weights:
+        for k, v in sd.items():
+            arrays["state/" + k] = v.detach().cpu().numpy()
+    arrays["meta_seed"] = np.array([seed])
+    arrays["meta_feat_outnc"] = np.array([feat, output_nc])
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **arrays)
+    print("wrote %s (%.1f KiB)" % (path, os.path.getsize(path) / 1024.0))
+
+
+def main():
+    install_stubs()
+    from torch_points3d_amd.pointnet2 import unet_config
+
+    # (1) BASELINE config 1: examples/pointnet2_segmentation_forward.py:5-19 -- randn cloud duplicated to B=2,
+    #     FEAT=5, 10 classes, unet_3_ss, weights from torch.manual_seed(0).
+    torch.manual_seed(0)
+    pos = torch.randn((1024, 3)).unsqueeze(0)
+    feats = torch.randn((1024, 5)).unsqueeze(0)
+    pos, feats = torch.cat([pos, pos], 0), torch.cat([feats, feats], 0)
+    make_case("c1_example", unet_config("unet_3_ss", 5), 5, 10, pos, feats, seed=0, store_weights=False)
+
+    # (2) distinct clouds, uniform cube (realistic full/partial balls), narrow network with stored weights.
+    g = torch.Generator().manual_seed(1234)
+    pos = torch.rand(3, 700, 3, generator=g) * 2 - 1
+    feats = torch.randn(3, 700, 4, generator=g)
+    small = dict(npoint=[160, 40], radii=[[0.35], [0.7]], nsample=[[24], [16]],
+                 down_conv_nn=[[[4 + 3, 16, 16, 24]], [[24 + 3, 24, 24, 32]]], innermost=[32 + 3, 32, 48],
+                 up_conv_nn=[[48 + 32, 32, 32], [32 + 24, 32, 24], [24 + 4, 24, 24, 24]],
+                 normalize_xyz=[False, True], save_sampling_id=[False, False])
+    make_case("small_ssg", small, 4, 6, pos, feats, seed=7, store_weights=True)
+
+    # (3) multi-scale grouping (unet_3_ms.yaml layout, narrow) on distinct clouds.
+    g = torch.Generator().manual_seed(99)
+    pos = torch.rand(2, 600, 3, generator=g) * 2 - 1
+    feats = torch.randn(2, 600, 3, generator=g)
+    msg = dict(npoint=[128, 32], radii=[[0.2, 0.4], [0.5, 0.9]], nsample=[[8, 16], [16, 24]],
+               down_conv_nn=[[[3 + 3, 8, 12], [3 + 3, 8, 16]], [[12 + 16 + 3, 16, 24], [12 + 16 + 3, 16, 20]]],
+               innermost=[24 + 20 + 3, 32, 48], up_conv_nn=[[48 + 44, 32, 32], [32 + 28, 24, 24], [24 + 3, 16, 16]],
+               normalize_xyz=[False, False], save_sampling_id=[False, False])
+    make_case("small_msg", msg, 3, 5, pos, feats, seed=11, store_weights=True)
+
+
+if __name__ == "__main__":
+    main()

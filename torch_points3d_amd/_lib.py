@@ -1,0 +1,82 @@
+"""ctypes binding of libtp3d_hip.so (C-ABI declared in include/tp3d_hip.h).
+
+There is no CPU fallback: if the library is missing or a call fails, the error is raised to the caller.
+"""
+import ctypes
+import os
+
+import torch  # noqa: F401  (loads the HIP runtime the library resolves against)
+
+from . import build as _build
+
+_p = ctypes.c_void_p
+_i = ctypes.c_int
+_l = ctypes.c_int64
+_f = ctypes.c_float
+
+# name -> argtypes; every function returns int (0 = ok). Mirrors include/tp3d_hip.h one to one.
+SIGNATURES = {
+    "tp3d_fps_f32": [_p, _i, _i, _i, _p, _p, _p],
+    "tp3d_ball_query_dense_f32": [_p, _p, _i, _i, _i, _f, _i, _i, _p, _p, _p],
+    "tp3d_ball_query_partial_dense_f32": [_p, _p, _p, _p, _l, _l, _f, _i, _i, _p, _p, _p],
+    "tp3d_three_nn_f32": [_p, _p, _i, _i, _i, _p, _p, _p],
+    "tp3d_three_interpolate_fwd_f32": [_p, _p, _p, _i, _i, _i, _i, _p, _p],
+    "tp3d_three_interpolate_bwd_f32": [_p, _p, _p, _i, _i, _i, _i, _p, _p],
+    "tp3d_group_fwd_f32": [_p, _p, _i, _i, _i, _i, _i, _p, _p],
+    "tp3d_group_bwd_f32": [_p, _p, _i, _i, _i, _i, _i, _p, _p],
+}
+MISC = ("tp3d_abi_version", "tp3d_strerror", "tp3d_last_hip_error")
+ABI_VERSION = 1
+
+_handle = None
+
+
+class Tp3dError(RuntimeError):
+    pass
+
+
+def library_path():
+    return _build.LIB_PATH
+
+
+def load():
+    """dlopen the library (building it first if the in-tree copy is missing or stale and hipcc exists)."""
+    global _handle
+    if _handle is not None:
+        return _handle
+    path = _build.LIB_PATH
+    if not os.path.exists(path):
+        _build.build_library()
+    if not os.path.exists(path):
+        raise Tp3dError("libtp3d_hip.so is missing at %s and could not be built" % path)
+    h = ctypes.CDLL(path)
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(h, name)  # AttributeError here = the .so does not match the header
+        fn.argtypes = argtypes
+        fn.restype = _i
+    h.tp3d_abi_version.restype = _i
+    h.tp3d_strerror.restype = ctypes.c_char_p
+    h.tp3d_strerror.argtypes = [_i]
+    h.tp3d_last_hip_error.restype = _i
+    if h.tp3d_abi_version() != ABI_VERSION:
+        raise Tp3dError("libtp3d_hip.so ABI %d != binding ABI %d" % (h.tp3d_abi_version(), ABI_VERSION))
+    _handle = h
+    return h
+
+
+def call(name, *args):
+    h = load()
+    rc = getattr(h, name)(*args)
+    if rc != 0:
+        raise Tp3dError("%s failed: %s (code %d, hipError %d)" % (
+            name, h.tp3d_strerror(rc).decode(), rc, h.tp3d_last_hip_error()))
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL)."""
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def stream_ptr(device):
+    """hipStream_t of torch's current stream on `device`, so launches order with surrounding torch ops."""
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)

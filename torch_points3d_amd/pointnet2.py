@@ -1,0 +1,111 @@
+"""PointNet++ U-Net assembled from the dense blocks, reproducing the reference's caller for the hot path.
+
+Mirrors torch_points3d/applications/pointnet2.py:22-191 (`PointNet2(architecture="unet", ...)` ->
+`PointNet2Unet.forward`) and the argument unpacking of models/base_architectures/unet.py:400-487 for the
+bundled configs torch_points3d/applications/conf/pointnet2/{unet_3_ss,unet_4_ss,unet_3_ms}.yaml:
+module order, skip-stack order, attribute names (`down_modules`, `inner_modules`, `up_modules`, `mlp`) and
+therefore state_dict keys are the reference's, so its checkpoints load unchanged.
+"""
+import torch
+import torch.nn as nn
+
+from .dense import Conv1D, Data, DenseFPModule, GlobalDenseBaseModule, PointNetMSGDown, Seq
+
+
+def unet_config(name, feat):
+    """The reference's bundled YAMLs with FEAT (and in_feat) already substituted."""
+    if name == "unet_3_ss":  # conf/pointnet2/unet_3_ss.yaml:1-19
+        return dict(
+            npoint=[512, 128], radii=[[0.2], [0.4]], nsample=[[64], [64]],
+            down_conv_nn=[[[feat + 3, 64, 64, 128]], [[128 + 3, 128, 128, 256]]],
+            innermost=[256 + 3, 256, 512, 1024],
+            up_conv_nn=[[1024 + 256, 256, 256], [256 + 128, 256, 128], [128 + feat, 128, 128, 128]],
+            normalize_xyz=[False, False], save_sampling_id=[False, False])
+    if name == "unet_4_ss":  # conf/pointnet2/unet_4_ss.yaml:1-25 (three down layers are built)
+        f = 64
+        return dict(
+            npoint=[2048, 1024, 512], radii=[[0.2], [0.4], [0.8]], nsample=[[64], [32], [16]],
+            down_conv_nn=[[[feat + 3, f, f, f * 2]], [[f * 2 + 3, f * 2, f * 2, f * 4]],
+                          [[f * 4 + 3, f * 2, f * 2, f * 4]]],
+            innermost=[f * 4 + 3, f * 8, f * 16],
+            up_conv_nn=[[f * 16 + f * 4, f * 8, f * 8], [f * 8 + f * 4, f * 8, f * 8],
+                        [f * 8 + f * 2, f * 4, f * 4], [f * 4 + feat, f * 2, f * 2]],
+            normalize_xyz=[True, True, True], save_sampling_id=[True, False, False])
+    if name == "unet_3_ms":  # conf/pointnet2/unet_3_ms.yaml
+        return dict(
+            npoint=[512, 128], radii=[[0.1, 0.2, 0.4], [0.4, 0.8]], nsample=[[32, 64, 128], [64, 128]],
+            down_conv_nn=[[[feat + 3, 32, 32, 64], [feat + 3, 64, 64, 128], [feat + 3, 64, 96, 128]],
+                          [[64 + 128 + 128 + 3, 128, 128, 256], [64 + 128 + 128 + 3, 128, 196, 256]]],
+            innermost=[256 * 2 + 3, 256, 512, 1024],
+            up_conv_nn=[[1024 + 256 * 2, 256, 256], [256 + 128 * 2 + 64, 256, 128], [128 + feat, 128, 128]],
+            normalize_xyz=[False, False], save_sampling_id=[False, False])
+    raise ValueError("unknown PointNet++ config %r" % name)
+
+
+class PointNet2Unet(nn.Module):
+    """Input -- D1 -- D2 -- I -- U1 -- U2 -- U3 -- (head), symmetric skips (applications/pointnet2.py:154-191)."""
+
+    def __init__(self, input_nc, output_nc=None, config="unet_3_ss", kernels=None):
+        super().__init__()
+        cfg = unet_config(config, input_nc) if isinstance(config, str) else config
+        self.config = cfg
+        self.down_modules = nn.ModuleList()
+        for i in range(len(cfg["down_conv_nn"])):
+            self.down_modules.append(PointNetMSGDown(
+                npoint=cfg["npoint"][i], radii=cfg["radii"][i], nsample=cfg["nsample"][i],
+                down_conv_nn=cfg["down_conv_nn"][i], normalize_xyz=cfg["normalize_xyz"][i],
+                save_sampling_id=cfg["save_sampling_id"][i], index=i, kernels=kernels))
+        self.inner_modules = nn.ModuleList([GlobalDenseBaseModule(nn=cfg["innermost"])])
+        self.up_modules = nn.ModuleList(
+            DenseFPModule(up_conv_nn=c, index=i, kernels=kernels) for i, c in enumerate(cfg["up_conv_nn"]))
+        self._output_nc = cfg["up_conv_nn"][-1][-1]
+        self.has_mlp_head = output_nc is not None
+        if self.has_mlp_head:
+            # BN + LeakyReLU are applied on the logits too (applications/pointnet2.py:100-104)
+            self.mlp = Seq().append(Conv1D(self._output_nc, output_nc, bn=True, bias=False))
+            self._output_nc = output_nc
+
+    @property
+    def output_nc(self):
+        return self._output_nc
+
+    def forward(self, data):
+        """data.pos (B,N,3), data.x (B,N,C) or None -> Data(pos (B,N,3), x (B,output_nc,N))."""
+        assert data.pos.dim() == 3
+        x = data.x.transpose(1, 2).contiguous() if data.x is not None else None
+        cur = Data(pos=data.pos, x=x)
+        stack_down = [cur]
+        for i in range(len(self.down_modules) - 1):
+            cur = self.down_modules[i](cur)
+            stack_down.append(cur)
+        cur = self.down_modules[-1](cur)
+        stack_down.append(cur)
+        cur = self.inner_modules[0](cur)
+        sampling_ids = {}
+        for d in stack_down:
+            for k, v in d.__dict__.items():
+                if k.startswith("sampling_id"):
+                    sampling_ids[k] = v
+        for up in self.up_modules:
+            cur = up((cur, stack_down.pop()))
+        for k, v in sampling_ids.items():
+            setattr(cur, k, v)
+        if self.has_mlp_head:
+            cur.x = self.mlp(cur.x)
+        return cur
+
+
+def PointNet2(architecture="unet", input_nc=None, num_layers=3, output_nc=None, multiscale=False, kernels=None):
+    """Config-free factory with the reference's signature (applications/pointnet2.py:22-55); unet only."""
+    if architecture != "unet":
+        raise NotImplementedError("only the unet architecture is on the hot path")
+    name = "unet_{}_{}".format(num_layers, "ms" if multiscale else "ss")
+    return PointNet2Unet(input_nc, output_nc=output_nc, config=name, kernels=kernels)
+
+
+def synthetic_batch(B, N, feat, device="cpu", seed=1234):
+    """The bench/parity input of SURVEY.md 8d: pos ~ U[-1,1]^3, x ~ N(0,1), fixed seed."""
+    g = torch.Generator().manual_seed(seed)
+    pos = torch.rand(B, N, 3, generator=g) * 2 - 1
+    x = torch.randn(B, N, feat, generator=g)
+    return Data(pos=pos.to(device), x=x.to(device))

@@ -1,0 +1,191 @@
+"""The ``torch_points_kernels`` function API, served by hand-written HIP kernels on MI355X.
+
+Mirrors the names, positional order, return values and error behaviour the reference relies on:
+  furthest_point_sample  <- torch_points3d/core/spatial_ops/sampling.py:100
+  ball_query             <- torch_points3d/core/spatial_ops/neighbour_finder.py:35-37,164;
+                            torch_points3d/core/losses/dirichlet_loss.py:52
+  three_nn               <- torch_points3d/core/base_conv/dense.py:136
+  three_interpolate      <- torch_points3d/core/base_conv/dense.py:140
+  grouping_operation     <- torch_points3d/modules/pointnet2/dense.py:38,45
+
+Tensors must live on a ROCm device: there is deliberately no CPU or eager-PyTorch fallback, a CPU
+tensor (or a missing libtp3d_hip.so) raises.
+"""
+import torch
+
+from . import _lib
+
+__all__ = ["furthest_point_sample", "ball_query", "three_nn", "three_interpolate", "grouping_operation"]
+
+
+def _dev(*tensors):
+    d = tensors[0].device
+    for t in tensors:
+        if t is None:
+            continue
+        if t.device.type != "cuda":
+            raise RuntimeError(
+                "torch_points3d_amd runs on MI355X only: got a %s tensor (no CPU fallback is provided)" % t.device.type)
+        if t.device != d:
+            raise RuntimeError("all tensors must be on the same device (%s vs %s)" % (d, t.device))
+    return d
+
+
+def _f32(t):
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t.detach().contiguous()
+
+
+def _i64(t):
+    if t.dtype != torch.int64:
+        t = t.long()
+    return t.contiguous()
+
+
+def furthest_point_sample(xyz, npoint):
+    """xyz (B,N,3) float -> (B,npoint) int64 indices; starts at point 0, ties -> lowest index."""
+    if xyz.dim() != 3 or xyz.shape[2] != 3:
+        raise ValueError("xyz must be (B, N, 3), got %s" % (tuple(xyz.shape),))
+    if npoint > xyz.shape[1]:
+        raise ValueError("caanot sample %i points from an input set of %i points" % (npoint, xyz.shape[1]))
+    dev = _dev(xyz)
+    xyz = _f32(xyz)
+    B, N, _ = xyz.shape
+    out = torch.empty((B, npoint), dtype=torch.int64, device=dev)
+    scratch = None
+    if N > 32768:  # TP3D_FPS_MAX_REG_POINTS: larger clouds keep the running min-distance in HBM
+        scratch = torch.empty((B, N), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        _lib.call("tp3d_fps_f32", _lib.ptr(xyz), B, N, int(npoint), _lib.ptr(scratch), _lib.ptr(out),
+                  _lib.stream_ptr(dev))
+    return out
+
+
+def ball_query(radius, nsample, x, y, mode="dense", batch_x=None, batch_y=None, sort=False):
+    """Radius search of the support `x` around the queries `y`.
+
+    dense:          x (B,N,3), y (B,np,3)  -> idx (B,np,nsample) int64, dist2 (B,np,nsample); pad = first hit
+    partial_dense:  x (M,3), y (Nq,3) + sorted batch vectors -> idx (Nq,nsample) global rows, pad = -1
+    """
+    if mode is None:
+        raise Exception('The mode should be defined within ["partial_dense | dense"]')
+    m = mode.lower()
+    if m == "partial_dense":
+        if batch_x is None or batch_y is None:
+            raise Exception("batch_x and batch_y should be provided")
+        if x.dim() != 2 or y.dim() != 2:
+            raise ValueError("partial_dense expects x (M,3) and y (Nq,3)")
+        dev = _dev(x, y, batch_x, batch_y)
+        x, y = _f32(x), _f32(y)
+        bx, by = _i64(batch_x), _i64(batch_y)
+        if bx.numel() != x.shape[0] or by.numel() != y.shape[0]:
+            raise ValueError("batch vectors must have one entry per point")
+        if bx.numel() > 1 and bool((bx[1:] < bx[:-1]).any()):
+            raise ValueError("batch_x must be sorted")
+        Nq = y.shape[0]
+        idx = torch.empty((Nq, nsample), dtype=torch.int64, device=dev)
+        d2 = torch.empty((Nq, nsample), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            _lib.call("tp3d_ball_query_partial_dense_f32", _lib.ptr(x), _lib.ptr(y), _lib.ptr(bx), _lib.ptr(by),
+                      x.shape[0], Nq, float(radius), int(nsample), int(bool(sort)), _lib.ptr(idx), _lib.ptr(d2),
+                      _lib.stream_ptr(dev))
+        return idx, d2
+    if m == "dense":
+        if batch_x is not None or batch_y is not None:
+            raise Exception("batch_x and batch_y should not be provided")
+        if x.dim() != 3 or y.dim() != 3:
+            raise ValueError("dense expects x (B,N,3) and y (B,np,3)")
+        dev = _dev(x, y)
+        x, y = _f32(x), _f32(y)
+        B, N, _ = x.shape
+        np_ = y.shape[1]
+        idx = torch.empty((B, np_, nsample), dtype=torch.int64, device=dev)
+        d2 = torch.empty((B, np_, nsample), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            _lib.call("tp3d_ball_query_dense_f32", _lib.ptr(x), _lib.ptr(y), B, N, np_, float(radius), int(nsample),
+                      int(bool(sort)), _lib.ptr(idx), _lib.ptr(d2), _lib.stream_ptr(dev))
+        return idx, d2
+    raise Exception("unrecognized mode {}".format(mode))
+
+
+def three_nn(unknown, known):
+    """unknown (B,n,3), known (B,m,3) -> (dist (B,n,3) Euclidean, idx (B,n,3) int64)."""
+    if known.shape[1] < 3:
+        raise ValueError("Not enough points. unknown should ahve at least 3 points.")
+    dev = _dev(unknown, known)
+    unknown, known = _f32(unknown), _f32(known)
+    B, n, _ = unknown.shape
+    m = known.shape[1]
+    dist = torch.empty((B, n, 3), dtype=torch.float32, device=dev)
+    idx = torch.empty((B, n, 3), dtype=torch.int64, device=dev)
+    with torch.cuda.device(dev):
+        _lib.call("tp3d_three_nn_f32", _lib.ptr(unknown), _lib.ptr(known), B, n, m, _lib.ptr(dist), _lib.ptr(idx),
+                  _lib.stream_ptr(dev))
+    return dist, idx
+
+
+class _ThreeInterpolate(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, features, idx, weight):
+        dev = _dev(features, idx, weight)
+        features, weight, idx = _f32(features), _f32(weight), _i64(idx)
+        B, C, m = features.shape
+        n = idx.shape[1]
+        ctx.save_for_backward(idx, weight)
+        ctx.m = m
+        out = torch.empty((B, C, n), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            _lib.call("tp3d_three_interpolate_fwd_f32", _lib.ptr(features), _lib.ptr(idx), _lib.ptr(weight), B, C,
+                      m, n, _lib.ptr(out), _lib.stream_ptr(dev))
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        idx, weight = ctx.saved_tensors
+        dev = grad_out.device
+        grad_out = _f32(grad_out)
+        B, C, n = grad_out.shape
+        g = torch.empty((B, C, ctx.m), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            _lib.call("tp3d_three_interpolate_bwd_f32", _lib.ptr(grad_out), _lib.ptr(idx), _lib.ptr(weight), B, C,
+                      ctx.m, n, _lib.ptr(g), _lib.stream_ptr(dev))
+        return g, None, None
+
+
+def three_interpolate(features, idx, weight):
+    """features (B,C,m), idx (B,n,3), weight (B,n,3) -> (B,C,n); differentiable wrt features."""
+    return _ThreeInterpolate.apply(features, idx, weight)
+
+
+class _Grouping(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, features, idx):
+        dev = _dev(features, idx)
+        features, idx = _f32(features), _i64(idx)
+        B, C, N = features.shape
+        _, np_, ns = idx.shape
+        ctx.save_for_backward(idx)
+        ctx.N = N
+        out = torch.empty((B, C, np_, ns), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            _lib.call("tp3d_group_fwd_f32", _lib.ptr(features), _lib.ptr(idx), B, C, N, np_, ns, _lib.ptr(out),
+                      _lib.stream_ptr(dev))
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        (idx,) = ctx.saved_tensors
+        dev = grad_out.device
+        grad_out = _f32(grad_out)
+        B, C, np_, ns = grad_out.shape
+        g = torch.empty((B, C, ctx.N), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            _lib.call("tp3d_group_bwd_f32", _lib.ptr(grad_out), _lib.ptr(idx), B, C, ctx.N, np_, ns, _lib.ptr(g),
+                      _lib.stream_ptr(dev))
+        return g, None
+
+
+def grouping_operation(features, idx):
+    """features (B,C,N), idx (B,np,ns) -> (B,C,np,ns); differentiable wrt features."""
+    return _Grouping.apply(features, idx)
