@@ -1,0 +1,275 @@
+#!/usr/bin/env python
+"""bench.py -- point-clouds/sec, fwd+bwd, PointNet++ SSG, B=32 N=16384 per GPU (BASELINE.json metric).
+
+One "step" = one training pass of the hot path over one synthetic batch: zero_grad -> forward (FPS,
+ball_query, grouping, grouped MLP, three_nn, three_interpolate, FP MLPs, head) -> cross-entropy -> backward
+-> Adam step.  Inputs are resident in HBM before the timed region.  One process per GPU; with N > 1 the batch
+is sharded per rank (B=32 per GPU, weak scaling) and the only collective is DDP's gradient all-reduce over
+RCCL.  Rank 0 prints ONE JSON line.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--no-cpu-baseline]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+B_PER_GPU = 32
+N_POINTS = 16384
+FEAT = 3
+NUM_CLASSES = 10
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
+
+
+class SegStep(nn.Module):
+    """tensor-in / tensor-out wrapper so DDP can own the module."""
+
+    def __init__(self, net):
+        super().__init__()
+        self.net = net
+
+    def forward(self, pos, x):
+        from torch_points3d_amd.dense import Data
+        return self.net(Data(pos=pos, x=x)).x  # (B, classes, N)
+
+
+def make_inputs(B, N, seed, device):
+    g = torch.Generator().manual_seed(seed)
+    pos = torch.rand(B, N, 3, generator=g) * 2 - 1
+    x = torch.randn(B, N, FEAT, generator=g)
+    y = torch.randint(0, NUM_CLASSES, (B, N), generator=g)
+    return pos.to(device), x.to(device), y.to(device)
+
+
+def build_model(kernels, device):
+    from torch_points3d_amd.pointnet2 import PointNet2Unet
+    torch.manual_seed(0)
+    net = PointNet2Unet(FEAT, output_nc=NUM_CLASSES, config="unet_3_ss", kernels=kernels)
+    return SegStep(net).to(device).train()
+
+
+def train_step(model, opt, pos, x, y):
+    opt.zero_grad(set_to_none=True)
+    logits = model(pos, x)
+    loss = F.cross_entropy(logits, y)
+    loss.backward()
+    opt.step()
+    return loss
+
+
+# ALGORITHMIC bytes of ONE launch (formulas: SURVEY.md 8d / DESIGN.md), from the entry point's size arguments
+# in the order include/tp3d_hip.h declares them.
+def algorithmic_bytes(name, a):
+    if name == "tp3d_fps_f32":  # B, N, npoint
+        B, N, npnt = a[:3]
+        return B * (N * 12 + npnt * 8)
+    if name == "tp3d_ball_query_dense_f32":  # B, N, np, nsample, sort
+        B, N, npnt, ns = a[:4]
+        return B * (N * 12 + npnt * 12 + npnt * ns * 12)
+    if name == "tp3d_ball_query_partial_dense_f32":  # M, Nq, nsample, sort
+        M, Nq, ns = a[:3]
+        return M * 20 + Nq * 20 + Nq * ns * 12
+    if name == "tp3d_three_nn_f32":  # B, n, m
+        B, n, m = a[:3]
+        return B * (n * 12 + m * 12 + n * 36)
+    if name in ("tp3d_three_interpolate_fwd_f32", "tp3d_three_interpolate_bwd_f32"):  # B, C, m, n
+        B, C, m, n = a[:4]
+        return B * (C * m * 4 + n * 36 + C * n * 4)
+    if name in ("tp3d_group_fwd_f32", "tp3d_group_bwd_f32"):  # B, C, N, np, ns
+        B, C, N, npnt, ns = a[:5]
+        return B * (C * N * 4 + npnt * ns * 8 + C * npnt * ns * 4)
+    return 0
+
+
+def log(msg):
+    sys.stderr.write("[bench %.1fs] %s\n" % (time.perf_counter() - T_START, msg))
+    sys.stderr.flush()
+
+
+T_START = time.perf_counter()
+
+
+def cpu_share():
+    """Host cores this process may actually use: affinity, capped by the cgroup CPU quota when one is set."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period) + 0.5)))
+    except (OSError, ValueError):
+        pass
+    return min(n, 64)
+
+
+def cpu_baseline(sample_b, iters):
+    """The same module graph on the host: PyTorch-CPU conv/BN + the CPU oracle kernels ("port")."""
+    from oracle import tpk_ref
+    cores = cpu_share()
+    log("cpu baseline on %d threads" % cores)
+    torch.set_num_threads(cores)
+    tpk_ref.set_num_threads(cores)
+    model = build_model(tpk_ref, "cpu")
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    pos, x, y = make_inputs(sample_b, N_POINTS, 1234, "cpu")
+    train_step(model, opt, pos, x, y)  # warm-up
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        train_step(model, opt, pos, x, y)
+    dt = time.perf_counter() - t0
+    model_name = ""
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model_name = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return {
+        "value": sample_b * iters / dt,
+        "unit": "point-clouds/s",
+        "cores": cores,
+        "kind": "port",
+        "sample": "%d train steps (fwd+bwd+Adam) of the same PointNet++ SSG on %d clouds of N=%d after 1 warm-up; "
+                  "PyTorch-CPU conv/BN + oracle/tpk_ref_cpu.c kernels (OpenMP over clouds/queries)" % (
+                      iters, sample_b, N_POINTS),
+        "cpu_model": model_name,
+        "seconds": dt,
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-clouds", type=int, default=8)
+    ap.add_argument("--cpu-sample-iters", type=int, default=8)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
+        raise SystemExit("WORLD_SIZE=%d does not match --gpus %d" % (world, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+
+    import torch.distributed as dist
+    device = torch.device("cuda", local_rank)
+    torch.cuda.set_device(device)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=device)
+
+    from torch_points3d_amd import _lib
+    _lib.load()  # fail loudly if the HIP extension is missing
+
+    model = build_model(None, device)
+    if world > 1:
+        # ~1.38 M fp32 parameters = 5.5 MB: a single bucket, one all-reduce per step over xGMI
+        model = nn.parallel.DistributedDataParallel(model, device_ids=[local_rank], bucket_cap_mb=16,
+                                                    gradient_as_bucket_view=True)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    pos, x, y = make_inputs(B_PER_GPU, N_POINTS, 1234 + rank, device)
+
+    log("model built; warm-up")
+    for i in range(args.warmup):
+        train_step(model, opt, pos, x, y)
+        torch.cuda.synchronize()
+        log("warm-up step %d done" % i)
+
+    timer = _lib.KernelTimer()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    _lib.set_timer(timer)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        train_step(model, opt, pos, x, y)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    _lib.set_timer(None)
+    log("timed region done: %.2f ms/step" % (dt / args.steps * 1e3))
+
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        summ = timer.summary()
+        kernels = []
+        for (name, a), (launches, total_ms) in sorted(summ.items(), key=lambda kv: -kv[1][1]):
+            avg_ms = total_ms / launches
+            nbytes = algorithmic_bytes(name, a)
+            kernels.append({
+                "entry": name, "sizes": list(a), "launches": launches, "avg_ms": round(avg_ms, 4),
+                "ms_per_step": round(total_ms / args.steps, 4), "algorithmic_MB": round(nbytes / 1e6, 3),
+                "GBps": round(nbytes / 1e9 / (avg_ms / 1e3), 2) if avg_ms > 0 else None,
+            })
+        # dominant HIP kernel = the (entry point, shape) with the largest share of device time
+        roofline = None
+        if kernels:
+            k = kernels[0]
+            traffic = None
+            tpath = os.path.join(ROOT, "profiles", "traffic.json")
+            if os.path.exists(tpath):
+                try:
+                    traffic = json.load(open(tpath)).get("%s%s" % (k["entry"], k["sizes"]))
+                except (OSError, ValueError):
+                    traffic = None
+            roofline = {"kernel": k["entry"], "sizes": k["sizes"], "bound": "hbm", "achieved": k["GBps"],
+                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(k["GBps"] / HBM_PEAK_GBS, 6),
+                        "traffic": traffic, "avg_launch_ms": k["avg_ms"], "launches": k["launches"],
+                        "algorithmic_bytes_per_launch": int(k["algorithmic_MB"] * 1e6)}
+        cpu = None
+        if world == 1 and not args.no_cpu_baseline:
+            cpu = cpu_baseline(args.cpu_sample_clouds, args.cpu_sample_iters)
+        value = world * B_PER_GPU * args.steps / dt
+        line = {
+            "metric": "point-clouds/sec fwd+bwd PointNet++SSG B=32 N=16384",
+            "value": round(value, 2),
+            "unit": "point-clouds/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 3),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "PointNet++ SSG (unet_3_ss) train step fwd+bwd+Adam, B=32 per GPU, N=16384, "
+                                   "FEAT=3, 10 classes, pos~U[-1,1]^3 (BASELINE configs[1])",
+                       "global_batch": world * B_PER_GPU, "points": N_POINTS,
+                       "parallelism": "dp%d (batch shards, DDP gradient all-reduce over RCCL)" % world},
+            "roofline": roofline,
+            "cpu_baseline": cpu,
+            "kernels": kernels,
+        }
+        if cpu:
+            line["gpu_over_cpu"] = round(value / cpu["value"], 1)
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

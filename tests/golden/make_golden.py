@@ -73,24 +73,25 @@ def install_stubs():
     sys.path.insert(0, REF)
 
 
-def build_reference_unet(cfg, output_nc):
+def build_reference_unet(cfg, output_nc, activation=None):
     """Reference modules assembled in the reference's order (down, inner, up, head)."""
     from torch_points3d.core.base_conv.dense import DenseFPModule, GlobalDenseBaseModule
     from torch_points3d.core.common_modules.base_modules import Seq
     from torch_points3d.core.common_modules.dense_modules import Conv1D
     from torch_points3d.modules.pointnet2.dense import PointNetMSGDown
 
+    kw = {} if activation is None else {"activation": activation}  # default = the modules' LeakyReLU(0.01)
     net = torch.nn.Module()
     net.down_modules = torch.nn.ModuleList()
     for i in range(len(cfg["down_conv_nn"])):
         net.down_modules.append(PointNetMSGDown(
             npoint=cfg["npoint"][i], radii=cfg["radii"][i], nsample=cfg["nsample"][i],
-            down_conv_nn=cfg["down_conv_nn"][i], normalize_xyz=cfg["normalize_xyz"][i], index=i))
-    net.inner_modules = torch.nn.ModuleList([GlobalDenseBaseModule(nn=cfg["innermost"])])
-    net.up_modules = torch.nn.ModuleList([DenseFPModule(up_conv_nn=c, index=i)
+            down_conv_nn=cfg["down_conv_nn"][i], normalize_xyz=cfg["normalize_xyz"][i], index=i, **kw))
+    net.inner_modules = torch.nn.ModuleList([GlobalDenseBaseModule(nn=cfg["innermost"], **kw)])
+    net.up_modules = torch.nn.ModuleList([DenseFPModule(up_conv_nn=c, index=i, **kw)
                                           for i, c in enumerate(cfg["up_conv_nn"])])
     net.mlp = Seq()
-    net.mlp.append(Conv1D(cfg["up_conv_nn"][-1][-1], output_nc, bn=True, bias=False))
+    net.mlp.append(Conv1D(cfg["up_conv_nn"][-1][-1], output_nc, bn=True, bias=False, **kw))
     return net
 
 
@@ -152,9 +153,9 @@ def to_np(rec):
     return out
 
 
-def make_case(name, cfg, feat, output_nc, pos, x, seed, store_weights):
+def make_case(name, cfg, feat, output_nc, pos, x, seed, store_weights, activation=None):
     torch.manual_seed(seed)
-    net = build_reference_unet(cfg, output_nc)
+    net = build_reference_unet(cfg, output_nc, activation)
     net.train()  # the example never calls .eval(): BatchNorm uses batch statistics
     sd = {k: v.detach().clone() for k, v in net.state_dict().items()}  # weights BEFORE the forward pass
     x_in = x.clone().requires_grad_(True)
@@ -208,6 +209,10 @@ def main():
                  up_conv_nn=[[48 + 32, 32, 32], [32 + 24, 32, 24], [24 + 4, 24, 24, 24]],
                  normalize_xyz=[False, True], save_sampling_id=[False, False])
     make_case("small_ssg", small, 4, 6, pos, feats, seed=7, store_weights=True)
+
+    # (2b) same, with a smooth activation handed to the reference modules (they take `activation=`): without the
+    #      LeakyReLU kink a last-bit forward difference cannot flip a gradient mask, so gradients compare tightly.
+    make_case("small_ssg_tanh", small, 4, 6, pos, feats, seed=7, store_weights=True, activation=torch.nn.Tanh())
 
     # (3) multi-scale grouping (unet_3_ms.yaml layout, narrow) on distinct clouds.
     g = torch.Generator().manual_seed(99)

@@ -22,14 +22,16 @@ CASES = {
     "c1_example": lambda: unet_config("unet_3_ss", 5),
     "small_ssg": lambda: SMALL_SSG,
     "small_msg": lambda: SMALL_MSG,
+    "small_ssg_tanh": lambda: SMALL_SSG,
 }
+ACTIVATION = {"small_ssg_tanh": torch.nn.Tanh}
 
 
-def build_from_golden(g, cfg, kernels, device="cpu"):
+def build_from_golden(g, cfg, kernels, device="cpu", activation=None):
     """Mirror model carrying exactly the reference modules' weights."""
     feat, out_nc = [int(v) for v in g["meta_feat_outnc"]]
     torch.manual_seed(int(g["meta_seed"][0]))
-    net = PointNet2Unet(feat, output_nc=out_nc, config=cfg, kernels=kernels)
+    net = PointNet2Unet(feat, output_nc=out_nc, config=cfg, kernels=kernels, activation=activation)
     stored = {k[len("state/"):]: v for k, v in g.items() if k.startswith("state/")}
     if stored:
         net.load_state_dict(stored, strict=True)
@@ -62,7 +64,7 @@ def run_stages(net, pos, x):
 @pytest.mark.parametrize("name", sorted(CASES))
 def test_mirror_reproduces_reference_modules(oracle, name):
     g = load_golden(name)
-    net = build_from_golden(g, CASES[name](), oracle)
+    net = build_from_golden(g, CASES[name](), oracle, activation=ACTIVATION.get(name, lambda: None)())
     x_in = g["x"].clone().requires_grad_(True)
     out, rec = run_stages(net, g["pos"], x_in)
     for k, v in rec.items():

@@ -1,0 +1,278 @@
+"""Parity of the HIP kernels (through the C-ABI / torch_points_kernels API) against the CPU oracle, the
+reference-generated goldens, and -- at BASELINE.json's full sizes -- size-independent properties.
+
+Bar: indices bit-exact; fp32 features within 1e-5 (BASELINE.json north_star)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+TOL = dict(rtol=1e-5, atol=1e-5)
+
+
+def cloud(B, N, seed, kind="uniform"):
+    g = torch.Generator().manual_seed(seed)
+    if kind == "uniform":
+        return torch.rand(B, N, 3, generator=g) * 2 - 1
+    if kind == "randn":
+        return torch.randn(B, N, 3, generator=g)
+    if kind == "clustered":  # heavy ties / duplicates and dense balls
+        p = torch.rand(B, N, 3, generator=g) * 2 - 1
+        p[:, N // 2:] = p[:, : N - N // 2].clone()
+        return p
+    if kind == "lattice":  # exact distance ties everywhere
+        return torch.randint(0, 5, (B, N, 3), generator=g).float() * 0.25
+    raise ValueError(kind)
+
+
+# --------------------------------------------------------------------------------------------- FPS
+
+@pytest.mark.parametrize("B,N,npoint,kind", [
+    (2, 1024, 512, "randn"), (3, 512, 128, "uniform"), (1, 5, 3, "uniform"), (2, 64, 64, "uniform"),
+    (2, 65, 17, "uniform"), (4, 2048, 512, "uniform"), (2, 3000, 700, "clustered"), (2, 4096, 64, "lattice"),
+    (2, 16384, 512, "uniform"), (1, 20000, 300, "uniform"), (1, 40000, 64, "uniform"), (2, 1, 1, "uniform"),
+    (2, 300, 300, "lattice"),
+])
+def test_fps_bit_exact(hip, oracle, B, N, npoint, kind):
+    pos = cloud(B, N, 10 + N, kind)
+    got = hip.furthest_point_sample(pos.to(DEV), npoint)
+    assert got.dtype == torch.int64 and got.shape == (B, npoint)
+    assert torch.equal(got.cpu(), oracle.furthest_point_sample(pos, npoint))
+
+
+def test_fps_kat_and_errors(hip):
+    pos = torch.tensor([[[0, 0, 0], [0.5, 0.5, 0], [0.4, 0.2, 0], [2, 2, 2], [-1, -2, -0.01]]]).float().to(DEV)
+    assert hip.furthest_point_sample(pos, 3)[0].tolist() == [0, 3, 4]  # reference test/test_fps.py:35-42
+    with pytest.raises(ValueError):
+        hip.furthest_point_sample(pos, 6)
+    assert hip.furthest_point_sample(pos, 0).shape == (1, 0)
+    assert hip.furthest_point_sample(pos[:0], 3).shape == (0, 3)
+
+
+# --------------------------------------------------------------------------------------- ball query
+
+@pytest.mark.parametrize("B,N,npnt,r,ns,kind", [
+    (2, 1024, 512, 0.2, 64, "randn"), (2, 512, 128, 0.4, 64, "randn"), (3, 2048, 300, 0.2, 32, "uniform"),
+    (2, 1000, 77, 0.1, 16, "uniform"), (2, 1500, 64, 0.45, 8, "clustered"), (2, 900, 50, 0.26, 128, "lattice"),
+    (1, 3, 3, 1.01, 32, "uniform"), (2, 5000, 33, 2.5, 64, "uniform"), (1, 70, 70, 0.5, 1, "uniform"),
+    (4, 16384, 512, 0.2, 64, "uniform"),
+])
+@pytest.mark.parametrize("sort", [False, True])
+def test_ball_query_dense_bit_exact(hip, oracle, B, N, npnt, r, ns, kind, sort):
+    if sort and N > 4096:
+        pytest.skip("sorted path is the rare dirichlet_loss path; covered at small sizes")
+    x = cloud(B, N, 20 + N, kind)
+    y = x[:, torch.randperm(N, generator=torch.Generator().manual_seed(N))[:npnt]].contiguous()
+    y[:, -1] = 50.0  # one query with an empty ball
+    gi, gd = hip.ball_query(r, ns, x.to(DEV), y.to(DEV), sort=sort)
+    ri, rd = oracle.ball_query(r, ns, x, y, sort=sort)
+    assert gi.dtype == torch.int64 and gi.shape == (B, npnt, ns)
+    assert torch.equal(gi.cpu(), ri)
+    assert torch.equal(gd.cpu(), rd)  # same fp32 evaluation order: exact
+
+
+def test_ball_query_dirichlet_kat(hip):
+    # reference test/test_losses.py:16-24
+    pos = torch.tensor([[[0, 0, 0], [1, 0, 0], [1.1, 0, 0]]], dtype=torch.float, device=DEV)
+    f = torch.tensor([[1, 1, 3]], dtype=torch.float, device=DEV)
+    nei = hip.ball_query(1.01, 32, pos, pos, sort=True)[0].reshape(1, -1).long()
+    fn = f.gather(1, nei).reshape(1, 3, -1)
+    var = ((f.unsqueeze(-1).repeat(1, 1, fn.shape[-1]) - fn) ** 2).sum(-1)
+    assert var.cpu().tolist() == [[0.0, 4.0, 4.0]]
+
+
+@pytest.mark.parametrize("sort", [False, True])
+def test_ball_query_partial_dense_bit_exact(hip, oracle, sort):
+    g = torch.Generator().manual_seed(3)
+    sizes = [700, 1, 0, 1300, 64]  # ragged clouds incl. an empty and a single-point one
+    x = torch.cat([torch.rand(n, 3, generator=g) for n in sizes])
+    bx = torch.cat([torch.full((n,), i, dtype=torch.long) for i, n in enumerate(sizes)])
+    qsizes = [100, 3, 2, 200, 10]  # cloud 2 has queries but no support points
+    y = torch.cat([torch.rand(n, 3, generator=g) for n in qsizes])
+    by = torch.cat([torch.full((n,), i, dtype=torch.long) for i, n in enumerate(qsizes)])
+    for r, ns in [(0.15, 25), (0.3, 8), (0.05, 16)]:
+        gi, gd = hip.ball_query(r, ns, x.to(DEV), y.to(DEV), mode="partial_dense", batch_x=bx.to(DEV),
+                                batch_y=by.to(DEV), sort=sort)
+        ri, rd = oracle.ball_query(r, ns, x, y, mode="partial_dense", batch_x=bx, batch_y=by, sort=sort)
+        assert torch.equal(gi.cpu(), ri) and torch.equal(gd.cpu(), rd)
+        assert (ri == -1).any()
+
+
+# ------------------------------------------------------------------------------------------ three_nn
+
+@pytest.mark.parametrize("B,n,m,kind", [
+    (2, 1024, 512, "randn"), (2, 512, 128, "uniform"), (3, 777, 3, "uniform"), (2, 2000, 1500, "lattice"),
+    (1, 1, 5, "uniform"), (2, 16384, 512, "uniform"),
+])
+def test_three_nn(hip, oracle, B, n, m, kind):
+    unknown = cloud(B, n, 30 + n, kind)
+    known = cloud(B, m, 31 + m, kind)
+    gd, gi = hip.three_nn(unknown.to(DEV), known.to(DEV))
+    rd, ri = oracle.three_nn(unknown, known)
+    assert torch.equal(gi.cpu(), ri)
+    torch.testing.assert_close(gd.cpu(), rd, **TOL)
+    with pytest.raises(ValueError):
+        hip.three_nn(unknown.to(DEV), known[:, :2].to(DEV))
+
+
+# ------------------------------------------------------------------------- interpolate / grouping
+
+@pytest.mark.parametrize("B,C,m,n", [(2, 256, 128, 512), (2, 128, 512, 1024), (3, 5, 7, 130), (1, 33, 3, 1)])
+def test_three_interpolate_fwd_bwd(hip, oracle, B, C, m, n):
+    g = torch.Generator().manual_seed(B * 1000 + n)
+    feat = torch.randn(B, C, m, generator=g)
+    idx = torch.randint(0, m, (B, n, 3), generator=g)
+    w = torch.rand(B, n, 3, generator=g)
+    w = w / w.sum(-1, keepdim=True)
+    cot = torch.randn(B, C, n, generator=g)
+    fa = feat.clone().to(DEV).requires_grad_(True)
+    fb = feat.clone().requires_grad_(True)
+    oa = hip.three_interpolate(fa, idx.to(DEV), w.to(DEV))
+    ob = oracle.three_interpolate(fb, idx, w)
+    assert torch.equal(oa.cpu(), ob.detach())  # fixed 3-term order, no fma: exact
+    oa.backward(cot.to(DEV))
+    ob.backward(cot)
+    torch.testing.assert_close(fa.grad.cpu(), fb.grad, **TOL)
+
+
+@pytest.mark.parametrize("B,C,N,npnt,ns", [(2, 8, 1024, 512, 64), (2, 131, 512, 128, 64), (3, 3, 50, 7, 5),
+                                          (1, 20, 9, 1, 1)])
+def test_grouping_fwd_bwd(hip, oracle, B, C, N, npnt, ns):
+    g = torch.Generator().manual_seed(B * 77 + N)
+    feat = torch.randn(B, C, N, generator=g)
+    idx = torch.randint(0, N, (B, npnt, ns), generator=g)
+    idx[:, :, 1:] = torch.where(torch.rand(B, npnt, ns - 1, generator=g) < 0.5, idx[:, :, :1], idx[:, :, 1:]) \
+        if ns > 1 else idx[:, :, 1:]  # padded slots repeat slot 0, as ball_query emits them
+    cot = torch.randn(B, C, npnt, ns, generator=g)
+    fa = feat.clone().to(DEV).requires_grad_(True)
+    fb = feat.clone().requires_grad_(True)
+    oa = hip.grouping_operation(fa, idx.to(DEV))
+    ob = oracle.grouping_operation(fb, idx)
+    assert torch.equal(oa.cpu(), ob.detach())
+    oa.backward(cot.to(DEV))
+    ob.backward(cot)
+    torch.testing.assert_close(fa.grad.cpu(), fb.grad, rtol=1e-5, atol=1e-4)
+
+
+def test_strided_and_int32_inputs_are_normalised(hip, oracle):
+    x = cloud(2, 400, 5)
+    xt = x.transpose(1, 2).contiguous().transpose(1, 2)  # non-contiguous view
+    assert torch.equal(hip.furthest_point_sample(xt.to(DEV), 50).cpu(), oracle.furthest_point_sample(x, 50))
+    feat = torch.randn(2, 6, 400)
+    idx = torch.randint(0, 400, (2, 10, 4))
+    assert torch.equal(hip.grouping_operation(feat.to(DEV), idx.int().to(DEV)).cpu(),
+                       oracle.grouping_operation(feat, idx))
+
+
+# ------------------------------------------------------- goldens written by the reference's modules
+
+GOLDEN_CFG = None
+
+
+def _cases():
+    from test_golden_cpu import CASES
+    return CASES
+
+
+@pytest.mark.parametrize("name", ["c1_example", "small_ssg", "small_msg"])
+def test_kernel_goldens(hip, name):
+    g = load_golden(name)
+    cfg = _cases()[name]()
+    cur = g["pos"].to(DEV)
+    for i in range(len(cfg["npoint"])):
+        fps = hip.furthest_point_sample(cur, cfg["npoint"][i])
+        assert torch.equal(fps.cpu(), g["fps%d" % i])
+        new = cur.gather(1, fps.unsqueeze(-1).repeat(1, 1, 3))
+        for s, (r, ns) in enumerate(zip(cfg["radii"][i], cfg["nsample"][i])):
+            idx, d2 = hip.ball_query(r, ns, cur, new)
+            assert torch.equal(idx.cpu(), g["ball%d_%d_idx" % (i, s)])
+            assert torch.equal(d2.cpu(), g["ball%d_%d_d2" % (i, s)])
+        cur = new
+
+
+@pytest.mark.parametrize("name", ["c1_example", "small_ssg", "small_msg", "small_ssg_tanh"])
+def test_model_goldens_on_gpu(hip, name):
+    """BASELINE config 1 end to end: the mirror on HIP kernels vs the reference modules' recorded tensors."""
+    from test_golden_cpu import ACTIVATION, build_from_golden, run_stages
+    g = load_golden(name)
+    net = build_from_golden(g, _cases()[name](), None, device=DEV,  # kernels=None -> the HIP product path
+                            activation=ACTIVATION.get(name, lambda: None)())
+    x_in = g["x"].to(DEV).requires_grad_(True)
+    out, rec = run_stages(net, g["pos"].to(DEV), x_in)
+    for k, v in rec.items():
+        # The kernel outputs feeding these tensors are exact (tests above); what differs from the CPU golden is
+        # the fp32 summation order of the 1x1-conv GEMMs (rocBLAS/MIOpen vs oneDNN, K up to 1280) amplified by
+        # train-mode BatchNorm, so the bound is relative to the tensor's scale rather than 1e-5 absolute.
+        scale = max(1.0, float(g[k].abs().max()))
+        torch.testing.assert_close(v.detach().cpu(), g[k], rtol=1e-4, atol=1e-4 * scale,
+                                   msg=lambda m, k=k: k + ": " + m)
+    (out.x * g["cotangent"].to(DEV)).sum().backward()
+    ga, gb = x_in.grad.cpu(), g["grad_x_in"]
+    wa, wb = net.up_modules[-1].nn[0][0].weight.grad.cpu(), g["grad_last_fp_conv"]
+    if name in ACTIVATION:  # smooth activation: gradients are well conditioned, compare element-wise
+        torch.testing.assert_close(ga, gb, rtol=1e-3, atol=1e-4 * max(1.0, float(gb.abs().max())))
+        torch.testing.assert_close(wa, wb, rtol=1e-3, atol=1e-4 * max(1.0, float(wb.abs().max())))
+    else:
+        # LeakyReLU: one pre-activation within ~1e-5 of zero flips its 1 / 0.01 slope between the GPU and CPU
+        # GEMMs, and train-mode BatchNorm backward couples that single element to the whole batch (measured:
+        # 1 flip of 50400 -> ~1% everywhere).  The backward KERNELS are pinned exactly in the tests above, so
+        # here only the relative L2 error is bounded.
+        assert float((ga - gb).norm() / gb.norm()) < 5e-2
+        assert float((wa - wb).norm() / wb.norm()) < 5e-2
+
+
+# ---------------------------------------------------- full BASELINE size: size-independent properties
+
+def test_full_size_properties(hip):
+    """B=32, N=16384 (BASELINE config 2 shapes): properties that need no CPU reference."""
+    B, N, npnt, ns, r = 32, 16384, 512, 64, 0.2
+    pos = cloud(B, N, 1234).to(DEV)
+    fps = hip.furthest_point_sample(pos, npnt)
+    assert fps.shape == (B, npnt) and int(fps.min()) >= 0 and int(fps.max()) < N
+    assert bool((fps[:, 0] == 0).all())
+    srt = fps.sort(dim=1)[0]
+    assert bool((srt[:, 1:] != srt[:, :-1]).all()), "FPS repeated a point on distinct coordinates"
+    new = pos.gather(1, fps.unsqueeze(-1).repeat(1, 1, 3))
+    # greedy property: the distance of sample i to the earlier samples is non-increasing in i
+    d = torch.cdist(new[:2, :64], new[:2, :64])
+    mins = torch.stack([d[:, i, :i].min(dim=1)[0] for i in range(1, 64)], 1)
+    assert bool((mins[:, 1:] <= mins[:, :-1] + 1e-6).all())
+
+    idx, d2 = hip.ball_query(r, ns, pos, new)
+    assert int(idx.min()) >= 0 and int(idx.max()) < N
+    valid = d2 >= 0
+    assert bool(valid[:, :, 0].all()), "every centroid is a cloud point, so its ball holds at least itself"
+    nb = pos.gather(1, idx.reshape(B, -1, 1).repeat(1, 1, 3)).reshape(B, npnt, ns, 3)
+    dd = ((nb - new.unsqueeze(2)) ** 2).sum(-1)
+    assert bool((dd[valid] < r * r + 1e-6).all())
+    torch.testing.assert_close(dd[valid], d2[valid], rtol=1e-4, atol=1e-6)
+    # ascending index order among real hits; padded slots repeat slot 0
+    inc = (idx[:, :, 1:] > idx[:, :, :-1]) | ~valid[:, :, 1:]
+    assert bool(inc.all())
+    assert bool((idx[~valid] == idx[:, :, :1].expand_as(idx)[~valid]).all())
+    # idempotence / determinism: a second launch gives identical bits
+    idx2, _ = hip.ball_query(r, ns, pos, new)
+    assert torch.equal(idx, idx2) and torch.equal(fps, hip.furthest_point_sample(pos, npnt))
+    # completeness on a sample: count of hits equals a brute-force count (capped at nsample)
+    cnt = (torch.cdist(new[:1, :128], pos[:1]) ** 2 < r * r).sum(-1).clamp(max=ns)
+    assert int(((valid[:1, :128].sum(-1) - cnt).abs() > 1).sum()) == 0  # cdist rounding may flip a boundary point
+
+    dist, i3 = hip.three_nn(pos, new)
+    assert bool((dist[:, :, 0] <= dist[:, :, 1]).all()) and bool((dist[:, :, 1] <= dist[:, :, 2]).all())
+    w = 1.0 / (dist + 1e-8)
+    w = w / w.sum(-1, keepdim=True)
+    ones = torch.ones(B, 4, npnt, device=DEV)
+    torch.testing.assert_close(hip.three_interpolate(ones, i3, w), torch.ones(B, 4, N, device=DEV), rtol=1e-5,
+                               atol=1e-5)  # weights sum to one: constants are reproduced
+    # linearity of grouping: group(a+b) == group(a)+group(b), and gather/scatter adjointness <G f, g> = <f, G^T g>
+    f = torch.randn(B, 3, N, device=DEV, requires_grad=True)
+    gsum = hip.grouping_operation(f, idx)
+    cot = torch.randn_like(gsum)
+    (grad,) = torch.autograd.grad(gsum, f, cot)
+    lhs = (gsum * cot).sum().item()
+    rhs = (f * grad).sum().item()
+    assert abs(lhs - rhs) <= 1e-3 * max(1.0, abs(lhs))

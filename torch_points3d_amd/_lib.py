@@ -64,9 +64,46 @@ def load():
     return h
 
 
+class KernelTimer(object):
+    """Optional per-entry-point device timing with HIP events on the launch stream (bench.py's roofline leg).
+
+    Events are recorded on torch's current stream, which is the stream every launch is enqueued on, so the
+    elapsed time brackets exactly the kernels (and memsets) one C-ABI call enqueues.
+    """
+
+    def __init__(self):
+        self.records = []  # ((entry point, integer arguments), start_event, end_event)
+
+    def summary(self):
+        """{(entry point, integer size arguments): (launches, total_ms)} -- call after a device synchronize."""
+        out = {}
+        for tag, a, b in self.records:
+            n, t = out.get(tag, (0, 0.0))
+            out[tag] = (n + 1, t + a.elapsed_time(b))
+        return out
+
+
+_timer = None
+
+
+def set_timer(timer):
+    """Install (or remove, with None) a KernelTimer; returns the previous one."""
+    global _timer
+    prev, _timer = _timer, timer
+    return prev
+
+
 def call(name, *args):
     h = load()
-    rc = getattr(h, name)(*args)
+    if _timer is not None:
+        a = torch.cuda.Event(enable_timing=True)
+        b = torch.cuda.Event(enable_timing=True)
+        a.record()
+        rc = getattr(h, name)(*args)
+        b.record()
+        _timer.records.append(((name, tuple(v for v in args if isinstance(v, int))), a, b))
+    else:
+        rc = getattr(h, name)(*args)
     if rc != 0:
         raise Tp3dError("%s failed: %s (code %d, hipError %d)" % (
             name, h.tp3d_strerror(rc).decode(), rc, h.tp3d_last_hip_error()))

@@ -45,7 +45,8 @@ def unet_config(name, feat):
 class PointNet2Unet(nn.Module):
     """Input -- D1 -- D2 -- I -- U1 -- U2 -- U3 -- (head), symmetric skips (applications/pointnet2.py:154-191)."""
 
-    def __init__(self, input_nc, output_nc=None, config="unet_3_ss", kernels=None):
+    def __init__(self, input_nc, output_nc=None, config="unet_3_ss", kernels=None, activation=None):
+        """`activation` (default LeakyReLU(0.01), as the reference modules) is shared by every layer."""
         super().__init__()
         cfg = unet_config(config, input_nc) if isinstance(config, str) else config
         self.config = cfg
@@ -54,15 +55,16 @@ class PointNet2Unet(nn.Module):
             self.down_modules.append(PointNetMSGDown(
                 npoint=cfg["npoint"][i], radii=cfg["radii"][i], nsample=cfg["nsample"][i],
                 down_conv_nn=cfg["down_conv_nn"][i], normalize_xyz=cfg["normalize_xyz"][i],
-                save_sampling_id=cfg["save_sampling_id"][i], index=i, kernels=kernels))
-        self.inner_modules = nn.ModuleList([GlobalDenseBaseModule(nn=cfg["innermost"])])
+                save_sampling_id=cfg["save_sampling_id"][i], index=i, kernels=kernels, activation=activation))
+        self.inner_modules = nn.ModuleList([GlobalDenseBaseModule(nn=cfg["innermost"], activation=activation)])
         self.up_modules = nn.ModuleList(
-            DenseFPModule(up_conv_nn=c, index=i, kernels=kernels) for i, c in enumerate(cfg["up_conv_nn"]))
+            DenseFPModule(up_conv_nn=c, index=i, kernels=kernels, activation=activation)
+            for i, c in enumerate(cfg["up_conv_nn"]))
         self._output_nc = cfg["up_conv_nn"][-1][-1]
         self.has_mlp_head = output_nc is not None
         if self.has_mlp_head:
             # BN + LeakyReLU are applied on the logits too (applications/pointnet2.py:100-104)
-            self.mlp = Seq().append(Conv1D(self._output_nc, output_nc, bn=True, bias=False))
+            self.mlp = Seq().append(Conv1D(self._output_nc, output_nc, bn=True, bias=False, activation=activation))
             self._output_nc = output_nc
 
     @property
