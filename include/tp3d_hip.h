@@ -22,6 +22,7 @@
 #ifndef TP3D_HIP_H
 #define TP3D_HIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -34,7 +35,7 @@ extern "C" {
 #define TP3D_E_UNSORTED (-3) /* reserved: batch vector not sorted (checked by the host wrapper) */
 #define TP3D_E_TOOBIG (-4)   /* size exceeds what the kernel's index arithmetic supports */
 
-#define TP3D_ABI_VERSION 1
+#define TP3D_ABI_VERSION 2
 
 int tp3d_abi_version(void);
 const char *tp3d_strerror(int code);
@@ -81,22 +82,31 @@ int tp3d_three_nn_f32(const float *unknown, const float *known, int B, int n, in
 /*
  * three_interpolate(features, idx, weight)      [reference call: core/base_conv/dense.py:140]
  *   features (B,C,m), idx (B,n,3) int64, weight (B,n,3) -> out (B,C,n) = (w0*f0 + w1*f1) + w2*f2.
- *   bwd: grad_out (B,C,n) -> grad_features (B,C,m) (overwritten, not accumulated).
+ *   bwd: grad_out (B,C,n) -> grad_features (B,C,m) (overwritten, not accumulated); atomic-free and bitwise
+ *        reproducible; needs tp3d_scatter_workspace_bytes(B, 3*n, m, 1) bytes of device workspace.
  */
 int tp3d_three_interpolate_fwd_f32(const float *features, const int64_t *idx, const float *weight, int B, int C,
                                    int m, int n, float *out, void *stream);
 int tp3d_three_interpolate_bwd_f32(const float *grad_out, const int64_t *idx, const float *weight, int B, int C,
-                                   int m, int n, float *grad_features, void *stream);
+                                   int m, int n, float *grad_features, void *workspace, size_t workspace_bytes,
+                                   void *stream);
+
+/*
+ * Device workspace (bytes) of the two scatter-add backward entry points: the inverse index of an
+ * index table with L slots per cloud pointing into nbins destinations (+ the permuted weights).
+ */
+size_t tp3d_scatter_workspace_bytes(int B, int L, int nbins, int with_weights);
 
 /*
  * grouping_operation(features, idx)             [reference call: modules/pointnet2/dense.py:38,45]
  *   features (B,C,N), idx (B,np,ns) int64 -> out (B,C,np,ns); bwd scatters grad_out into (B,C,N)
- *   (overwritten, not accumulated).
+ *   (overwritten, not accumulated); atomic-free and bitwise reproducible; needs
+ *   tp3d_scatter_workspace_bytes(B, np*ns, N, 0) bytes of device workspace.
  */
 int tp3d_group_fwd_f32(const float *features, const int64_t *idx, int B, int C, int N, int np, int ns, float *out,
                        void *stream);
 int tp3d_group_bwd_f32(const float *grad_out, const int64_t *idx, int B, int C, int N, int np, int ns,
-                       float *grad_features, void *stream);
+                       float *grad_features, void *workspace, size_t workspace_bytes, void *stream);
 
 #ifdef __cplusplus
 }

@@ -121,7 +121,8 @@ def test_three_nn(hip, oracle, B, n, m, kind):
 
 # ------------------------------------------------------------------------- interpolate / grouping
 
-@pytest.mark.parametrize("B,C,m,n", [(2, 256, 128, 512), (2, 128, 512, 1024), (3, 5, 7, 130), (1, 33, 3, 1)])
+@pytest.mark.parametrize("B,C,m,n", [(2, 256, 128, 512), (2, 128, 512, 1024), (3, 5, 7, 130), (1, 33, 3, 1),
+                                     (2, 3, 512, 16384), (1, 2, 64, 40000), (2, 1, 9, 300)])
 def test_three_interpolate_fwd_bwd(hip, oracle, B, C, m, n):
     g = torch.Generator().manual_seed(B * 1000 + n)
     feat = torch.randn(B, C, m, generator=g)
@@ -136,11 +137,13 @@ def test_three_interpolate_fwd_bwd(hip, oracle, B, C, m, n):
     assert torch.equal(oa.cpu(), ob.detach())  # fixed 3-term order, no fma: exact
     oa.backward(cot.to(DEV))
     ob.backward(cot)
-    torch.testing.assert_close(fa.grad.cpu(), fb.grad, **TOL)
+    # transpose + gather-sum accumulates in the oracle's order (ascending (i,t), mul then add): exact
+    assert torch.equal(fa.grad.cpu(), fb.grad)
 
 
 @pytest.mark.parametrize("B,C,N,npnt,ns", [(2, 8, 1024, 512, 64), (2, 131, 512, 128, 64), (3, 3, 50, 7, 5),
-                                          (1, 20, 9, 1, 1)])
+                                          (1, 20, 9, 1, 1), (2, 3, 16384, 512, 64), (1, 2, 50000, 1100, 64),
+                                          (2, 1, 40, 30, 3), (1, 6, 70000, 64, 16)])
 def test_grouping_fwd_bwd(hip, oracle, B, C, N, npnt, ns):
     g = torch.Generator().manual_seed(B * 77 + N)
     feat = torch.randn(B, C, N, generator=g)
@@ -155,7 +158,9 @@ def test_grouping_fwd_bwd(hip, oracle, B, C, N, npnt, ns):
     assert torch.equal(oa.cpu(), ob.detach())
     oa.backward(cot.to(DEV))
     ob.backward(cot)
-    torch.testing.assert_close(fa.grad.cpu(), fb.grad, rtol=1e-5, atol=1e-4)
+    assert torch.equal(fa.grad.cpu(), fb.grad)  # ascending-slot accumulation, same as the oracle: exact
+    (g2,) = torch.autograd.grad(hip.grouping_operation(fa, idx.to(DEV)), fa, cot.to(DEV))
+    assert torch.equal(g2, fa.grad)  # no atomics: bitwise reproducible run to run
 
 
 def test_strided_and_int32_inputs_are_normalised(hip, oracle):

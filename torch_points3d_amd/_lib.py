@@ -21,12 +21,12 @@ SIGNATURES = {
     "tp3d_ball_query_partial_dense_f32": [_p, _p, _p, _p, _l, _l, _f, _i, _i, _p, _p, _p],
     "tp3d_three_nn_f32": [_p, _p, _i, _i, _i, _p, _p, _p],
     "tp3d_three_interpolate_fwd_f32": [_p, _p, _p, _i, _i, _i, _i, _p, _p],
-    "tp3d_three_interpolate_bwd_f32": [_p, _p, _p, _i, _i, _i, _i, _p, _p],
+    "tp3d_three_interpolate_bwd_f32": [_p, _p, _p, _i, _i, _i, _i, _p, _p, ctypes.c_size_t, _p],
     "tp3d_group_fwd_f32": [_p, _p, _i, _i, _i, _i, _i, _p, _p],
-    "tp3d_group_bwd_f32": [_p, _p, _i, _i, _i, _i, _i, _p, _p],
+    "tp3d_group_bwd_f32": [_p, _p, _i, _i, _i, _i, _i, _p, _p, ctypes.c_size_t, _p],
 }
-MISC = ("tp3d_abi_version", "tp3d_strerror", "tp3d_last_hip_error")
-ABI_VERSION = 1
+MISC = ("tp3d_abi_version", "tp3d_strerror", "tp3d_last_hip_error", "tp3d_scatter_workspace_bytes")
+ABI_VERSION = 2
 
 _handle = None
 
@@ -58,6 +58,8 @@ def load():
     h.tp3d_strerror.restype = ctypes.c_char_p
     h.tp3d_strerror.argtypes = [_i]
     h.tp3d_last_hip_error.restype = _i
+    h.tp3d_scatter_workspace_bytes.restype = ctypes.c_size_t
+    h.tp3d_scatter_workspace_bytes.argtypes = [_i, _i, _i, _i]
     if h.tp3d_abi_version() != ABI_VERSION:
         raise Tp3dError("libtp3d_hip.so ABI %d != binding ABI %d" % (h.tp3d_abi_version(), ABI_VERSION))
     _handle = h
@@ -107,6 +109,12 @@ def call(name, *args):
     if rc != 0:
         raise Tp3dError("%s failed: %s (code %d, hipError %d)" % (
             name, h.tp3d_strerror(rc).decode(), rc, h.tp3d_last_hip_error()))
+
+
+def scatter_workspace(B, L, nbins, with_weights, device):
+    """Device scratch for the atomic-free scatter-add backward ops (size dictated by the library)."""
+    nbytes = load().tp3d_scatter_workspace_bytes(B, L, nbins, int(with_weights))
+    return torch.empty(max(nbytes, 16), dtype=torch.uint8, device=device), nbytes
 
 
 def ptr(t):

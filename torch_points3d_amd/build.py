@@ -19,6 +19,7 @@ HIPCC_FLAGS = [
     "--offload-arch=" + ARCH,
     "-O3",
     "-ffp-contract=off",
+    "-fno-honor-nans",  # fminf/fmaxf -> bare v_min/v_max (no canonicalising v_max x,x); inputs are finite clouds
     "-fPIC",
     "-shared",
     "-fvisibility=hidden",

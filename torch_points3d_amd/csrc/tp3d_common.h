@@ -46,6 +46,20 @@ __device__ __forceinline__ float sqdist3(float ax, float ay, float az, float bx,
     return (dx * dx + dy * dy) + dz * dz;
 }
 
+// csr.hip: inverse index of a neighbour table + the gather-sum that replaces scatter-add atomics
+struct ScatterWorkspace {
+    int *start;      // B*(nbins+1)
+    int *order;      // B*L
+    int *scratch;    // B*L (only touched when a cloud's tables do not fit LDS)
+    float *wsorted;  // B*L or null
+    size_t bytes;
+};
+ScatterWorkspace carve_scatter_workspace(void *ws, int B, int L, int nbins, bool with_weights);
+int csr_transpose(const int64_t *idx, int B, int L, int nbins, int div, const float *weight, int *start, int *order,
+                  float *wsorted, int *scratch_ord, hipStream_t s);
+int gather_sum(const float *rows, const int *start, const int *order, const float *wsorted, int B, int C, int nbins,
+               int Lrow, int Lslots, float *out, hipStream_t s);
+
 __device__ __forceinline__ int lane_id() { return threadIdx.x & (kWave - 1); }
 
 // number of set bits of `mask` strictly below this lane

@@ -147,9 +147,10 @@ class _ThreeInterpolate(torch.autograd.Function):
         grad_out = _f32(grad_out)
         B, C, n = grad_out.shape
         g = torch.empty((B, C, ctx.m), dtype=torch.float32, device=dev)
+        ws, ws_bytes = _lib.scatter_workspace(B, 3 * n, ctx.m, True, dev)
         with torch.cuda.device(dev):
             _lib.call("tp3d_three_interpolate_bwd_f32", _lib.ptr(grad_out), _lib.ptr(idx), _lib.ptr(weight), B, C,
-                      ctx.m, n, _lib.ptr(g), _lib.stream_ptr(dev))
+                      ctx.m, n, _lib.ptr(g), _lib.ptr(ws), ws_bytes, _lib.stream_ptr(dev))
         return g, None, None
 
 
@@ -180,9 +181,10 @@ class _Grouping(torch.autograd.Function):
         grad_out = _f32(grad_out)
         B, C, np_, ns = grad_out.shape
         g = torch.empty((B, C, ctx.N), dtype=torch.float32, device=dev)
+        ws, ws_bytes = _lib.scatter_workspace(B, np_ * ns, ctx.N, False, dev)
         with torch.cuda.device(dev):
             _lib.call("tp3d_group_bwd_f32", _lib.ptr(grad_out), _lib.ptr(idx), B, C, ctx.N, np_, ns, _lib.ptr(g),
-                      _lib.stream_ptr(dev))
+                      _lib.ptr(ws), ws_bytes, _lib.stream_ptr(dev))
         return g, None
 
 
