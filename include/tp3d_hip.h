@@ -35,7 +35,7 @@ extern "C" {
 #define TP3D_E_UNSORTED (-3) /* reserved: batch vector not sorted (checked by the host wrapper) */
 #define TP3D_E_TOOBIG (-4)   /* size exceeds what the kernel's index arithmetic supports */
 
-#define TP3D_ABI_VERSION 2
+#define TP3D_ABI_VERSION 4
 
 int tp3d_abi_version(void);
 const char *tp3d_strerror(int code);
@@ -107,6 +107,63 @@ int tp3d_group_fwd_f32(const float *features, const int64_t *idx, int B, int C, 
                        void *stream);
 int tp3d_group_bwd_f32(const float *grad_out, const int64_t *idx, int B, int C, int N, int np, int ns,
                        float *grad_features, void *workspace, size_t workspace_bytes, void *stream);
+
+/* =====================================================================================================
+ * Grouped-MLP aggregation in channel-last ("rows") layout: the work PointNetMSGDown / DenseFPModule /
+ * GlobalDenseBaseModule do around their 1x1-conv GEMMs (reference modules/pointnet2/dense.py:36-75,
+ * core/base_conv/dense.py:102-184, core/common_modules/dense_modules.py:5-29).  Activations are (rows, C)
+ * row-major fp32; the GEMMs themselves are plain library GEMMs issued by the host wrapper.
+ * ===================================================================================================== */
+
+/* out[(b,j,s), :] = [ (pos[b,idx[b,j,s]] - new_pos[b,j]) (/ radius if normalize), x_cl[b,idx[b,j,s], 0:C] ]
+ * pos (B,N,3), new_pos (B,np,3), x_cl (B,N,C) or NULL when C == 0, idx (B,np,ns) -> out (B*np*ns, 3+C). */
+int tp3d_group_concat_fwd_f32(const float *pos, const float *new_pos, const float *x_cl, const int64_t *idx, int B,
+                              int N, int np, int ns, int C, float radius, int normalize, float *out, void *stream);
+
+/* Scatter-add of row gradients back onto their source points, atomic-free (inverse index + gather-sum):
+ *   grad_x_cl[b,k,0:C] = sum over slots l of cloud b with idx[b,l] == k (ascending l) of
+ *                        weight[b,l] * grad_rows[(b, l/div), col0 : col0+C]          (weight NULL -> 1)
+ * grad_rows (B, L/div, ld); idx (B, L) with values in [0, nbins); grad_x_cl (B, nbins, C).
+ * workspace: tp3d_scatter_workspace_bytes(B, L, nbins, weight != NULL). */
+int tp3d_rows_scatter_bwd_f32(const float *grad_rows, const int64_t *idx, const float *weight, int B, int L, int div,
+                              int nbins, int ld, int col0, int C, float *grad_x_cl, void *workspace,
+                              size_t workspace_bytes, void *stream);
+
+/* BatchNorm statistics of Y (M, C) and the folded affine  scale = gamma*invstd, shift = beta - mean*scale.
+ * training != 0: batch mean / biased variance (running stats updated in place with `momentum`, unbiased var);
+ * training == 0: running statistics.  workspace: tp3d_bn_workspace_floats(M, C) floats. */
+size_t tp3d_bn_workspace_floats(int64_t M, int C);
+int tp3d_bn_stats_f32(const float *Y, int64_t M, int C, float eps, float momentum, const float *gamma,
+                      const float *beta, float *running_mean, float *running_var, int training, float *mean,
+                      float *invstd, float *scale, float *shift, float *workspace, void *stream);
+
+/* out = LeakyReLU_slope(scale*Y + shift) over (M, C);  the pooled form also takes the max over each group of
+ * ns consecutive rows (first maximum wins) and records its row in argmax (G, C). */
+int tp3d_bn_act_f32(const float *Y, const float *scale, const float *shift, float slope, int64_t M, int C, float *out,
+                    void *stream);
+int tp3d_bn_act_maxpool_f32(const float *Y, const float *scale, const float *shift, float slope, int64_t G, int ns,
+                            int C, float *out, int *argmax, void *stream);
+
+/* Backward of out = act(BN(Y)): dbeta, dgamma (C) and dY (M, C).  dA is (M, C), or -- with argmax != NULL --
+ * the gradient (M/ns, C) of the pooled output.  workspace: tp3d_bn_workspace_floats(M, C) floats. */
+int tp3d_bn_act_bwd_f32(const float *dA, const int *argmax, const float *Y, const float *scale, const float *shift,
+                        const float *mean, const float *invstd, float slope, int64_t M, int ns, int C, int training,
+                        float *dbeta, float *dgamma, float *dY, float *workspace, void *stream);
+
+/* out[(b,i), :] = [ (w0*f0 + w1*f1) + w2*f2 , skip_cl[b,i,0:C2] ],  f_t = feat_cl[b, idx[b,i,t], 0:C1]
+ * feat_cl (B,m,C1), idx/weight (B,n,3), skip_cl (B,n,C2) or NULL -> out (B*n, C1+C2). */
+int tp3d_interp_concat_fwd_f32(const float *feat_cl, const int64_t *idx, const float *weight, const float *skip_cl,
+                               int B, int m, int n, int C1, int C2, float *out, void *stream);
+
+/* Weight gradient of a 1x1 conv / shared-MLP layer:  out[n,k] = sum_r dY[r,n] * A[r,k]
+ * dY (M,N), A (M,K) row-major -> out (N,K); rows split over the grid, fp32 MFMA, fixed-order reduction of the
+ * splits (reproducible).  workspace: tp3d_gemm_tn_workspace_floats(M, N, K) floats. */
+size_t tp3d_gemm_tn_workspace_floats(int64_t M, int N, int K);
+int tp3d_gemm_tn_f32(const float *dY, const float *A, int64_t M, int N, int K, float *out, float *workspace,
+                     void *stream);
+
+/* inverse-distance weights of DenseFPModule (core/base_conv/dense.py:137-139): dist (rows,3) -> weight (rows,3) */
+int tp3d_idw_weights_f32(const float *dist, int64_t rows, float *weight, void *stream);
 
 #ifdef __cplusplus
 }

@@ -214,6 +214,11 @@ def main():
     #      LeakyReLU kink a last-bit forward difference cannot flip a gradient mask, so gradients compare tightly.
     make_case("small_ssg_tanh", small, 4, 6, pos, feats, seed=7, store_weights=True, activation=torch.nn.Tanh())
 
+    # (2c) LeakyReLU(negative_slope=1.0) == identity: still a LeakyReLU (so the fused channel-last kernels run it)
+    #      but kink-free, so the gradients of the fused path can be compared element-wise as well.
+    make_case("small_ssg_slope1", small, 4, 6, pos, feats, seed=7, store_weights=True,
+              activation=torch.nn.LeakyReLU(negative_slope=1.0))
+
     # (3) multi-scale grouping (unet_3_ms.yaml layout, narrow) on distinct clouds.
     g = torch.Generator().manual_seed(99)
     pos = torch.rand(2, 600, 3, generator=g) * 2 - 1

@@ -23,15 +23,16 @@ CASES = {
     "small_ssg": lambda: SMALL_SSG,
     "small_msg": lambda: SMALL_MSG,
     "small_ssg_tanh": lambda: SMALL_SSG,
+    "small_ssg_slope1": lambda: SMALL_SSG,
 }
-ACTIVATION = {"small_ssg_tanh": torch.nn.Tanh}
+ACTIVATION = {"small_ssg_tanh": torch.nn.Tanh, "small_ssg_slope1": lambda: torch.nn.LeakyReLU(negative_slope=1.0)}
 
 
-def build_from_golden(g, cfg, kernels, device="cpu", activation=None):
+def build_from_golden(g, cfg, kernels, device="cpu", activation=None, fused=True):
     """Mirror model carrying exactly the reference modules' weights."""
     feat, out_nc = [int(v) for v in g["meta_feat_outnc"]]
     torch.manual_seed(int(g["meta_seed"][0]))
-    net = PointNet2Unet(feat, output_nc=out_nc, config=cfg, kernels=kernels, activation=activation)
+    net = PointNet2Unet(feat, output_nc=out_nc, config=cfg, kernels=kernels, activation=activation, fused=fused)
     stored = {k[len("state/"):]: v for k, v in g.items() if k.startswith("state/")}
     if stored:
         net.load_state_dict(stored, strict=True)

@@ -1,0 +1,179 @@
+"""Channel-last fused kernels of the grouped-MLP aggregation (csrc/rows.hip via torch_points3d_amd.fused)
+against a plain PyTorch fp32 evaluation of the reference's graph (Conv2d 1x1 -> BatchNorm2d(train) ->
+LeakyReLU -> max_pool2d, modules/pointnet2/dense.py:36-75), forward and backward."""
+import pytest
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _rel(a, b):
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+@pytest.mark.parametrize("B,N,npnt,ns,C,normalize", [(2, 300, 40, 16, 5, False), (3, 1000, 64, 64, 128, True),
+                                                     (1, 50, 7, 3, 0, False), (2, 64, 9, 5, 1, True)])
+def test_group_concat_fwd_bwd(B, N, npnt, ns, C, normalize):
+    from torch_points3d_amd import fused
+    g = torch.Generator().manual_seed(N + C)
+    pos = torch.rand(B, N, 3, generator=g).to(DEV)
+    new_pos = torch.rand(B, npnt, 3, generator=g).to(DEV)
+    idx = torch.randint(0, N, (B, npnt, ns), generator=g).to(DEV)
+    x = torch.randn(B, C, N, generator=g).to(DEV) if C else None
+    r = 0.37
+    # reference graph (channel-first), as PointNetMSGDown._prepare_features builds it
+    xr = x.clone().requires_grad_(True) if C else None
+    gp = pos.transpose(1, 2).contiguous().gather(2, idx.view(B, 1, -1).repeat(1, 3, 1)).view(B, 3, npnt, ns)
+    gp = gp - new_pos.transpose(1, 2).unsqueeze(-1)
+    if normalize:
+        gp = gp / r
+    ref = gp if not C else torch.cat([gp, xr.gather(2, idx.view(B, 1, -1).repeat(1, C, 1)).view(B, C, npnt, ns)], 1)
+    xf = x.clone().requires_grad_(True) if C else None
+    rows = fused.group_concat(pos, new_pos, None if not C else xf.transpose(1, 2), idx, r, normalize)
+    got = rows.view(B, npnt, ns, C + 3).permute(0, 3, 1, 2)
+    if normalize:
+        # the kernel performs the IEEE division the reference's CPU path performs; torch's GPU kernel multiplies
+        # by a reciprocal for a scalar divisor, so this comparison is within one ulp rather than bitwise
+        torch.testing.assert_close(got, ref.detach(), rtol=3e-7, atol=0)
+        cpu = (pos.cpu().transpose(1, 2).contiguous().gather(2, idx.cpu().view(B, 1, -1).repeat(1, 3, 1))
+               .view(B, 3, npnt, ns) - new_pos.cpu().transpose(1, 2).unsqueeze(-1)) / r
+        assert torch.equal(got[:, :3].cpu(), cpu)
+    else:
+        assert torch.equal(got, ref.detach())  # copies and one subtraction: exact
+    if C:
+        cot = torch.randn(B, C + 3, npnt, ns, generator=g).to(DEV)
+        ref.backward(cot)
+        got.backward(cot)
+        torch.testing.assert_close(xf.grad, xr.grad, rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("M_groups,ns,Cin,Cout,slope,pool", [(70, 16, 7, 24, 0.01, True), (512, 64, 131, 128, 0.01, True),
+                                                              (900, 1, 28, 24, 0.01, False), (33, 5, 6, 64, 0.0, True),
+                                                              (4096, 1, 259, 256, 0.01, False), (8, 128, 35, 33, 1.0, True)])
+@pytest.mark.parametrize("training", [True, False])
+def test_linear_bn_act_matches_torch(M_groups, ns, Cin, Cout, slope, pool, training):
+    from torch_points3d_amd import fused
+    g = torch.Generator().manual_seed(M_groups + Cin)
+    M = M_groups * ns
+    A = torch.randn(M, Cin, generator=g).to(DEV)
+    conv_a, conv_b = nn.Conv2d(Cin, Cout, 1, bias=False).to(DEV), nn.Conv2d(Cin, Cout, 1, bias=False).to(DEV)
+    conv_b.load_state_dict(conv_a.state_dict())
+    bn_a, bn_b = nn.BatchNorm2d(Cout).to(DEV), nn.BatchNorm2d(Cout).to(DEV)
+    with torch.no_grad():
+        bn_a.weight.copy_(torch.rand(Cout, generator=g) + 0.5)
+        bn_a.bias.copy_(torch.randn(Cout, generator=g) * 0.1)
+        bn_a.weight[0] = -0.7  # a negative gamma must not break the fused max-pool
+        bn_a.running_mean.copy_(torch.randn(Cout, generator=g) * 0.1)
+        bn_a.running_var.copy_(torch.rand(Cout, generator=g) + 0.5)
+    bn_b.load_state_dict(bn_a.state_dict())
+    bn_a.train(training)
+    bn_b.train(training)
+    act = nn.LeakyReLU(slope) if slope not in (0.0,) else nn.ReLU()
+    # reference: (1, Cin, groups, ns) image
+    Ar = A.clone().requires_grad_(True)
+    img = Ar.view(1, M_groups, ns, Cin).permute(0, 3, 1, 2)
+    ref = act(bn_a(conv_a(img)))
+    if pool:
+        ref = F.max_pool2d(ref, kernel_size=[1, ns])
+    ref_rows = ref.permute(0, 2, 3, 1).reshape(-1, Cout)
+    Af = A.clone().requires_grad_(True)
+    got = fused.linear_bn_act(Af, conv_b, bn_b, float(slope), ns if pool else 0)
+    scale = max(1.0, float(ref_rows.detach().abs().max()))
+    torch.testing.assert_close(got, ref_rows.detach(), rtol=1e-4, atol=1e-5 * scale)
+    if training:
+        torch.testing.assert_close(bn_b.running_mean, bn_a.running_mean, rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(bn_b.running_var, bn_a.running_var, rtol=1e-5, atol=1e-6)
+        assert int(bn_b.num_batches_tracked) == int(bn_a.num_batches_tracked) == 1
+    cot = torch.randn(ref_rows.shape, generator=g).to(DEV)
+    ref_rows.backward(cot)
+    got.backward(cot)
+    # a LeakyReLU / max-pool decision can flip on a last-bit difference, so gradients are bounded in L2
+    tol = 1e-5 if slope == 1.0 and not pool else 2e-2
+    assert _rel(Af.grad, Ar.grad) < tol
+    assert _rel(conv_b.weight.grad, conv_a.weight.grad) < tol
+    assert _rel(bn_b.weight.grad, bn_a.weight.grad) < tol
+    assert _rel(bn_b.bias.grad, bn_a.bias.grad) < tol
+
+
+@pytest.mark.parametrize("B,m,n,C1,C2", [(2, 16, 50, 8, 5), (2, 128, 512, 256, 128), (1, 3, 9, 4, 0), (3, 40, 100, 1, 3)])
+def test_interp_concat_fwd_bwd(B, m, n, C1, C2, hip):
+    from torch_points3d_amd import fused
+    g = torch.Generator().manual_seed(m * n)
+    known = torch.rand(B, m, 3, generator=g).to(DEV)
+    unknown = torch.rand(B, n, 3, generator=g).to(DEV)
+    feat = torch.randn(B, C1, m, generator=g).to(DEV)
+    skip = torch.randn(B, C2, n, generator=g).to(DEV) if C2 else None
+    dist, idx = hip.three_nn(unknown, known)
+    # reference graph: DenseFPModule.conv + BaseDenseConvolutionUp.forward (core/base_conv/dense.py:102-144)
+    dist_recip = 1.0 / (dist + 1e-8)
+    w_ref = dist_recip / torch.sum(dist_recip, dim=2, keepdim=True)
+    w = fused.idw_weights(dist)
+    torch.testing.assert_close(w, w_ref, rtol=1e-6, atol=1e-7)
+    fr = feat.clone().requires_grad_(True)
+    sr = skip.clone().requires_grad_(True) if C2 else None
+    ref = hip.three_interpolate(fr, idx, w)
+    if C2:
+        ref = torch.cat([ref, sr], dim=1)
+    ff = feat.clone().requires_grad_(True)
+    sf = skip.clone().requires_grad_(True) if C2 else None
+    rows = fused.interp_concat(ff.transpose(1, 2), idx, w, None if not C2 else sf.transpose(1, 2))
+    got = rows.view(B, n, C1 + C2).transpose(1, 2)
+    assert torch.equal(got, ref.detach())
+    cot = torch.randn(B, C1 + C2, n, generator=g).to(DEV)
+    ref.backward(cot)
+    got.backward(cot)
+    torch.testing.assert_close(ff.grad, fr.grad, rtol=1e-5, atol=1e-5)
+    if C2:
+        assert torch.equal(sf.grad, sr.grad)
+
+
+def test_fused_model_equals_unfused_model():
+    """Same weights, same input: channel-last fused path vs the reference's (B,C,np,ns) PyTorch graph, on GPU."""
+    from torch_points3d_amd.dense import Data
+    from torch_points3d_amd.pointnet2 import PointNet2Unet
+    for cfg in ("unet_3_ss", "unet_3_ms", "unet_4_ss"):
+        torch.manual_seed(0)
+        a = PointNet2Unet(3, output_nc=7, config=cfg, fused=True).to(DEV).train()
+        torch.manual_seed(0)
+        b = PointNet2Unet(3, output_nc=7, config=cfg, fused=False).to(DEV).train()
+        g = torch.Generator().manual_seed(3)
+        pos = (torch.rand(2, 4096, 3, generator=g) * 2 - 1).to(DEV)
+        x = torch.randn(2, 4096, 3, generator=g).to(DEV)
+        oa = a(Data(pos=pos, x=x)).x
+        ob = b(Data(pos=pos, x=x)).x
+        assert oa.shape == ob.shape == (2, 7, 4096)
+        torch.testing.assert_close(oa, ob, rtol=1e-3, atol=1e-3)
+        oa.square().mean().backward()
+        ob.square().mean().backward()
+        gmax = max(float(p.grad.norm()) for p in b.parameters())
+        for (na, pa), (nb, pb) in zip(a.named_parameters(), b.named_parameters()):
+            assert na == nb
+            # (a BatchNorm bias that feeds another BatchNorm has a mathematically zero gradient: absolute floor)
+            assert float((pa.grad - pb.grad).norm()) < 5e-2 * float(pb.grad.norm()) + 1e-5 * gmax, na
+        for (na, ba), (nb, bb) in zip(a.named_buffers(), b.named_buffers()):
+            torch.testing.assert_close(ba.float(), bb.float(), rtol=1e-3, atol=1e-4, msg=lambda m, na=na: na + m)
+
+
+@pytest.mark.parametrize("M,N,K", [(1000, 64, 6), (4096, 128, 131), (70000, 10, 128), (33, 7, 5), (20000, 256, 259),
+                                   (5000, 1024, 512), (262144, 128, 128), (17, 130, 70)])
+def test_gemm_tn_matches_fp64(M, N, K):
+    """split-K MFMA weight-gradient kernel vs an fp64 evaluation (and vs torch.mm's fp32 for scale)."""
+    from torch_points3d_amd import fused
+    g = torch.Generator().manual_seed(M + N + K)
+    dY = torch.randn(M, N, generator=g).to(DEV)
+    A = torch.randn(M, K, generator=g).to(DEV)
+    got = fused.gemm_tn(dY, A)
+    ref = torch.mm(dY.double().t(), A.double())
+    err = float((got.double() - ref).abs().max())
+    lib = float((torch.mm(dY.t(), A).double() - ref).abs().max())
+    assert got.shape == (N, K)
+    assert err <= max(2.0 * lib, 1e-5 * float(ref.abs().max())), (err, lib)
+    assert torch.equal(got, fused.gemm_tn(dY, A))  # fixed-order split reduction: reproducible
+    # exact integer data: catches any operand / accumulator layout mix-up
+    dYi = torch.randint(-3, 4, (M, N), generator=g).float().to(DEV)
+    Ai = torch.randint(-3, 4, (M, K), generator=g).float().to(DEV)
+    if M <= 70000:
+        assert torch.equal(fused.gemm_tn(dYi, Ai), torch.mm(dYi.double().t(), Ai.double()).float())

@@ -24,9 +24,19 @@ SIGNATURES = {
     "tp3d_three_interpolate_bwd_f32": [_p, _p, _p, _i, _i, _i, _i, _p, _p, ctypes.c_size_t, _p],
     "tp3d_group_fwd_f32": [_p, _p, _i, _i, _i, _i, _i, _p, _p],
     "tp3d_group_bwd_f32": [_p, _p, _i, _i, _i, _i, _i, _p, _p, ctypes.c_size_t, _p],
+    "tp3d_group_concat_fwd_f32": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _i, _p, _p],
+    "tp3d_rows_scatter_bwd_f32": [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p, _p, ctypes.c_size_t, _p],
+    "tp3d_bn_stats_f32": [_p, _l, _i, _f, _f, _p, _p, _p, _p, _i, _p, _p, _p, _p, _p, _p],
+    "tp3d_bn_act_f32": [_p, _p, _p, _f, _l, _i, _p, _p],
+    "tp3d_bn_act_maxpool_f32": [_p, _p, _p, _f, _l, _i, _i, _p, _p, _p],
+    "tp3d_bn_act_bwd_f32": [_p, _p, _p, _p, _p, _p, _p, _f, _l, _i, _i, _i, _p, _p, _p, _p, _p],
+    "tp3d_interp_concat_fwd_f32": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _p],
+    "tp3d_idw_weights_f32": [_p, _l, _p, _p],
+    "tp3d_gemm_tn_f32": [_p, _p, _l, _i, _i, _p, _p, _p],
 }
-MISC = ("tp3d_abi_version", "tp3d_strerror", "tp3d_last_hip_error", "tp3d_scatter_workspace_bytes")
-ABI_VERSION = 2
+MISC = ("tp3d_abi_version", "tp3d_strerror", "tp3d_last_hip_error", "tp3d_scatter_workspace_bytes",
+        "tp3d_bn_workspace_floats", "tp3d_gemm_tn_workspace_floats")
+ABI_VERSION = 4
 
 _handle = None
 
@@ -60,6 +70,10 @@ def load():
     h.tp3d_last_hip_error.restype = _i
     h.tp3d_scatter_workspace_bytes.restype = ctypes.c_size_t
     h.tp3d_scatter_workspace_bytes.argtypes = [_i, _i, _i, _i]
+    h.tp3d_bn_workspace_floats.restype = ctypes.c_size_t
+    h.tp3d_bn_workspace_floats.argtypes = [_l, _i]
+    h.tp3d_gemm_tn_workspace_floats.restype = ctypes.c_size_t
+    h.tp3d_gemm_tn_workspace_floats.argtypes = [_l, _i, _i]
     if h.tp3d_abi_version() != ABI_VERSION:
         raise Tp3dError("libtp3d_hip.so ABI %d != binding ABI %d" % (h.tp3d_abi_version(), ABI_VERSION))
     _handle = h
@@ -115,6 +129,11 @@ def scatter_workspace(B, L, nbins, with_weights, device):
     """Device scratch for the atomic-free scatter-add backward ops (size dictated by the library)."""
     nbytes = load().tp3d_scatter_workspace_bytes(B, L, nbins, int(with_weights))
     return torch.empty(max(nbytes, 16), dtype=torch.uint8, device=device), nbytes
+
+
+def bn_workspace(M, C, device):
+    n = load().tp3d_bn_workspace_floats(M, C)
+    return torch.empty(max(n, 4), dtype=torch.float32, device=device)
 
 
 def ptr(t):

@@ -1,0 +1,184 @@
+// Weight-gradient contraction of the shared MLPs:  dW[n,k] = sum_r dY[r,n] * A[r,k]
+// dY (M, N) and A (M, K) row-major with M = B*npoint*nsample up to ~1e6 rows and N, K <= ~1300: a GEMM whose
+// OUTPUT is tiny and whose contraction dimension is huge.  Library GEMMs pick 32x32 macro-tiles without a
+// split over M for it (measured 0.5-1.5 ms per layer on MI355X); here the rows are split over the grid, every
+// workgroup streams its row range once through LDS and accumulates a (TN x TK) tile with fp32 MFMA
+// (v_mfma_f32_32x32x2_f32: exact fp32, 64 FLOP/clk/SIMD), and a second pass sums the splits in fixed order
+// (no atomics: bitwise reproducible).
+//
+// Reference semantics: the weight gradient of Conv2d 1x1 (bias=False) inside MLP2D
+// (torch_points3d/core/common_modules/dense_modules.py:5-12,25-29) -- computed by autograd in the reference.
+#include "tp3d_common.h"
+
+namespace tp3d {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int TN_BLOCK = 256;  // 4 waves as 2 x 2
+constexpr int TN_BR = 16;      // rows staged per step
+
+// Each wave owns WM x WN MFMA tiles of 32x32; the workgroup tile is (2*WM*32) x (2*WN*32).
+template <int WM, int WN>
+__global__ __launch_bounds__(TN_BLOCK) void gemm_tn_partial_kernel(const float *__restrict__ dY,
+                                                                    const float *__restrict__ A, int64_t M, int N,
+                                                                    int K, int64_t rows_per_split, int tiles_k,
+                                                                    float *__restrict__ partial /*[S][N][K]*/)
+{
+    constexpr int TN = 2 * WM * 32, TK = 2 * WN * 32;
+    constexpr int LDN = TN + 4, LDK = TK + 4;  // +4 floats: keeps float4 stores aligned, spreads rows over banks
+    __shared__ __attribute__((aligned(16))) float sY[TN_BR * LDN];
+    __shared__ __attribute__((aligned(16))) float sA[TN_BR * LDK];
+
+    const int tile = blockIdx.x;
+    const int n0 = (tile / tiles_k) * TN, k0 = (tile % tiles_k) * TK;
+    const int split = blockIdx.y;
+    const int64_t r_begin = (int64_t)split * rows_per_split;
+    const int64_t r_end = min(r_begin + rows_per_split, M);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int l31 = lane & 31, lh = lane >> 5;
+
+    f32x16 acc[WM][WN];
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+
+    const bool vecY = ((N & 3) == 0) && (n0 + TN <= N);
+    const bool vecA = ((K & 3) == 0) && (k0 + TK <= K);
+
+    for (int64_t r0 = r_begin; r0 < r_end; r0 += TN_BR) {
+        // ---- stage TN_BR rows of both operands (zero-filled past the matrix edge / row range)
+        if (vecY) {
+            for (int e = tid; e < TN_BR * (TN / 4); e += TN_BLOCK) {
+                const int rr = e / (TN / 4), c4 = (e % (TN / 4)) * 4;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (r0 + rr < r_end) v = *reinterpret_cast<const float4 *>(dY + (r0 + rr) * N + n0 + c4);
+                *reinterpret_cast<float4 *>(&sY[rr * LDN + c4]) = v;
+            }
+        } else {
+            for (int e = tid; e < TN_BR * TN; e += TN_BLOCK) {
+                const int rr = e / TN, c = e % TN;
+                sY[rr * LDN + c] = (r0 + rr < r_end && n0 + c < N) ? dY[(r0 + rr) * N + n0 + c] : 0.0f;
+            }
+        }
+        if (vecA) {
+            for (int e = tid; e < TN_BR * (TK / 4); e += TN_BLOCK) {
+                const int rr = e / (TK / 4), c4 = (e % (TK / 4)) * 4;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (r0 + rr < r_end) v = *reinterpret_cast<const float4 *>(A + (r0 + rr) * K + k0 + c4);
+                *reinterpret_cast<float4 *>(&sA[rr * LDK + c4]) = v;
+            }
+        } else {
+            for (int e = tid; e < TN_BR * TK; e += TN_BLOCK) {
+                const int rr = e / TK, c = e % TK;
+                sA[rr * LDK + c] = (r0 + rr < r_end && k0 + c < K) ? A[(r0 + rr) * K + k0 + c] : 0.0f;
+            }
+        }
+        __syncthreads();
+        // ---- contraction over the staged rows, two rows per MFMA
+#pragma unroll
+        for (int rr = 0; rr < TN_BR; rr += 2) {
+            float a[WM], b[WN];
+#pragma unroll
+            for (int i = 0; i < WM; ++i) a[i] = sY[(rr + lh) * LDN + (wr * WM + i) * 32 + l31];
+#pragma unroll
+            for (int j = 0; j < WN; ++j) b[j] = sA[(rr + lh) * LDK + (wc * WN + j) * 32 + l31];
+#pragma unroll
+            for (int i = 0; i < WM; ++i)
+#pragma unroll
+                for (int j = 0; j < WN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+
+    // ---- write the split's partial tile: D[row][col], col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+    float *out = partial + (size_t)split * N * K;
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int n = n0 + (wr * WM + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                const int k = k0 + (wc * WN + j) * 32 + l31;
+                if (n < N && k < K) out[(size_t)n * K + k] = acc[i][j][e];
+            }
+}
+
+__global__ void gemm_tn_reduce_kernel(const float *__restrict__ partial, int S, int64_t NK, float *__restrict__ out)
+{
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= NK) return;
+    float acc = 0.0f;
+    for (int s = 0; s < S; ++s) acc += partial[(size_t)s * NK + e];  // fixed order
+    out[e] = acc;
+}
+
+struct TnPlan {
+    int wm, wn, tn, tk, tiles_n, tiles_k, splits;
+    int64_t rows_per_split;
+};
+
+static TnPlan plan_tn(int64_t M, int N, int K)
+{
+    TnPlan p;
+    p.wm = N > 64 ? 2 : 1;
+    p.wn = K > 64 ? 2 : 1;
+    p.tn = 64 * p.wm;
+    p.tk = 64 * p.wn;
+    p.tiles_n = (N + p.tn - 1) / p.tn;
+    p.tiles_k = (K + p.tk - 1) / p.tk;
+    const int tiles = p.tiles_n * p.tiles_k;
+    // ~8 workgroups per CU in flight (256 CUs), at least 256 rows per split, at most 1024 splits
+    int64_t want = (2048 + tiles - 1) / tiles;
+    int64_t max_by_rows = (M + 255) / 256;
+    int64_t s = want < max_by_rows ? want : max_by_rows;
+    if (s < 1) s = 1;
+    if (s > 1024) s = 1024;
+    p.rows_per_split = ((M + s - 1) / s + TN_BR - 1) / TN_BR * TN_BR;
+    p.splits = (int)((M + p.rows_per_split - 1) / p.rows_per_split);
+    return p;
+}
+
+}  // namespace tp3d
+
+using namespace tp3d;
+
+TP3D_EXPORT size_t tp3d_gemm_tn_workspace_floats(int64_t M, int N, int K)
+{
+    if (M <= 0 || N <= 0 || K <= 0) return 0;
+    const TnPlan p = plan_tn(M, N, K);
+    return (size_t)p.splits * (size_t)N * (size_t)K;
+}
+
+TP3D_EXPORT int tp3d_gemm_tn_f32(const float *dY, const float *A, int64_t M, int N, int K, float *out,
+                                 float *workspace, void *stream)
+{
+    if (M < 0 || N <= 0 || K <= 0 || !out) return TP3D_E_BADARG;
+    hipStream_t s = (hipStream_t)stream;
+    if (M == 0) return zero_async(out, (size_t)N * K * sizeof(float), s);
+    if (!dY || !A || !workspace) return TP3D_E_BADARG;
+    const TnPlan p = plan_tn(M, N, K);
+    if (p.splits > 65535) return TP3D_E_TOOBIG;
+    dim3 grid(p.tiles_n * p.tiles_k, p.splits);
+    if (p.wm == 2 && p.wn == 2)
+        hipLaunchKernelGGL((gemm_tn_partial_kernel<2, 2>), grid, dim3(TN_BLOCK), 0, s, dY, A, M, N, K, p.rows_per_split,
+                           p.tiles_k, workspace);
+    else if (p.wm == 2)
+        hipLaunchKernelGGL((gemm_tn_partial_kernel<2, 1>), grid, dim3(TN_BLOCK), 0, s, dY, A, M, N, K, p.rows_per_split,
+                           p.tiles_k, workspace);
+    else if (p.wn == 2)
+        hipLaunchKernelGGL((gemm_tn_partial_kernel<1, 2>), grid, dim3(TN_BLOCK), 0, s, dY, A, M, N, K, p.rows_per_split,
+                           p.tiles_k, workspace);
+    else
+        hipLaunchKernelGGL((gemm_tn_partial_kernel<1, 1>), grid, dim3(TN_BLOCK), 0, s, dY, A, M, N, K, p.rows_per_split,
+                           p.tiles_k, workspace);
+    if (int rc = check_launch()) return rc;
+    const int64_t NK = (int64_t)N * K;
+    hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3((unsigned)((NK + 255) / 256)), dim3(256), 0, s, workspace, p.splits,
+                       NK, out);
+    return check_launch();
+}

@@ -1,0 +1,654 @@
+// Channel-last ("rows") kernels of the grouped-MLP aggregation: everything around the 1x1-conv GEMMs of
+// PointNetMSGDown / DenseFPModule / GlobalDenseBaseModule, with activations stored as (rows, C) row-major
+// so that every access is a coalesced row segment and the GEMMs need no NCHW<->NHWC transposes.
+//
+// Reference semantics restated here (fp32):
+//   torch_points3d/modules/pointnet2/dense.py:36-54   group -> centre (-> /radius) -> concat [xyz, feats]
+//   torch_points3d/core/common_modules/dense_modules.py:5-29  Conv2d 1x1 (bias=False) -> BatchNorm2d -> LeakyReLU
+//   torch_points3d/modules/pointnet2/dense.py:72-73   max over nsample
+//   torch_points3d/core/base_conv/dense.py:132-144    inverse-distance 3-NN interpolation (+ skip concat :117)
+// HBM-bound: each kernel reads and writes every activation byte at most once per pass.
+#include "tp3d_common.h"
+
+namespace tp3d {
+
+constexpr int RW_BLOCK = 256;
+
+// -------------------------------------------------------------------------------------------------
+// group + centre + concat:  out[(b,j,s), :] = [ (pos[b,idx] - new_pos[b,j]) (/ radius) , x_cl[b,idx,:] ]
+__global__ __launch_bounds__(RW_BLOCK) void group_concat_fwd_kernel(const float *__restrict__ pos,
+                                                                     const float *__restrict__ new_pos,
+                                                                     const float *__restrict__ x_cl,
+                                                                     const int64_t *__restrict__ idx, int N, int np,
+                                                                     int ns, int C, float radius, int normalize,
+                                                                     int64_t total, float *__restrict__ out)
+{
+    const int Cw = C + 3;
+    for (int64_t e = (int64_t)blockIdx.x * RW_BLOCK + threadIdx.x; e < total; e += (int64_t)gridDim.x * RW_BLOCK) {
+        const int64_t row = e / Cw;
+        const int c = (int)(e - row * Cw);
+        const int64_t bj = row / ns;          // b*np + j
+        const int b = (int)(bj / np);
+        const int k = min(max((int)idx[row], 0), N - 1);
+        float v;
+        if (c < 3) {
+            v = pos[((size_t)b * N + k) * 3 + c] - new_pos[bj * 3 + c];
+            if (normalize) v = v / radius;  // the reference divides (modules/pointnet2/dense.py:41-42)
+        } else {
+            v = x_cl[((size_t)b * N + k) * C + (c - 3)];
+        }
+        out[e] = v;
+    }
+}
+
+// grad_x_cl[b,k,:] = sum over slots l (ascending) with idx[b,l]==k of grad_rows[(b,l), col0 + :]   (CSR gather)
+// one wave per destination point, lanes over channels: every read is a contiguous row segment.
+__global__ __launch_bounds__(RW_BLOCK) void rows_gather_sum_kernel(const float *__restrict__ grad_rows,
+                                                                    const int *__restrict__ start,
+                                                                    const int *__restrict__ order,
+                                                                    const float *__restrict__ wsorted, int nbins,
+                                                                    int L, int rows_per_cloud, int ld, int col0,
+                                                                    int C, float *__restrict__ out)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t dest = (int64_t)blockIdx.x * (RW_BLOCK / 64) + (threadIdx.x >> 6);  // destination point k
+    const int b = blockIdx.y;
+    if (dest >= nbins) return;
+    const int *st = start + (size_t)b * (nbins + 1);
+    const int *od = order + (size_t)b * L;
+    const float *ws = wsorted ? wsorted + (size_t)b * L : nullptr;
+    const int lo = st[dest], hi = st[dest + 1];
+    const float *base = grad_rows + (size_t)b * rows_per_cloud * ld + col0;
+    for (int c0 = 0; c0 < C; c0 += 64) {
+        const int c = c0 + lane;
+        float acc = 0.0f;
+        if (c < C) {
+            for (int j = lo; j < hi; ++j) {
+                const float v = base[(size_t)od[j] * ld + c];
+                acc = acc + (ws ? ws[j] * v : v);
+            }
+            out[((size_t)b * nbins + dest) * C + c] = acc;
+        }
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
+// per-channel statistics of Y (M, C): partial (sum, sum of squares) per row chunk, then a small finalize.
+// A workgroup is a (column-thread x row-lane) tile: V floats per column thread (float4 when C % 4 == 0), the
+// row lanes stride over the chunk with 4 independent rows in flight each, so every wave keeps several KiB
+// of coalesced loads outstanding (the first version had one 256-B row per wave in flight: 0.46 TB/s).
+constexpr int ST_ROWS = 256;  // rows per workgroup
+
+struct StatTile {
+    int colthreads, rowlanes, gridx;
+};
+static inline StatTile stat_tile(int C, int V)
+{
+    int cols = (C + V - 1) / V;  // column threads needed
+    int ct = 1;
+    while (ct < cols && ct < 64) ct <<= 1;
+    StatTile t;
+    t.colthreads = ct;
+    t.rowlanes = RW_BLOCK / ct;
+    t.gridx = (cols + ct - 1) / ct;
+    return t;
+}
+
+// MODE 0: a += y, q += y*y                      (forward statistics)
+// MODE 1: a += dz, q += dz*yhat, dz = dA*act'   (backward reductions)
+template <int V, int MODE>
+__global__ __launch_bounds__(RW_BLOCK) void colreduce_partial_kernel(
+    const float *__restrict__ Y, const float *__restrict__ dA, const float *__restrict__ scale,
+    const float *__restrict__ shift, const float *__restrict__ mean, const float *__restrict__ invstd, float slope,
+    int64_t M, int C, int colthreads, float *__restrict__ partial /*[chunks][2][C]*/)
+{
+    __shared__ float s1[RW_BLOCK * V], s2[RW_BLOCK * V];
+    const int ct = threadIdx.x % colthreads, rl = threadIdx.x / colthreads;
+    const int rowlanes = RW_BLOCK / colthreads;
+    const int c = (blockIdx.x * colthreads + ct) * V;
+    const int64_t r0 = (int64_t)blockIdx.y * ST_ROWS;
+    const int64_t r1 = min(r0 + ST_ROWS, M);
+    float a[V], q[V], sc[V], sh[V], mu[V], is[V];
+#pragma unroll
+    for (int v = 0; v < V; ++v) {
+        a[v] = 0.0f;
+        q[v] = 0.0f;
+        if (MODE == 1 && c + v < C) {
+            sc[v] = scale[c + v];
+            sh[v] = shift[c + v];
+            mu[v] = mean[c + v];
+            is[v] = invstd[c + v];
+        }
+    }
+    if (c < C) {
+        constexpr int U = 4;  // rows in flight per thread
+        for (int64_t r = r0 + rl; r < r1; r += (int64_t)rowlanes * U) {
+            float y[U][V], d[U][V];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int64_t rr = r + (int64_t)u * rowlanes;
+                if (rr < r1) {
+                    if (V == 4) {
+                        *reinterpret_cast<float4 *>(y[u]) = *reinterpret_cast<const float4 *>(Y + rr * C + c);
+                        if (MODE == 1) *reinterpret_cast<float4 *>(d[u]) = *reinterpret_cast<const float4 *>(dA + rr * C + c);
+                    } else {
+                        y[u][0] = Y[rr * C + c];
+                        if (MODE == 1) d[u][0] = dA[rr * C + c];
+                    }
+                } else {
+#pragma unroll
+                    for (int v = 0; v < V; ++v) {
+                        y[u][v] = MODE == 1 ? mu[v] : 0.0f;  // contributes exactly zero
+                        d[u][v] = 0.0f;
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int v = 0; v < V; ++v) {
+                    if (MODE == 0) {
+                        a[v] += y[u][v];
+                        q[v] += y[u][v] * y[u][v];
+                    } else {
+                        const float z = y[u][v] * sc[v] + sh[v];
+                        const float dz = d[u][v] * (z > 0.0f ? 1.0f : slope);
+                        a[v] += dz;
+                        q[v] += dz * ((y[u][v] - mu[v]) * is[v]);
+                    }
+                }
+        }
+    }
+#pragma unroll
+    for (int v = 0; v < V; ++v) {
+        s1[(rl * colthreads + ct) * V + v] = a[v];
+        s2[(rl * colthreads + ct) * V + v] = q[v];
+    }
+    __syncthreads();
+    if (rl == 0 && c < C) {
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+            if (c + v < C) {
+                float sa = 0.0f, sq = 0.0f;
+                for (int k = 0; k < rowlanes; ++k) {  // fixed order: reproducible
+                    sa += s1[(k * colthreads + ct) * V + v];
+                    sq += s2[(k * colthreads + ct) * V + v];
+                }
+                partial[((size_t)blockIdx.y * 2 + 0) * C + c + v] = sa;
+                partial[((size_t)blockIdx.y * 2 + 1) * C + c + v] = sq;
+            }
+        }
+    }
+}
+
+// sums the chunk partials of one channel: one workgroup per channel, fixed tree => reproducible; double accum.
+__device__ __forceinline__ void sum_partials(const float *__restrict__ partial, int chunks, int C, int c, double &a,
+                                             double &q)
+{
+    __shared__ double r1[RW_BLOCK], r2[RW_BLOCK];
+    double la = 0.0, lq = 0.0;
+    for (int k = threadIdx.x; k < chunks; k += RW_BLOCK) {
+        la += (double)partial[((size_t)k * 2 + 0) * C + c];
+        lq += (double)partial[((size_t)k * 2 + 1) * C + c];
+    }
+    r1[threadIdx.x] = la;
+    r2[threadIdx.x] = lq;
+    __syncthreads();
+    for (int off = RW_BLOCK / 2; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) {
+            r1[threadIdx.x] += r1[threadIdx.x + off];
+            r2[threadIdx.x] += r2[threadIdx.x + off];
+        }
+        __syncthreads();
+    }
+    a = r1[0];
+    q = r2[0];
+}
+
+// finalize (training): mean, biased var -> scale = gamma*invstd, shift = beta - mean*scale; running stats update.
+// eval: scale/shift from the running statistics.  One workgroup per channel.
+__global__ __launch_bounds__(RW_BLOCK) void bn_finalize_kernel(
+    const float *__restrict__ partial, int chunks, int64_t M, int C, float eps, float momentum,
+    const float *__restrict__ gamma, const float *__restrict__ beta, float *__restrict__ running_mean,
+    float *__restrict__ running_var, int training, float *__restrict__ mean_out, float *__restrict__ invstd_out,
+    float *__restrict__ scale_out, float *__restrict__ shift_out)
+{
+    const int c = blockIdx.x;
+    float mean, var;
+    if (training) {
+        double a, q;
+        sum_partials(partial, chunks, C, c, a, q);
+        const double mu = a / (double)M;
+        double v = q / (double)M - mu * mu;
+        if (v < 0.0) v = 0.0;
+        mean = (float)mu;
+        var = (float)v;
+        if (running_mean && threadIdx.x == 0) {
+            const double unb = M > 1 ? v * ((double)M / (double)(M - 1)) : v;
+            running_mean[c] = (1.0f - momentum) * running_mean[c] + momentum * mean;
+            running_var[c] = (1.0f - momentum) * running_var[c] + momentum * (float)unb;
+        }
+    } else {
+        mean = running_mean[c];
+        var = running_var[c];
+    }
+    if (threadIdx.x != 0) return;
+    const float invstd = 1.0f / sqrtf(var + eps);
+    const float g = gamma ? gamma[c] : 1.0f;
+    const float sc = g * invstd;
+    mean_out[c] = mean;
+    invstd_out[c] = invstd;
+    scale_out[c] = sc;
+    shift_out[c] = (beta ? beta[c] : 0.0f) - mean * sc;
+}
+
+// Grid-stride walk over a (rows, C) matrix in units of V floats that tracks the channel without a division per
+// element: the stride is a fixed number of elements, so the channel advances by (stride % C) modulo C.
+struct ChanWalk {
+    int c, step, C;
+    __device__ ChanWalk(int64_t e0, int64_t stride, int C_) : C(C_)
+    {
+        c = (int)(e0 % C_);
+        step = (int)(stride % C_);
+    }
+    __device__ __forceinline__ void next()
+    {
+        c += step;
+        if (c >= C) c -= C;
+    }
+};
+
+__device__ __forceinline__ float leaky(float z, float slope) { return z > 0.0f ? z : z * slope; }
+
+// A = act(scale*Y + shift), act = LeakyReLU(slope) (slope = 1 -> identity)
+template <int V>
+__global__ __launch_bounds__(RW_BLOCK) void bn_act_kernel(const float *__restrict__ Y,
+                                                           const float *__restrict__ scale,
+                                                           const float *__restrict__ shift, float slope,
+                                                           int64_t total, int C, float *__restrict__ out)
+{
+    const int64_t stride = (int64_t)gridDim.x * RW_BLOCK * V;
+    int64_t e = ((int64_t)blockIdx.x * RW_BLOCK + threadIdx.x) * V;
+    ChanWalk cw(e, stride, C);
+    for (; e < total; e += stride, cw.next()) {
+        if (V == 4) {
+            const float4 y = *reinterpret_cast<const float4 *>(Y + e);
+            const float4 sc = *reinterpret_cast<const float4 *>(scale + cw.c);
+            const float4 sh = *reinterpret_cast<const float4 *>(shift + cw.c);
+            float4 o;
+            o.x = leaky(y.x * sc.x + sh.x, slope);
+            o.y = leaky(y.y * sc.y + sh.y, slope);
+            o.z = leaky(y.z * sc.z + sh.z, slope);
+            o.w = leaky(y.w * sc.w + sh.w, slope);
+            *reinterpret_cast<float4 *>(out + e) = o;
+        } else {
+            out[e] = leaky(Y[e] * scale[cw.c] + shift[cw.c], slope);
+        }
+    }
+}
+
+// fused BN-affine + LeakyReLU + max over the ns consecutive rows of a group (first max wins, like max_pool2d)
+__global__ __launch_bounds__(RW_BLOCK) void bn_act_maxpool_kernel(const float *__restrict__ Y,
+                                                                   const float *__restrict__ scale,
+                                                                   const float *__restrict__ shift, float slope,
+                                                                   int64_t G, int ns, int C,
+                                                                   float *__restrict__ out, int *__restrict__ arg)
+{
+    const int64_t total = G * C;
+    for (int64_t e = (int64_t)blockIdx.x * RW_BLOCK + threadIdx.x; e < total; e += (int64_t)gridDim.x * RW_BLOCK) {
+        const int64_t g = e / C;
+        const int c = (int)(e - g * C);
+        const float sc = scale[c], sh = shift[c];
+        const float *y = Y + (size_t)g * ns * C + c;
+        float best = -INFINITY;
+        int bs = 0;
+        for (int s = 0; s < ns; ++s) {
+            const float z = y[(size_t)s * C] * sc + sh;
+            const float a = z > 0.0f ? z : z * slope;
+            if (a > best) {
+                best = a;
+                bs = s;
+            }
+        }
+        out[e] = best;
+        arg[e] = bs;
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
+// backward of  A = act(BN_train(Y)):  dZ = dA * act'(z);  dbeta = sum dZ;  dgamma = sum dZ * yhat
+//   pass 1: per-chunk partial sums of dZ and dZ*yhat (colreduce_partial_kernel<V, 1> above; pooled form below)
+// same reduction when dA is the gradient of the POOLED output: only the arg-max row of each group is non-zero
+__global__ __launch_bounds__(RW_BLOCK) void bn_pool_bwd_partial_kernel(const float *__restrict__ dP,
+                                                                        const int *__restrict__ arg,
+                                                                        const float *__restrict__ Y,
+                                                                        const float *__restrict__ scale,
+                                                                        const float *__restrict__ shift,
+                                                                        const float *__restrict__ mean,
+                                                                        const float *__restrict__ invstd, float slope,
+                                                                        int64_t G, int ns, int C,
+                                                                        float *__restrict__ partial)
+{
+    __shared__ float s1[4][64], s2[4][64];
+    const int tc = threadIdx.x & 63, tr = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + tc;
+    const int64_t g0 = (int64_t)blockIdx.y * ST_ROWS;
+    const int64_t g1 = min(g0 + ST_ROWS, G);
+    float a = 0.0f, q = 0.0f;
+    if (c < C) {
+        const float sc = scale[c], sh = shift[c], mu = mean[c], is = invstd[c];
+        for (int64_t g = g0 + tr; g < g1; g += 4) {
+            const int s = arg[g * C + c];
+            const float y = Y[((size_t)g * ns + s) * C + c];
+            const float z = y * sc + sh;
+            const float dz = dP[g * C + c] * (z > 0.0f ? 1.0f : slope);
+            a += dz;
+            q += dz * ((y - mu) * is);
+        }
+    }
+    s1[tr][tc] = a;
+    s2[tr][tc] = q;
+    __syncthreads();
+    if (tr == 0 && c < C) {
+        a = (s1[0][tc] + s1[1][tc]) + (s1[2][tc] + s1[3][tc]);
+        q = (s2[0][tc] + s2[1][tc]) + (s2[2][tc] + s2[3][tc]);
+        partial[((size_t)blockIdx.y * 2 + 0) * C + c] = a;
+        partial[((size_t)blockIdx.y * 2 + 1) * C + c] = q;
+    }
+}
+
+// sums the chunk partials: dbeta[c], dgamma[c]  (one workgroup per channel)
+__global__ __launch_bounds__(RW_BLOCK) void bn_bwd_finalize_kernel(const float *__restrict__ partial, int chunks,
+                                                                    int C, float *__restrict__ dbeta,
+                                                                    float *__restrict__ dgamma)
+{
+    double a, q;
+    sum_partials(partial, chunks, C, blockIdx.x, a, q);
+    if (threadIdx.x == 0) {
+        dbeta[blockIdx.x] = (float)a;
+        dgamma[blockIdx.x] = (float)q;
+    }
+}
+
+//   pass 2: dY = scale * (dZ - dbeta/M - yhat * dgamma/M)     (training);   dY = scale * dZ   (eval)
+__device__ __forceinline__ float bn_bwd_elem(float da, float y, float sc, float sh, float mu, float is, float db,
+                                             float dg, float slope, float invM, int training)
+{
+    const float z = y * sc + sh;
+    const float dz = da * (z > 0.0f ? 1.0f : slope);
+    float v = dz;
+    if (training) v = dz - db * invM - ((y - mu) * is) * (dg * invM);
+    return sc * v;
+}
+
+template <int V>
+__global__ __launch_bounds__(RW_BLOCK) void bn_act_bwd_apply_kernel(
+    const float *__restrict__ dA, const float *__restrict__ Y, const float *__restrict__ scale,
+    const float *__restrict__ shift, const float *__restrict__ mean, const float *__restrict__ invstd,
+    const float *__restrict__ dbeta, const float *__restrict__ dgamma, float slope, int64_t M, int C, int training,
+    float *__restrict__ dY)
+{
+    const int64_t total = M * C;
+    const float invM = 1.0f / (float)M;
+    const int64_t stride = (int64_t)gridDim.x * RW_BLOCK * V;
+    int64_t e = ((int64_t)blockIdx.x * RW_BLOCK + threadIdx.x) * V;
+    ChanWalk cw(e, stride, C);
+    for (; e < total; e += stride, cw.next()) {
+        float y[V], d[V], o[V];
+        if (V == 4) {
+            *reinterpret_cast<float4 *>(y) = *reinterpret_cast<const float4 *>(Y + e);
+            *reinterpret_cast<float4 *>(d) = *reinterpret_cast<const float4 *>(dA + e);
+        } else {
+            y[0] = Y[e];
+            d[0] = dA[e];
+        }
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+            const int c = cw.c + v;
+            o[v] = bn_bwd_elem(d[v], y[v], scale[c], shift[c], mean[c], invstd[c], dbeta[c], dgamma[c], slope, invM,
+                               training);
+        }
+        if (V == 4) *reinterpret_cast<float4 *>(dY + e) = *reinterpret_cast<float4 *>(o);
+        else dY[e] = o[0];
+    }
+}
+
+// pooled variant: dP (G, C) reaches only the arg-max row of each group; one lane per (group, channel) walks ns rows
+__global__ __launch_bounds__(RW_BLOCK) void bn_pool_bwd_apply_kernel(
+    const float *__restrict__ dP, const int *__restrict__ arg, const float *__restrict__ Y,
+    const float *__restrict__ scale, const float *__restrict__ shift, const float *__restrict__ mean,
+    const float *__restrict__ invstd, const float *__restrict__ dbeta, const float *__restrict__ dgamma, float slope,
+    int64_t G, int ns, int C, int training, float *__restrict__ dY)
+{
+    const int64_t total = G * C;
+    const float invM = 1.0f / (float)(G * ns);
+    for (int64_t e = (int64_t)blockIdx.x * RW_BLOCK + threadIdx.x; e < total; e += (int64_t)gridDim.x * RW_BLOCK) {
+        const int64_t g = e / C;
+        const int c = (int)(e - g * C);
+        const float sc = scale[c], sh = shift[c], mu = mean[c], is = invstd[c], db = dbeta[c], dg = dgamma[c];
+        const float dp = dP[e];
+        const int sa = arg[e];
+        const size_t base = (size_t)g * ns * C + c;
+        for (int s = 0; s < ns; ++s) {
+            const float y = Y[base + (size_t)s * C];
+            dY[base + (size_t)s * C] = bn_bwd_elem(s == sa ? dp : 0.0f, y, sc, sh, mu, is, db, dg, slope, invM, training);
+        }
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
+// three_nn weights + interpolation + skip concat (DenseFPModule.conv + BaseDenseConvolutionUp.forward):
+//   out[(b,i), :] = [ (w0*f0 + w1*f1) + w2*f2 , skip_cl[b,i,:] ],  f_t = feat_cl[b, idx[b,i,t], :]
+__global__ __launch_bounds__(RW_BLOCK) void interp_concat_fwd_kernel(const float *__restrict__ feat_cl,
+                                                                      const int64_t *__restrict__ idx,
+                                                                      const float *__restrict__ w,
+                                                                      const float *__restrict__ skip_cl, int m, int n,
+                                                                      int C1, int C2, int64_t total,
+                                                                      float *__restrict__ out)
+{
+    const int Cw = C1 + C2;
+    for (int64_t e = (int64_t)blockIdx.x * RW_BLOCK + threadIdx.x; e < total; e += (int64_t)gridDim.x * RW_BLOCK) {
+        const int64_t row = e / Cw;  // b*n + i
+        const int c = (int)(e - row * Cw);
+        float v;
+        if (c < C1) {
+            const int b = (int)(row / n);
+            const int64_t *ip = idx + row * 3;
+            const float *wp = w + row * 3;
+            const int k0 = min(max((int)ip[0], 0), m - 1), k1 = min(max((int)ip[1], 0), m - 1),
+                      k2 = min(max((int)ip[2], 0), m - 1);
+            const float *fb = feat_cl + (size_t)b * m * C1 + c;
+            const float a0 = wp[0] * fb[(size_t)k0 * C1];
+            const float a1 = wp[1] * fb[(size_t)k1 * C1];
+            const float a2 = wp[2] * fb[(size_t)k2 * C1];
+            v = (a0 + a1) + a2;
+        } else {
+            v = skip_cl[row * C2 + (c - C1)];
+        }
+        out[e] = v;
+    }
+}
+
+// inverse-distance weights exactly as the reference builds them (core/base_conv/dense.py:137-139):
+//   r_t = 1/(dist_t + 1e-8);  w_t = r_t / ((r0 + r1) + r2)
+__global__ void idw_weights_kernel(const float *__restrict__ dist, int64_t rows, float *__restrict__ w)
+{
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= rows) return;
+    const float r0 = 1.0f / (dist[r * 3 + 0] + 1e-8f);
+    const float r1 = 1.0f / (dist[r * 3 + 1] + 1e-8f);
+    const float r2 = 1.0f / (dist[r * 3 + 2] + 1e-8f);
+    const float norm = (r0 + r1) + r2;
+    w[r * 3 + 0] = r0 / norm;
+    w[r * 3 + 1] = r1 / norm;
+    w[r * 3 + 2] = r2 / norm;
+}
+
+static inline unsigned grid_for(int64_t total)
+{
+    int64_t g = (total + RW_BLOCK - 1) / RW_BLOCK;
+    return (unsigned)(g < 1 ? 1 : (g > 8192 ? 8192 : g));
+}
+
+}  // namespace tp3d
+
+using namespace tp3d;
+
+TP3D_EXPORT int tp3d_group_concat_fwd_f32(const float *pos, const float *new_pos, const float *x_cl,
+                                          const int64_t *idx, int B, int N, int np, int ns, int C, float radius,
+                                          int normalize, float *out, void *stream)
+{
+    if (B < 0 || N <= 0 || np < 0 || ns < 0 || C < 0) return TP3D_E_BADARG;
+    const int64_t total = (int64_t)B * np * ns * (C + 3);
+    if (total == 0) return TP3D_OK;
+    if (!pos || !new_pos || !idx || !out || (C > 0 && !x_cl)) return TP3D_E_BADARG;
+    hipLaunchKernelGGL(group_concat_fwd_kernel, dim3(grid_for(total)), dim3(RW_BLOCK), 0, (hipStream_t)stream, pos,
+                       new_pos, x_cl, idx, N, np, ns, C, radius, normalize, total, out);
+    return check_launch();
+}
+
+TP3D_EXPORT int tp3d_rows_scatter_bwd_f32(const float *grad_rows, const int64_t *idx, const float *weight, int B,
+                                          int L, int div, int nbins, int ld, int col0, int C, float *grad_x_cl,
+                                          void *workspace, size_t workspace_bytes, void *stream)
+{
+    // grad_rows: (B, L/div rows, ld); slot l of cloud b refers to row l/div; destinations: (B, nbins, C)
+    if (B < 0 || L < 0 || div <= 0 || nbins <= 0 || ld <= 0 || col0 < 0 || C < 0 || col0 + C > ld) return TP3D_E_BADARG;
+    if (B == 0 || C == 0) return TP3D_OK;
+    if (!grad_x_cl) return TP3D_E_BADARG;
+    hipStream_t s = (hipStream_t)stream;
+    if (L == 0) return zero_async(grad_x_cl, (size_t)B * nbins * C * sizeof(float), s);
+    if (!grad_rows || !idx || !workspace || B > 65535) return TP3D_E_BADARG;
+    ScatterWorkspace w = carve_scatter_workspace(workspace, B, L, nbins, weight != nullptr);
+    if (workspace_bytes < w.bytes) return TP3D_E_BADARG;
+    if (int rc = csr_transpose(idx, B, L, nbins, div, weight, w.start, w.order, w.wsorted, w.scratch, s)) return rc;
+    dim3 grid((nbins + RW_BLOCK / 64 - 1) / (RW_BLOCK / 64), B);
+    hipLaunchKernelGGL(rows_gather_sum_kernel, grid, dim3(RW_BLOCK), 0, s, grad_rows, w.start, w.order, w.wsorted,
+                       nbins, L, L / div, ld, col0, C, grad_x_cl);
+    return check_launch();
+}
+
+TP3D_EXPORT size_t tp3d_bn_workspace_floats(int64_t M, int C)
+{
+    if (M < 0 || C < 0) return 0;
+    return (size_t)((M + ST_ROWS - 1) / ST_ROWS) * 2 * (size_t)C;
+}
+
+TP3D_EXPORT int tp3d_bn_stats_f32(const float *Y, int64_t M, int C, float eps, float momentum, const float *gamma,
+                                  const float *beta, float *running_mean, float *running_var, int training,
+                                  float *mean, float *invstd, float *scale, float *shift, float *workspace,
+                                  void *stream)
+{
+    if (M <= 0 || C <= 0 || !mean || !invstd || !scale || !shift) return TP3D_E_BADARG;
+    if (!training && (!running_mean || !running_var)) return TP3D_E_BADARG;
+    hipStream_t s = (hipStream_t)stream;
+    const int chunks = (int)((M + ST_ROWS - 1) / ST_ROWS);
+    if (training) {
+        if (!Y || !workspace) return TP3D_E_BADARG;
+        if (chunks > 65535) return TP3D_E_TOOBIG;
+        if ((C & 3) == 0) {
+            const StatTile t = stat_tile(C, 4);
+            hipLaunchKernelGGL((colreduce_partial_kernel<4, 0>), dim3(t.gridx, chunks), dim3(RW_BLOCK), 0, s, Y,
+                               (const float *)nullptr, (const float *)nullptr, (const float *)nullptr,
+                               (const float *)nullptr, (const float *)nullptr, 0.0f, M, C, t.colthreads, workspace);
+        } else {
+            const StatTile t = stat_tile(C, 1);
+            hipLaunchKernelGGL((colreduce_partial_kernel<1, 0>), dim3(t.gridx, chunks), dim3(RW_BLOCK), 0, s, Y,
+                               (const float *)nullptr, (const float *)nullptr, (const float *)nullptr,
+                               (const float *)nullptr, (const float *)nullptr, 0.0f, M, C, t.colthreads, workspace);
+        }
+        if (int rc = check_launch()) return rc;
+    }
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(RW_BLOCK), 0, s, workspace, chunks, M, C, eps, momentum, gamma,
+                       beta, running_mean, running_var, training, mean, invstd, scale, shift);
+    return check_launch();
+}
+
+TP3D_EXPORT int tp3d_bn_act_f32(const float *Y, const float *scale, const float *shift, float slope, int64_t M, int C,
+                                float *out, void *stream)
+{
+    if (M < 0 || C <= 0) return TP3D_E_BADARG;
+    if (M == 0) return TP3D_OK;
+    if (!Y || !scale || !shift || !out) return TP3D_E_BADARG;
+    const int64_t total = M * C;
+    if ((C & 3) == 0)
+        hipLaunchKernelGGL(bn_act_kernel<4>, dim3(grid_for(total / 4)), dim3(RW_BLOCK), 0, (hipStream_t)stream, Y, scale,
+                           shift, slope, total, C, out);
+    else
+        hipLaunchKernelGGL(bn_act_kernel<1>, dim3(grid_for(total)), dim3(RW_BLOCK), 0, (hipStream_t)stream, Y, scale,
+                           shift, slope, total, C, out);
+    return check_launch();
+}
+
+TP3D_EXPORT int tp3d_bn_act_maxpool_f32(const float *Y, const float *scale, const float *shift, float slope,
+                                        int64_t G, int ns, int C, float *out, int *argmax, void *stream)
+{
+    if (G < 0 || ns <= 0 || C <= 0) return TP3D_E_BADARG;
+    if (G == 0) return TP3D_OK;
+    if (!Y || !scale || !shift || !out || !argmax) return TP3D_E_BADARG;
+    hipLaunchKernelGGL(bn_act_maxpool_kernel, dim3(grid_for(G * C)), dim3(RW_BLOCK), 0, (hipStream_t)stream, Y, scale,
+                       shift, slope, G, ns, C, out, argmax);
+    return check_launch();
+}
+
+TP3D_EXPORT int tp3d_bn_act_bwd_f32(const float *dA, const int *argmax, const float *Y, const float *scale,
+                                    const float *shift, const float *mean, const float *invstd, float slope,
+                                    int64_t M, int ns, int C, int training, float *dbeta, float *dgamma, float *dY,
+                                    float *workspace, void *stream)
+{
+    // dA: (M, C) dense when argmax == NULL, else the pooled gradient (M/ns, C) with its arg-max rows
+    if (M <= 0 || C <= 0 || ns <= 0 || (argmax && M % ns)) return TP3D_E_BADARG;
+    if (!dA || !Y || !scale || !shift || !mean || !invstd || !dbeta || !dgamma || !dY || !workspace)
+        return TP3D_E_BADARG;
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t R = argmax ? M / ns : M;  // rows of the reduction domain
+    const int chunks = (int)((R + ST_ROWS - 1) / ST_ROWS);
+    if (chunks > 65535) return TP3D_E_TOOBIG;
+    if (argmax) {
+        hipLaunchKernelGGL(bn_pool_bwd_partial_kernel, dim3((C + 63) / 64, chunks), dim3(RW_BLOCK), 0, s, dA, argmax, Y,
+                           scale, shift, mean, invstd, slope, R, ns, C, workspace);
+    } else if ((C & 3) == 0) {
+        const StatTile t = stat_tile(C, 4);
+        hipLaunchKernelGGL((colreduce_partial_kernel<4, 1>), dim3(t.gridx, chunks), dim3(RW_BLOCK), 0, s, Y, dA, scale,
+                           shift, mean, invstd, slope, M, C, t.colthreads, workspace);
+    } else {
+        const StatTile t = stat_tile(C, 1);
+        hipLaunchKernelGGL((colreduce_partial_kernel<1, 1>), dim3(t.gridx, chunks), dim3(RW_BLOCK), 0, s, Y, dA, scale,
+                           shift, mean, invstd, slope, M, C, t.colthreads, workspace);
+    }
+    if (int rc = check_launch()) return rc;
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(RW_BLOCK), 0, s, workspace, chunks, C, dbeta, dgamma);
+    if (int rc = check_launch()) return rc;
+    if (argmax)
+        hipLaunchKernelGGL(bn_pool_bwd_apply_kernel, dim3(grid_for(R * C)), dim3(RW_BLOCK), 0, s, dA, argmax, Y, scale,
+                           shift, mean, invstd, dbeta, dgamma, slope, R, ns, C, training, dY);
+    else if ((C & 3) == 0)
+        hipLaunchKernelGGL(bn_act_bwd_apply_kernel<4>, dim3(grid_for(M * C / 4)), dim3(RW_BLOCK), 0, s, dA, Y, scale,
+                           shift, mean, invstd, dbeta, dgamma, slope, M, C, training, dY);
+    else
+        hipLaunchKernelGGL(bn_act_bwd_apply_kernel<1>, dim3(grid_for(M * C)), dim3(RW_BLOCK), 0, s, dA, Y, scale,
+                           shift, mean, invstd, dbeta, dgamma, slope, M, C, training, dY);
+    return check_launch();
+}
+
+TP3D_EXPORT int tp3d_interp_concat_fwd_f32(const float *feat_cl, const int64_t *idx, const float *weight,
+                                           const float *skip_cl, int B, int m, int n, int C1, int C2, float *out,
+                                           void *stream)
+{
+    if (B < 0 || m <= 0 || n < 0 || C1 < 0 || C2 < 0) return TP3D_E_BADARG;
+    const int64_t total = (int64_t)B * n * (C1 + C2);
+    if (total == 0) return TP3D_OK;
+    if (!out || (C1 > 0 && (!feat_cl || !idx || !weight)) || (C2 > 0 && !skip_cl)) return TP3D_E_BADARG;
+    hipLaunchKernelGGL(interp_concat_fwd_kernel, dim3(grid_for(total)), dim3(RW_BLOCK), 0, (hipStream_t)stream,
+                       feat_cl, idx, weight, skip_cl, m, n, C1, C2, total, out);
+    return check_launch();
+}
+
+TP3D_EXPORT int tp3d_idw_weights_f32(const float *dist, int64_t rows, float *weight, void *stream)
+{
+    if (rows < 0) return TP3D_E_BADARG;
+    if (rows == 0) return TP3D_OK;
+    if (!dist || !weight) return TP3D_E_BADARG;
+    hipLaunchKernelGGL(idw_weights_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       dist, rows, weight);
+    return check_launch();
+}

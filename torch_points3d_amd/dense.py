@@ -19,6 +19,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import fused as _fused
 from . import torchpoints as _hip_kernels
 
 
@@ -141,6 +142,15 @@ class DenseRadiusNeighbourFinder(object):
         return self.find_neighbours(x, y, scale_idx)
 
 
+def _is_channel_last(t):
+    return t.dim() == 3 and t.stride(1) == 1 and t.transpose(1, 2).is_contiguous()
+
+
+def _use_fused(tp, *tensors):
+    """The fused channel-last kernels serve the HIP product path only (never the oracle-driven CPU graph)."""
+    return tp is _hip_kernels and all(t is None or t.is_cuda for t in tensors)
+
+
 class BaseDenseConvolutionDown(nn.Module):
     """sample -> gather centroids -> per scale (radius search + conv) -> concat   (reference dense.py:60-87)."""
 
@@ -163,7 +173,12 @@ class BaseDenseConvolutionDown(nn.Module):
         for scale_idx in range(self.neighbour_finder.num_scales):
             radius_idx = self.neighbour_finder(pos, new_pos, scale_idx=scale_idx)
             ms_x.append(self.conv(x, pos, new_pos, radius_idx, scale_idx))
-        new_data = Data(pos=new_pos, x=torch.cat(ms_x, 1))
+        if all(_is_channel_last(t) for t in ms_x):
+            # fused path: scales are (B, C_i, np) VIEWS of channel-last storage; concatenate the storage itself
+            new_x = ms_x[0] if len(ms_x) == 1 else torch.cat([t.transpose(1, 2) for t in ms_x], 2).transpose(1, 2)
+        else:
+            new_x = torch.cat(ms_x, 1)
+        new_data = Data(pos=new_pos, x=new_x)
         if self._save_sampling_id:
             setattr(new_data, "sampling_id_{}".format(self._index), idx[:, :, 0])
         return new_data
@@ -173,12 +188,13 @@ class PointNetMSGDown(BaseDenseConvolutionDown):
     """PointNet++ set abstraction (single or multi scale): group -> centre -> [xyz, feats] -> MLP2D -> max."""
 
     def __init__(self, npoint=None, radii=None, nsample=None, down_conv_nn=None, bn=True, activation=None,
-                 use_xyz=True, normalize_xyz=False, kernels=None, **kwargs):
+                 use_xyz=True, normalize_xyz=False, kernels=None, fused=True, **kwargs):
         assert len(radii) == len(nsample) == len(down_conv_nn)
         tp = kernels or _hip_kernels
         super().__init__(DenseFPSSampler(num_to_sample=npoint, kernels=tp),
                          DenseRadiusNeighbourFinder(radii, nsample, kernels=tp), **kwargs)
         self._tp = tp
+        self.fused = fused
         self.use_xyz = use_xyz
         self.npoint = npoint
         self.radii = radii
@@ -198,8 +214,26 @@ class PointNetMSGDown(BaseDenseConvolutionDown):
             return torch.cat([grouped_pos, grouped_features], dim=1)  # (B,3+C,np,ns), xyz first
         return grouped_features
 
+    def _conv_fused(self, parts, x, pos, new_pos, radius_idx, scale_idx):
+        """Same arithmetic on (rows, C) activations: HIP gather/BN/act/pool kernels around library GEMMs."""
+        B, npnt, ns = radius_idx.shape
+        x_cl = None
+        if x is not None and self.use_xyz:
+            x_cl = _fused._cl(x)
+        elif x is not None:
+            return None  # use_xyz=False never occurs in the bundled configs: keep it on the reference graph
+        rows = _fused.group_concat(pos, new_pos, x_cl, radius_idx, self.radii[scale_idx], self.normalize_xyz)
+        pooled = _fused.run_mlp(rows, parts, pool_ns=ns)  # (B*np, Cout)
+        return pooled.view(B, npnt, -1).transpose(1, 2)  # (B, Cout, np) view of channel-last storage
+
     def conv(self, x, pos, new_pos, radius_idx, scale_idx):
         assert scale_idx < len(self.mlps)
+        if self.fused and _use_fused(self._tp, x, pos):
+            parts = _fused.mlp_parts(self.mlps[scale_idx])
+            if parts is not None:
+                out = self._conv_fused(parts, x, pos, new_pos, radius_idx, scale_idx)
+                if out is not None:
+                    return out
         feats = self._prepare_features(x, pos, new_pos, radius_idx, scale_idx)
         feats = self.mlps[scale_idx](feats)
         feats = F.max_pool2d(feats, kernel_size=[1, feats.size(3)])
@@ -218,6 +252,9 @@ class BaseDenseConvolutionUp(nn.Module):
 
     def forward(self, data, **kwargs):
         data, data_skip = data
+        fused_out = self._forward_fused(data, data_skip) if hasattr(self, "_forward_fused") else None
+        if fused_out is not None:
+            return Data(x=fused_out, pos=data_skip.pos)
         new_features = self.conv(data.pos, data_skip.pos, data.x)
         if data_skip.x is not None:
             new_features = torch.cat([new_features, data_skip.x], dim=1)
@@ -230,10 +267,31 @@ class BaseDenseConvolutionUp(nn.Module):
 class DenseFPModule(BaseDenseConvolutionUp):
     """PointNet++ feature propagation: inverse-distance 3-NN interpolation + skip concat + MLP2D."""
 
-    def __init__(self, up_conv_nn, bn=True, bias=False, activation=None, kernels=None, **kwargs):
+    def __init__(self, up_conv_nn, bn=True, bias=False, activation=None, kernels=None, fused=True, **kwargs):
         super().__init__(None, **kwargs)
         self._tp = kernels or _hip_kernels
+        self.fused = fused
         self.nn = MLP2D(up_conv_nn, bn=bn, activation=activation, bias=False)
+
+    def _forward_fused(self, data, data_skip):
+        """interpolate + skip concat + MLP on (rows, C): HIP kernels around library GEMMs; None -> reference graph."""
+        if not (self.fused and _use_fused(self._tp, data.x, data_skip.pos, data_skip.x)):
+            return None
+        parts = _fused.mlp_parts(self.nn)
+        if parts is None:
+            return None
+        pos, pos_skip, x, x_skip = data.pos, data_skip.pos, data.x, data_skip.x
+        B, n = pos_skip.shape[0], pos_skip.shape[1]
+        skip_cl = None if x_skip is None else _fused._cl(x_skip)
+        if pos is None:  # below the global module: one feature column broadcast to every skip point
+            rows = x.transpose(1, 2).expand(B, n, x.shape[1])
+            rows = torch.cat([rows, skip_cl], 2) if skip_cl is not None else rows.contiguous()
+            rows = rows.reshape(B * n, -1)
+        else:
+            dist, idx = self._tp.three_nn(pos_skip, pos)
+            rows = _fused.interp_concat(_fused._cl(x), idx, _fused.idw_weights(dist), skip_cl)
+        out = _fused.run_mlp(rows, parts)
+        return out.view(B, n, -1).transpose(1, 2)
 
     def conv(self, pos, pos_skip, x):
         assert pos_skip.shape[2] == 3
@@ -248,14 +306,22 @@ class DenseFPModule(BaseDenseConvolutionUp):
 class GlobalDenseBaseModule(nn.Module):
     """MLP2D over [x, pos] of all points then max/mean over points; returns pos=None (dense.py:169-184)."""
 
-    def __init__(self, nn, aggr="max", bn=True, activation=None, **kwargs):
+    def __init__(self, nn, aggr="max", bn=True, activation=None, fused=True, **kwargs):
         super().__init__()
+        self.fused = fused
         self.nn = MLP2D(nn, bn=bn, activation=activation, bias=False)
         if aggr.lower() not in ["mean", "max"]:
             raise Exception("The aggregation provided is unrecognized {}".format(aggr))
         self._aggr = aggr.lower()
 
     def forward(self, data, **kwargs):
+        if self.fused and self._aggr == "max" and data.x.is_cuda:
+            parts = _fused.mlp_parts(self.nn)
+            if parts is not None:
+                B, n = data.pos.shape[0], data.pos.shape[1]
+                rows = torch.cat([_fused._cl(data.x), data.pos], 2).reshape(B * n, -1)  # channel order [x, pos]
+                pooled = _fused.run_mlp(rows, parts, pool_ns=n)  # max over all points of a cloud
+                return Data(x=pooled.view(B, -1, 1), pos=None)
         x = self.nn(torch.cat([data.x, data.pos.transpose(1, 2).contiguous()], dim=1).unsqueeze(-1)).squeeze(-1)
         x = x.max(-1)[0] if self._aggr == "max" else x.mean(-1)
         return Data(x=x.unsqueeze(-1), pos=None)

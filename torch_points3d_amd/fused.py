@@ -1,0 +1,233 @@
+"""Channel-last fused implementation of the grouped-MLP aggregation.
+
+The reference materialises (B, C, npoint, nsample) tensors and runs Conv2d 1x1 -> BatchNorm2d -> LeakyReLU ->
+max_pool2d on them (modules/pointnet2/dense.py:36-75, core/common_modules/dense_modules.py:5-29).  Here the same
+arithmetic runs on (rows, C) row-major activations: hand-written HIP kernels (csrc/rows.hip) do the gather /
+centre / concat, the BatchNorm statistics, the folded affine + LeakyReLU (+ max over nsample) and every
+backward pass; only the dense contractions are issued as plain library GEMMs (torch.mm -> rocBLAS/hipBLASLt).
+Parameters and buffers are read from the very same nn.Conv2d / nn.BatchNorm2d modules the reference layout
+defines, so state_dict keys and checkpoints are unchanged.
+"""
+import torch
+import torch.nn as nn
+
+from . import _lib
+
+
+def _cl(x):
+    """(B, C, N) tensor -> its (B, N, C) contiguous channel-last form (free when x is a transposed view)."""
+    return x.transpose(1, 2).contiguous()
+
+
+def _slope_of(act):
+    if act is None:
+        return 1.0
+    if isinstance(act, nn.LeakyReLU):
+        return float(act.negative_slope)
+    if isinstance(act, nn.ReLU):
+        return 0.0
+    return None
+
+
+def layer_parts(block):
+    """(conv, bn, slope) of a Conv2D/Conv1D Seq block if the fused kernels can run it, else None."""
+    mods = list(block.children())
+    if not mods or not isinstance(mods[0], (nn.Conv2d, nn.Conv1d)):
+        return None
+    conv = mods[0]
+    if conv.bias is not None or any(k != 1 for k in conv.kernel_size):
+        return None
+    bn, act = None, None
+    for m in mods[1:]:
+        if isinstance(m, (nn.BatchNorm2d, nn.BatchNorm1d)) and bn is None and act is None:
+            bn = m
+        elif act is None:
+            act = m
+        else:
+            return None
+    if bn is None or not bn.affine or not bn.track_running_stats or bn.momentum is None:
+        return None
+    slope = _slope_of(act)
+    if slope is None:
+        return None
+    return conv, bn, slope
+
+
+def mlp_parts(mlp):
+    parts = [layer_parts(b) for b in mlp.children()]
+    return None if (not parts or any(p is None for p in parts)) else parts
+
+
+def gemm_tn(dY, A):
+    """dY (M,N), A (M,K) -> dY^T @ A (N,K): split-K fp32 MFMA kernel (csrc/gemm_tn.hip), reproducible."""
+    dev = dY.device
+    dY, A = dY.contiguous(), A.contiguous()
+    M, N = dY.shape
+    K = A.shape[1]
+    out = torch.empty((N, K), dtype=torch.float32, device=dev)
+    nws = _lib.load().tp3d_gemm_tn_workspace_floats(M, N, K)
+    ws = torch.empty(max(nws, 4), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        _lib.call("tp3d_gemm_tn_f32", _lib.ptr(dY), _lib.ptr(A), M, N, K, _lib.ptr(out), _lib.ptr(ws),
+                  _lib.stream_ptr(dev))
+    return out
+
+
+class _LinearBNAct(torch.autograd.Function):
+    """out = LeakyReLU(BatchNorm(A @ W^T)) on rows; with pool_ns > 0 also the max over groups of pool_ns rows."""
+
+    @staticmethod
+    def forward(ctx, A, weight, gamma, beta, bn, slope, pool_ns):
+        dev = A.device
+        A = A.contiguous()
+        M, Cin = A.shape
+        Cout = weight.shape[0]
+        W2 = weight.reshape(Cout, Cin)
+        Y = torch.mm(A, W2.t())  # the dense contraction: a plain library GEMM
+        training = bn.training
+        stats = torch.empty((4, Cout), dtype=torch.float32, device=dev)  # mean, invstd, scale, shift
+        ws = _lib.bn_workspace(M, Cout, dev)
+        st = _lib.stream_ptr(dev)
+        with torch.cuda.device(dev):
+            _lib.call("tp3d_bn_stats_f32", _lib.ptr(Y), M, Cout, float(bn.eps), float(bn.momentum),
+                      _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(bn.running_mean), _lib.ptr(bn.running_var),
+                      int(training), _lib.ptr(stats[0]), _lib.ptr(stats[1]), _lib.ptr(stats[2]), _lib.ptr(stats[3]),
+                      _lib.ptr(ws), st)
+            if pool_ns:
+                G = M // pool_ns
+                out = torch.empty((G, Cout), dtype=torch.float32, device=dev)
+                arg = torch.empty((G, Cout), dtype=torch.int32, device=dev)
+                _lib.call("tp3d_bn_act_maxpool_f32", _lib.ptr(Y), _lib.ptr(stats[2]), _lib.ptr(stats[3]), slope, G,
+                          pool_ns, Cout, _lib.ptr(out), _lib.ptr(arg), st)
+            else:
+                arg = None
+                out = torch.empty((M, Cout), dtype=torch.float32, device=dev)
+                _lib.call("tp3d_bn_act_f32", _lib.ptr(Y), _lib.ptr(stats[2]), _lib.ptr(stats[3]), slope, M, Cout,
+                          _lib.ptr(out), st)
+        if training:
+            bn.num_batches_tracked.add_(1)
+        ctx.save_for_backward(A, W2, Y, stats, arg)
+        ctx.cfg = (slope, pool_ns, training, tuple(weight.shape))
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        A, W2, Y, stats, arg = ctx.saved_tensors
+        slope, pool_ns, training, wshape = ctx.cfg
+        dev = grad_out.device
+        grad_out = grad_out.contiguous()
+        M, Cout = Y.shape
+        dY = torch.empty_like(Y)
+        dgb = torch.empty((2, Cout), dtype=torch.float32, device=dev)  # dbeta, dgamma
+        ws = _lib.bn_workspace(M, Cout, dev)
+        with torch.cuda.device(dev):
+            _lib.call("tp3d_bn_act_bwd_f32", _lib.ptr(grad_out), _lib.ptr(arg), _lib.ptr(Y), _lib.ptr(stats[2]),
+                      _lib.ptr(stats[3]), _lib.ptr(stats[0]), _lib.ptr(stats[1]), slope, M, max(pool_ns, 1), Cout,
+                      int(training), _lib.ptr(dgb[0]), _lib.ptr(dgb[1]), _lib.ptr(dY), _lib.ptr(ws),
+                      _lib.stream_ptr(dev))
+        dW = gemm_tn(dY, A).reshape(wshape) if ctx.needs_input_grad[1] else None
+        dA = torch.mm(dY, W2) if ctx.needs_input_grad[0] else None
+        return dA, dW, dgb[1], dgb[0], None, None, None
+
+
+def linear_bn_act(A, conv, bn, slope, pool_ns=0):
+    return _LinearBNAct.apply(A, conv.weight, bn.weight, bn.bias, bn, slope, pool_ns)
+
+
+def run_mlp(rows, parts, pool_ns=0):
+    """Shared MLP over rows; the last layer optionally max-pools groups of pool_ns consecutive rows."""
+    for i, (conv, bn, slope) in enumerate(parts):
+        rows = linear_bn_act(rows, conv, bn, slope, pool_ns if i == len(parts) - 1 else 0)
+    return rows
+
+
+class _GroupConcat(torch.autograd.Function):
+    """rows[(b,j,s)] = [pos[b,idx]-new_pos[b,j] (/r), x_cl[b,idx]]; differentiable wrt x_cl."""
+
+    @staticmethod
+    def forward(ctx, pos, new_pos, x_cl, idx, radius, normalize):
+        dev = pos.device
+        B, N, _ = pos.shape
+        _, npnt, ns = idx.shape
+        C = 0 if x_cl is None else x_cl.shape[2]
+        pos, new_pos, idx = pos.contiguous(), new_pos.contiguous(), idx.contiguous()
+        xc = None if x_cl is None else x_cl.contiguous()
+        out = torch.empty((B * npnt * ns, C + 3), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            _lib.call("tp3d_group_concat_fwd_f32", _lib.ptr(pos), _lib.ptr(new_pos), _lib.ptr(xc), _lib.ptr(idx), B, N,
+                      npnt, ns, C, float(radius), int(bool(normalize)), _lib.ptr(out), _lib.stream_ptr(dev))
+        ctx.save_for_backward(idx)
+        ctx.dims = (B, N, npnt, ns, C)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_rows):
+        (idx,) = ctx.saved_tensors
+        B, N, npnt, ns, C = ctx.dims
+        if C == 0 or not ctx.needs_input_grad[2]:
+            return None, None, None, None, None, None
+        dev = grad_rows.device
+        grad_rows = grad_rows.contiguous()
+        g = torch.empty((B, N, C), dtype=torch.float32, device=dev)
+        L = npnt * ns
+        ws, ws_bytes = _lib.scatter_workspace(B, L, N, False, dev)
+        with torch.cuda.device(dev):
+            _lib.call("tp3d_rows_scatter_bwd_f32", _lib.ptr(grad_rows), _lib.ptr(idx), None, B, L, 1, N, C + 3, 3, C,
+                      _lib.ptr(g), _lib.ptr(ws), ws_bytes, _lib.stream_ptr(dev))
+        return None, None, g, None, None, None
+
+
+def group_concat(pos, new_pos, x_cl, idx, radius, normalize):
+    return _GroupConcat.apply(pos, new_pos, x_cl, idx, radius, normalize)
+
+
+class _InterpConcat(torch.autograd.Function):
+    """rows[(b,i)] = [sum_t w_t * feat_cl[b, idx_t], skip_cl[b,i]]; differentiable wrt feat_cl and skip_cl."""
+
+    @staticmethod
+    def forward(ctx, feat_cl, idx, weight, skip_cl):
+        dev = feat_cl.device
+        B, m, C1 = feat_cl.shape
+        n = idx.shape[1]
+        C2 = 0 if skip_cl is None else skip_cl.shape[2]
+        feat_cl, idx, weight = feat_cl.contiguous(), idx.contiguous(), weight.contiguous()
+        sk = None if skip_cl is None else skip_cl.contiguous()
+        out = torch.empty((B * n, C1 + C2), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            _lib.call("tp3d_interp_concat_fwd_f32", _lib.ptr(feat_cl), _lib.ptr(idx), _lib.ptr(weight), _lib.ptr(sk), B,
+                      m, n, C1, C2, _lib.ptr(out), _lib.stream_ptr(dev))
+        ctx.save_for_backward(idx, weight)
+        ctx.dims = (B, m, n, C1, C2)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_rows):
+        idx, weight = ctx.saved_tensors
+        B, m, n, C1, C2 = ctx.dims
+        dev = grad_rows.device
+        grad_rows = grad_rows.contiguous()
+        g_feat = None
+        if ctx.needs_input_grad[0]:
+            g_feat = torch.empty((B, m, C1), dtype=torch.float32, device=dev)
+            ws, ws_bytes = _lib.scatter_workspace(B, 3 * n, m, True, dev)
+            with torch.cuda.device(dev):
+                _lib.call("tp3d_rows_scatter_bwd_f32", _lib.ptr(grad_rows), _lib.ptr(idx), _lib.ptr(weight), B, 3 * n,
+                          3, m, C1 + C2, 0, C1, _lib.ptr(g_feat), _lib.ptr(ws), ws_bytes, _lib.stream_ptr(dev))
+        g_skip = None
+        if C2 and ctx.needs_input_grad[3]:
+            g_skip = grad_rows.view(B, n, C1 + C2)[:, :, C1:]
+        return g_feat, None, None, g_skip
+
+
+def interp_concat(feat_cl, idx, weight, skip_cl):
+    return _InterpConcat.apply(feat_cl, idx, weight, skip_cl)
+
+
+def idw_weights(dist):
+    """(1/(d+1e-8)) / sum over the 3 neighbours, evaluated in the reference's order (dense.py:137-139)."""
+    dev = dist.device
+    dist = dist.contiguous()
+    w = torch.empty_like(dist)
+    with torch.cuda.device(dev):
+        _lib.call("tp3d_idw_weights_f32", _lib.ptr(dist), dist.numel() // 3, _lib.ptr(w), _lib.stream_ptr(dev))
+    return w

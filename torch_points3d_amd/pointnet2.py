@@ -9,6 +9,7 @@ therefore state_dict keys are the reference's, so its checkpoints load unchanged
 import torch
 import torch.nn as nn
 
+from . import fused as _fused
 from .dense import Conv1D, Data, DenseFPModule, GlobalDenseBaseModule, PointNetMSGDown, Seq
 
 
@@ -45,20 +46,25 @@ def unet_config(name, feat):
 class PointNet2Unet(nn.Module):
     """Input -- D1 -- D2 -- I -- U1 -- U2 -- U3 -- (head), symmetric skips (applications/pointnet2.py:154-191)."""
 
-    def __init__(self, input_nc, output_nc=None, config="unet_3_ss", kernels=None, activation=None):
-        """`activation` (default LeakyReLU(0.01), as the reference modules) is shared by every layer."""
+    def __init__(self, input_nc, output_nc=None, config="unet_3_ss", kernels=None, activation=None, fused=True):
+        """`activation` (default LeakyReLU(0.01), as the reference modules) is shared by every layer.
+        `fused=False` keeps the reference's (B,C,np,ns) PyTorch graph around the HIP spatial kernels."""
         super().__init__()
+        self.fused = fused
         cfg = unet_config(config, input_nc) if isinstance(config, str) else config
         self.config = cfg
+        self._kernels_are_hip = kernels is None
         self.down_modules = nn.ModuleList()
         for i in range(len(cfg["down_conv_nn"])):
             self.down_modules.append(PointNetMSGDown(
                 npoint=cfg["npoint"][i], radii=cfg["radii"][i], nsample=cfg["nsample"][i],
                 down_conv_nn=cfg["down_conv_nn"][i], normalize_xyz=cfg["normalize_xyz"][i],
-                save_sampling_id=cfg["save_sampling_id"][i], index=i, kernels=kernels, activation=activation))
-        self.inner_modules = nn.ModuleList([GlobalDenseBaseModule(nn=cfg["innermost"], activation=activation)])
+                save_sampling_id=cfg["save_sampling_id"][i], index=i, kernels=kernels, activation=activation,
+                fused=fused))
+        self.inner_modules = nn.ModuleList([GlobalDenseBaseModule(nn=cfg["innermost"], activation=activation,
+                                                                  fused=fused and kernels is None)])
         self.up_modules = nn.ModuleList(
-            DenseFPModule(up_conv_nn=c, index=i, kernels=kernels, activation=activation)
+            DenseFPModule(up_conv_nn=c, index=i, kernels=kernels, activation=activation, fused=fused)
             for i, c in enumerate(cfg["up_conv_nn"]))
         self._output_nc = cfg["up_conv_nn"][-1][-1]
         self.has_mlp_head = output_nc is not None
@@ -74,7 +80,13 @@ class PointNet2Unet(nn.Module):
     def forward(self, data):
         """data.pos (B,N,3), data.x (B,N,C) or None -> Data(pos (B,N,3), x (B,output_nc,N))."""
         assert data.pos.dim() == 3
-        x = data.x.transpose(1, 2).contiguous() if data.x is not None else None
+        x = None
+        if data.x is not None:
+            # the reference makes (B,C,N) contiguous (pointnet2.py:118-121); the fused modules consume the
+            # channel-last storage directly, so there the transposed VIEW is handed on instead of a copy
+            x = data.x.transpose(1, 2)
+            if not (self.fused and self._kernels_are_hip and x.is_cuda):
+                x = x.contiguous()
         cur = Data(pos=data.pos, x=x)
         stack_down = [cur]
         for i in range(len(self.down_modules) - 1):
@@ -93,8 +105,17 @@ class PointNet2Unet(nn.Module):
         for k, v in sampling_ids.items():
             setattr(cur, k, v)
         if self.has_mlp_head:
-            cur.x = self.mlp(cur.x)
+            cur.x = self._head(cur.x)
         return cur
+
+    def _head(self, x):
+        if self.fused and x.is_cuda and self._kernels_are_hip:
+            parts = _fused.mlp_parts(self.mlp)
+            if parts is not None:
+                B, _, n = x.shape
+                out = _fused.run_mlp(_fused._cl(x).reshape(B * n, -1), parts)
+                return out.view(B, n, -1).transpose(1, 2)
+        return self.mlp(x)
 
 
 def PointNet2(architecture="unet", input_nc=None, num_layers=3, output_nc=None, multiscale=False, kernels=None):
