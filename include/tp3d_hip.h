@@ -35,7 +35,7 @@ extern "C" {
 #define TP3D_E_UNSORTED (-3) /* reserved: batch vector not sorted (checked by the host wrapper) */
 #define TP3D_E_TOOBIG (-4)   /* size exceeds what the kernel's index arithmetic supports */
 
-#define TP3D_ABI_VERSION 4
+#define TP3D_ABI_VERSION 5
 
 int tp3d_abi_version(void);
 const char *tp3d_strerror(int code);
@@ -115,10 +115,12 @@ int tp3d_group_bwd_f32(const float *grad_out, const int64_t *idx, int B, int C, 
  * row-major fp32; the GEMMs themselves are plain library GEMMs issued by the host wrapper.
  * ===================================================================================================== */
 
-/* out[(b,j,s), :] = [ (pos[b,idx[b,j,s]] - new_pos[b,j]) (/ radius if normalize), x_cl[b,idx[b,j,s], 0:C] ]
- * pos (B,N,3), new_pos (B,np,3), x_cl (B,N,C) or NULL when C == 0, idx (B,np,ns) -> out (B*np*ns, 3+C). */
+/* out[(b,j,s), :] = [ (pos[b,idx[b,j,s]] - new_pos[b,j]) (/ radius if normalize), x_cl[b,idx[b,j,s], 0:C], 0.. ]
+ * pos (B,N,3), new_pos (B,np,3), x_cl (B,N,C) or NULL when C == 0, idx (B,np,ns) -> out (B*np*ns, ld),
+ * ld >= 3+C; columns past 3+C are written as zeros (row padding for 16-byte aligned GEMM operands). */
 int tp3d_group_concat_fwd_f32(const float *pos, const float *new_pos, const float *x_cl, const int64_t *idx, int B,
-                              int N, int np, int ns, int C, float radius, int normalize, float *out, void *stream);
+                              int N, int np, int ns, int C, int ld, float radius, int normalize, float *out,
+                              void *stream);
 
 /* Scatter-add of row gradients back onto their source points, atomic-free (inverse index + gather-sum):
  *   grad_x_cl[b,k,0:C] = sum over slots l of cloud b with idx[b,l] == k (ascending l) of
@@ -150,10 +152,10 @@ int tp3d_bn_act_bwd_f32(const float *dA, const int *argmax, const float *Y, cons
                         const float *mean, const float *invstd, float slope, int64_t M, int ns, int C, int training,
                         float *dbeta, float *dgamma, float *dY, float *workspace, void *stream);
 
-/* out[(b,i), :] = [ (w0*f0 + w1*f1) + w2*f2 , skip_cl[b,i,0:C2] ],  f_t = feat_cl[b, idx[b,i,t], 0:C1]
- * feat_cl (B,m,C1), idx/weight (B,n,3), skip_cl (B,n,C2) or NULL -> out (B*n, C1+C2). */
+/* out[(b,i), :] = [ (w0*f0 + w1*f1) + w2*f2 , skip_cl[b,i,0:C2], 0.. ],  f_t = feat_cl[b, idx[b,i,t], 0:C1]
+ * feat_cl (B,m,C1), idx/weight (B,n,3), skip_cl (B,n,C2) or NULL -> out (B*n, ld), ld >= C1+C2 (zero padded). */
 int tp3d_interp_concat_fwd_f32(const float *feat_cl, const int64_t *idx, const float *weight, const float *skip_cl,
-                               int B, int m, int n, int C1, int C2, float *out, void *stream);
+                               int B, int m, int n, int C1, int C2, int ld, float *out, void *stream);
 
 /* Weight gradient of a 1x1 conv / shared-MLP layer:  out[n,k] = sum_r dY[r,n] * A[r,k]
  * dY (M,N), A (M,K) row-major -> out (N,K); rows split over the grid, fp32 MFMA, fixed-order reduction of the

@@ -33,7 +33,10 @@ def test_group_concat_fwd_bwd(B, N, npnt, ns, C, normalize):
     ref = gp if not C else torch.cat([gp, xr.gather(2, idx.view(B, 1, -1).repeat(1, C, 1)).view(B, C, npnt, ns)], 1)
     xf = x.clone().requires_grad_(True) if C else None
     rows = fused.group_concat(pos, new_pos, None if not C else xf.transpose(1, 2), idx, r, normalize)
-    got = rows.view(B, npnt, ns, C + 3).permute(0, 3, 1, 2)
+    ld = (C + 3 + 3) // 4 * 4
+    assert rows.shape == (B * npnt * ns, ld)
+    assert ld == C + 3 or bool((rows[:, C + 3:] == 0).all())  # zero padding columns
+    got = rows.view(B, npnt, ns, ld)[..., : C + 3].permute(0, 3, 1, 2)
     if normalize:
         # the kernel performs the IEEE division the reference's CPU path performs; torch's GPU kernel multiplies
         # by a reciprocal for a scalar divisor, so this comparison is within one ulp rather than bitwise
@@ -120,7 +123,9 @@ def test_interp_concat_fwd_bwd(B, m, n, C1, C2, hip):
     ff = feat.clone().requires_grad_(True)
     sf = skip.clone().requires_grad_(True) if C2 else None
     rows = fused.interp_concat(ff.transpose(1, 2), idx, w, None if not C2 else sf.transpose(1, 2))
-    got = rows.view(B, n, C1 + C2).transpose(1, 2)
+    ld = (C1 + C2 + 3) // 4 * 4
+    assert rows.shape == (B * n, ld)
+    got = rows.view(B, n, ld)[..., : C1 + C2].transpose(1, 2)
     assert torch.equal(got, ref.detach())
     cot = torch.randn(B, C1 + C2, n, generator=g).to(DEV)
     ref.backward(cot)

@@ -1,0 +1,68 @@
+"""Kernel micro-benchmarks (device time via HIP events on the launch stream). Usage:
+   python tools/microbench.py gemm_tn|fps|ball|rows|all [reps]"""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from torch_points3d_amd import _lib, fused, torchpoints as tp  # noqa: E402
+
+DEV = "cuda:0"
+
+
+def timeit(fn, reps=20, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(reps):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / reps
+
+
+def bench_gemm_tn(reps):
+    for M, N, K in [(524288, 128, 128), (524288, 128, 131), (262144, 128, 131), (262144, 256, 128), (1048576, 128, 64),
+                    (1048576, 64, 6), (1048576, 64, 64), (524288, 10, 128), (262144, 128, 128), (4096, 1024, 512),
+                    (4096, 512, 256), (4096, 256, 259), (16384, 256, 1280)]:
+        dY = torch.randn(M, N, device=DEV)
+        A = torch.randn(M, K, device=DEV)
+        t = timeit(lambda: fused.gemm_tn(dY, A), reps)
+        t2 = timeit(lambda: torch.mm(dY.t(), A), max(2, reps // 4))
+        fl = 2.0 * M * N * K
+        by = 4.0 * M * (N + K)
+        print("gemm_tn M=%8d N=%4d K=%4d  %8.1f us  %6.1f TF/s  %6.2f TB/s   (torch.mm %8.1f us)" % (
+            M, N, K, t * 1e3, fl / t / 1e9, by / t / 1e9, t2 * 1e3))
+
+
+def bench_fps(reps):
+    for B, N, n in [(32, 16384, 512), (32, 512, 128), (32, 2048, 512), (32, 4096, 1024), (8, 16384, 2048)]:
+        pos = torch.rand(B, N, 3, device=DEV) * 2 - 1
+        t = timeit(lambda: tp.furthest_point_sample(pos, n), reps)
+        print("fps B=%d N=%d npoint=%d  %8.1f us  (%.2f us/step)" % (B, N, n, t * 1e3, t * 1e3 / n))
+
+
+def bench_ball(reps):
+    for B, N, n, r, ns in [(32, 16384, 512, 0.2, 64), (32, 512, 128, 0.4, 64), (32, 2048, 512, 0.1, 32), (32, 16384, 2048, 0.2, 64)]:
+        pos = torch.rand(B, N, 3, device=DEV) * 2 - 1
+        q = pos[:, :n].contiguous()
+        t = timeit(lambda: tp.ball_query(r, ns, pos, q), reps)
+        by = B * (N * 12 + n * 12 + n * ns * 12)
+        print("ball_query B=%d N=%d np=%d r=%.2f ns=%d  %8.1f us  %7.1f GB/s algorithmic" % (B, N, n, r, ns, t * 1e3, by / t / 1e6))
+        t = timeit(lambda: tp.three_nn(pos, q), reps)
+        print("three_nn   n=%d m=%d  %8.1f us" % (N, n, t * 1e3))
+
+
+if __name__ == "__main__":
+    what = sys.argv[1] if len(sys.argv) > 1 else "all"
+    reps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+    _lib.load()
+    if what in ("gemm_tn", "all"):
+        bench_gemm_tn(reps)
+    if what in ("fps", "all"):
+        bench_fps(reps)
+    if what in ("ball", "all"):
+        bench_ball(reps)

@@ -24,19 +24,19 @@ SIGNATURES = {
     "tp3d_three_interpolate_bwd_f32": [_p, _p, _p, _i, _i, _i, _i, _p, _p, ctypes.c_size_t, _p],
     "tp3d_group_fwd_f32": [_p, _p, _i, _i, _i, _i, _i, _p, _p],
     "tp3d_group_bwd_f32": [_p, _p, _i, _i, _i, _i, _i, _p, _p, ctypes.c_size_t, _p],
-    "tp3d_group_concat_fwd_f32": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _i, _p, _p],
+    "tp3d_group_concat_fwd_f32": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _f, _i, _p, _p],
     "tp3d_rows_scatter_bwd_f32": [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p, _p, ctypes.c_size_t, _p],
     "tp3d_bn_stats_f32": [_p, _l, _i, _f, _f, _p, _p, _p, _p, _i, _p, _p, _p, _p, _p, _p],
     "tp3d_bn_act_f32": [_p, _p, _p, _f, _l, _i, _p, _p],
     "tp3d_bn_act_maxpool_f32": [_p, _p, _p, _f, _l, _i, _i, _p, _p, _p],
     "tp3d_bn_act_bwd_f32": [_p, _p, _p, _p, _p, _p, _p, _f, _l, _i, _i, _i, _p, _p, _p, _p, _p],
-    "tp3d_interp_concat_fwd_f32": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _p],
+    "tp3d_interp_concat_fwd_f32": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _p],
     "tp3d_idw_weights_f32": [_p, _l, _p, _p],
     "tp3d_gemm_tn_f32": [_p, _p, _l, _i, _i, _p, _p, _p],
 }
 MISC = ("tp3d_abi_version", "tp3d_strerror", "tp3d_last_hip_error", "tp3d_scatter_workspace_bytes",
         "tp3d_bn_workspace_floats", "tp3d_gemm_tn_workspace_floats")
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 _handle = None
 

@@ -108,13 +108,26 @@ __global__ __launch_bounds__(TN_BLOCK) void gemm_tn_partial_kernel(const float *
             }
 }
 
-__global__ void gemm_tn_reduce_kernel(const float *__restrict__ partial, int S, int64_t NK, float *__restrict__ out)
+// out[e] = sum_s partial[s][e]: 64 outputs x 16 split lanes per workgroup; every lane adds its splits in
+// ascending order and the 16 lane sums are combined in lane order, so the result does not depend on timing.
+constexpr int RD_E = 64, RD_S = 16;
+__global__ __launch_bounds__(RD_E *RD_S) void gemm_tn_reduce_kernel(const float *__restrict__ partial, int S,
+                                                                     int64_t NK, float *__restrict__ out)
 {
-    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= NK) return;
+    __shared__ float sm[RD_S][RD_E];
+    const int tx = threadIdx.x % RD_E, ty = threadIdx.x / RD_E;
+    const int64_t e = (int64_t)blockIdx.x * RD_E + tx;
     float acc = 0.0f;
-    for (int s = 0; s < S; ++s) acc += partial[(size_t)s * NK + e];  // fixed order
-    out[e] = acc;
+    if (e < NK)
+        for (int s = ty; s < S; s += RD_S) acc += partial[(size_t)s * NK + e];
+    sm[ty][tx] = acc;
+    __syncthreads();
+    if (ty == 0 && e < NK) {
+        float t = 0.0f;
+#pragma unroll
+        for (int k = 0; k < RD_S; ++k) t += sm[k][tx];
+        out[e] = t;
+    }
 }
 
 struct TnPlan {
@@ -132,12 +145,13 @@ static TnPlan plan_tn(int64_t M, int N, int K)
     p.tiles_n = (N + p.tn - 1) / p.tn;
     p.tiles_k = (K + p.tk - 1) / p.tk;
     const int tiles = p.tiles_n * p.tiles_k;
-    // ~8 workgroups per CU in flight (256 CUs), at least 256 rows per split, at most 1024 splits
-    int64_t want = (2048 + tiles - 1) / tiles;
+    // ~4 workgroups per CU (256 CUs) keep the MFMA pipes fed; at least 256 rows per split, at most 512 splits
+    // (every split writes an N x K partial tile that the reduction pass reads back)
+    int64_t want = (1024 + tiles - 1) / tiles;
     int64_t max_by_rows = (M + 255) / 256;
     int64_t s = want < max_by_rows ? want : max_by_rows;
     if (s < 1) s = 1;
-    if (s > 1024) s = 1024;
+    if (s > 512) s = 512;
     p.rows_per_split = ((M + s - 1) / s + TN_BR - 1) / TN_BR * TN_BR;
     p.splits = (int)((M + p.rows_per_split - 1) / p.rows_per_split);
     return p;
@@ -178,7 +192,7 @@ TP3D_EXPORT int tp3d_gemm_tn_f32(const float *dY, const float *A, int64_t M, int
                            p.tiles_k, workspace);
     if (int rc = check_launch()) return rc;
     const int64_t NK = (int64_t)N * K;
-    hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3((unsigned)((NK + 255) / 256)), dim3(256), 0, s, workspace, p.splits,
-                       NK, out);
+    hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3((unsigned)((NK + RD_E - 1) / RD_E)), dim3(RD_E * RD_S), 0, s, workspace,
+                       p.splits, NK, out);
     return check_launch();
 }

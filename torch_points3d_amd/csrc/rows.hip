@@ -20,13 +20,18 @@ __global__ __launch_bounds__(RW_BLOCK) void group_concat_fwd_kernel(const float 
                                                                      const float *__restrict__ new_pos,
                                                                      const float *__restrict__ x_cl,
                                                                      const int64_t *__restrict__ idx, int N, int np,
-                                                                     int ns, int C, float radius, int normalize,
-                                                                     int64_t total, float *__restrict__ out)
+                                                                     int ns, int C, int ld, float radius,
+                                                                     int normalize, int64_t total,
+                                                                     float *__restrict__ out)
 {
-    const int Cw = C + 3;
+    const int Cw = C + 3;  // columns [Cw, ld) are zero padding (keeps rows 16-byte aligned for the GEMMs)
     for (int64_t e = (int64_t)blockIdx.x * RW_BLOCK + threadIdx.x; e < total; e += (int64_t)gridDim.x * RW_BLOCK) {
-        const int64_t row = e / Cw;
-        const int c = (int)(e - row * Cw);
+        const int64_t row = e / ld;
+        const int c = (int)(e - row * ld);
+        if (c >= Cw) {
+            out[e] = 0.0f;
+            continue;
+        }
         const int64_t bj = row / ns;          // b*np + j
         const int b = (int)(bj / np);
         const int k = min(max((int)idx[row], 0), N - 1);
@@ -443,13 +448,17 @@ __global__ __launch_bounds__(RW_BLOCK) void interp_concat_fwd_kernel(const float
                                                                       const int64_t *__restrict__ idx,
                                                                       const float *__restrict__ w,
                                                                       const float *__restrict__ skip_cl, int m, int n,
-                                                                      int C1, int C2, int64_t total,
+                                                                      int C1, int C2, int ld, int64_t total,
                                                                       float *__restrict__ out)
 {
-    const int Cw = C1 + C2;
+    const int Cw = C1 + C2;  // columns [Cw, ld) are zero padding
     for (int64_t e = (int64_t)blockIdx.x * RW_BLOCK + threadIdx.x; e < total; e += (int64_t)gridDim.x * RW_BLOCK) {
-        const int64_t row = e / Cw;  // b*n + i
-        const int c = (int)(e - row * Cw);
+        const int64_t row = e / ld;  // b*n + i
+        const int c = (int)(e - row * ld);
+        if (c >= Cw) {
+            out[e] = 0.0f;
+            continue;
+        }
         float v;
         if (c < C1) {
             const int b = (int)(row / n);
@@ -495,15 +504,15 @@ static inline unsigned grid_for(int64_t total)
 using namespace tp3d;
 
 TP3D_EXPORT int tp3d_group_concat_fwd_f32(const float *pos, const float *new_pos, const float *x_cl,
-                                          const int64_t *idx, int B, int N, int np, int ns, int C, float radius,
-                                          int normalize, float *out, void *stream)
+                                          const int64_t *idx, int B, int N, int np, int ns, int C, int ld,
+                                          float radius, int normalize, float *out, void *stream)
 {
-    if (B < 0 || N <= 0 || np < 0 || ns < 0 || C < 0) return TP3D_E_BADARG;
-    const int64_t total = (int64_t)B * np * ns * (C + 3);
+    if (B < 0 || N <= 0 || np < 0 || ns < 0 || C < 0 || ld < C + 3) return TP3D_E_BADARG;
+    const int64_t total = (int64_t)B * np * ns * ld;
     if (total == 0) return TP3D_OK;
     if (!pos || !new_pos || !idx || !out || (C > 0 && !x_cl)) return TP3D_E_BADARG;
     hipLaunchKernelGGL(group_concat_fwd_kernel, dim3(grid_for(total)), dim3(RW_BLOCK), 0, (hipStream_t)stream, pos,
-                       new_pos, x_cl, idx, N, np, ns, C, radius, normalize, total, out);
+                       new_pos, x_cl, idx, N, np, ns, C, ld, radius, normalize, total, out);
     return check_launch();
 }
 
@@ -631,15 +640,15 @@ TP3D_EXPORT int tp3d_bn_act_bwd_f32(const float *dA, const int *argmax, const fl
 }
 
 TP3D_EXPORT int tp3d_interp_concat_fwd_f32(const float *feat_cl, const int64_t *idx, const float *weight,
-                                           const float *skip_cl, int B, int m, int n, int C1, int C2, float *out,
-                                           void *stream)
+                                           const float *skip_cl, int B, int m, int n, int C1, int C2, int ld,
+                                           float *out, void *stream)
 {
-    if (B < 0 || m <= 0 || n < 0 || C1 < 0 || C2 < 0) return TP3D_E_BADARG;
-    const int64_t total = (int64_t)B * n * (C1 + C2);
+    if (B < 0 || m <= 0 || n < 0 || C1 < 0 || C2 < 0 || ld < C1 + C2) return TP3D_E_BADARG;
+    const int64_t total = (int64_t)B * n * ld;
     if (total == 0) return TP3D_OK;
     if (!out || (C1 > 0 && (!feat_cl || !idx || !weight)) || (C2 > 0 && !skip_cl)) return TP3D_E_BADARG;
     hipLaunchKernelGGL(interp_concat_fwd_kernel, dim3(grid_for(total)), dim3(RW_BLOCK), 0, (hipStream_t)stream,
-                       feat_cl, idx, weight, skip_cl, m, n, C1, C2, total, out);
+                       feat_cl, idx, weight, skip_cl, m, n, C1, C2, ld, total, out);
     return check_launch();
 }
 

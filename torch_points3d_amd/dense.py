@@ -285,8 +285,7 @@ class DenseFPModule(BaseDenseConvolutionUp):
         skip_cl = None if x_skip is None else _fused._cl(x_skip)
         if pos is None:  # below the global module: one feature column broadcast to every skip point
             rows = x.transpose(1, 2).expand(B, n, x.shape[1])
-            rows = torch.cat([rows, skip_cl], 2) if skip_cl is not None else rows.contiguous()
-            rows = rows.reshape(B * n, -1)
+            rows = _fused.cat_rows([rows] + ([skip_cl] if skip_cl is not None else []))
         else:
             dist, idx = self._tp.three_nn(pos_skip, pos)
             rows = _fused.interp_concat(_fused._cl(x), idx, _fused.idw_weights(dist), skip_cl)
@@ -319,7 +318,7 @@ class GlobalDenseBaseModule(nn.Module):
             parts = _fused.mlp_parts(self.nn)
             if parts is not None:
                 B, n = data.pos.shape[0], data.pos.shape[1]
-                rows = torch.cat([_fused._cl(data.x), data.pos], 2).reshape(B * n, -1)  # channel order [x, pos]
+                rows = _fused.cat_rows([_fused._cl(data.x), data.pos])  # channel order [x, pos]
                 pooled = _fused.run_mlp(rows, parts, pool_ns=n)  # max over all points of a cloud
                 return Data(x=pooled.view(B, -1, 1), pos=None)
         x = self.nn(torch.cat([data.x, data.pos.transpose(1, 2).contiguous()], dim=1).unsqueeze(-1)).squeeze(-1)

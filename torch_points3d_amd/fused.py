@@ -19,6 +19,10 @@ def _cl(x):
     return x.transpose(1, 2).contiguous()
 
 
+def _pad4(c):
+    return (c + 3) & ~3
+
+
 def _slope_of(act):
     if act is None:
         return 1.0
@@ -80,9 +84,12 @@ class _LinearBNAct(torch.autograd.Function):
     def forward(ctx, A, weight, gamma, beta, bn, slope, pool_ns):
         dev = A.device
         A = A.contiguous()
-        M, Cin = A.shape
+        M, Kp = A.shape  # Kp >= Cin: producers pad rows with zero columns to a multiple of 4 floats
         Cout = weight.shape[0]
-        W2 = weight.reshape(Cout, Cin)
+        W2 = weight.reshape(Cout, -1)
+        Cin = W2.shape[1]
+        if Kp != Cin:
+            W2 = torch.nn.functional.pad(W2, (0, Kp - Cin))
         Y = torch.mm(A, W2.t())  # the dense contraction: a plain library GEMM
         training = bn.training
         stats = torch.empty((4, Cout), dtype=torch.float32, device=dev)  # mean, invstd, scale, shift
@@ -107,13 +114,13 @@ class _LinearBNAct(torch.autograd.Function):
         if training:
             bn.num_batches_tracked.add_(1)
         ctx.save_for_backward(A, W2, Y, stats, arg)
-        ctx.cfg = (slope, pool_ns, training, tuple(weight.shape))
+        ctx.cfg = (slope, pool_ns, training, tuple(weight.shape), Cin)
         return out
 
     @staticmethod
     def backward(ctx, grad_out):
         A, W2, Y, stats, arg = ctx.saved_tensors
-        slope, pool_ns, training, wshape = ctx.cfg
+        slope, pool_ns, training, wshape, Cin = ctx.cfg
         dev = grad_out.device
         grad_out = grad_out.contiguous()
         M, Cout = Y.shape
@@ -125,7 +132,7 @@ class _LinearBNAct(torch.autograd.Function):
                       _lib.ptr(stats[3]), _lib.ptr(stats[0]), _lib.ptr(stats[1]), slope, M, max(pool_ns, 1), Cout,
                       int(training), _lib.ptr(dgb[0]), _lib.ptr(dgb[1]), _lib.ptr(dY), _lib.ptr(ws),
                       _lib.stream_ptr(dev))
-        dW = gemm_tn(dY, A).reshape(wshape) if ctx.needs_input_grad[1] else None
+        dW = gemm_tn(dY, A)[:, :Cin].reshape(wshape) if ctx.needs_input_grad[1] else None
         dA = torch.mm(dY, W2) if ctx.needs_input_grad[0] else None
         return dA, dW, dgb[1], dgb[0], None, None, None
 
@@ -142,7 +149,7 @@ def run_mlp(rows, parts, pool_ns=0):
 
 
 class _GroupConcat(torch.autograd.Function):
-    """rows[(b,j,s)] = [pos[b,idx]-new_pos[b,j] (/r), x_cl[b,idx]]; differentiable wrt x_cl."""
+    """rows[(b,j,s)] = [pos[b,idx]-new_pos[b,j] (/r), x_cl[b,idx], 0-pad to 4k columns]; differentiable wrt x_cl."""
 
     @staticmethod
     def forward(ctx, pos, new_pos, x_cl, idx, radius, normalize):
@@ -152,18 +159,19 @@ class _GroupConcat(torch.autograd.Function):
         C = 0 if x_cl is None else x_cl.shape[2]
         pos, new_pos, idx = pos.contiguous(), new_pos.contiguous(), idx.contiguous()
         xc = None if x_cl is None else x_cl.contiguous()
-        out = torch.empty((B * npnt * ns, C + 3), dtype=torch.float32, device=dev)
+        ld = _pad4(C + 3)
+        out = torch.empty((B * npnt * ns, ld), dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
             _lib.call("tp3d_group_concat_fwd_f32", _lib.ptr(pos), _lib.ptr(new_pos), _lib.ptr(xc), _lib.ptr(idx), B, N,
-                      npnt, ns, C, float(radius), int(bool(normalize)), _lib.ptr(out), _lib.stream_ptr(dev))
+                      npnt, ns, C, ld, float(radius), int(bool(normalize)), _lib.ptr(out), _lib.stream_ptr(dev))
         ctx.save_for_backward(idx)
-        ctx.dims = (B, N, npnt, ns, C)
+        ctx.dims = (B, N, npnt, ns, C, ld)
         return out
 
     @staticmethod
     def backward(ctx, grad_rows):
         (idx,) = ctx.saved_tensors
-        B, N, npnt, ns, C = ctx.dims
+        B, N, npnt, ns, C, ld = ctx.dims
         if C == 0 or not ctx.needs_input_grad[2]:
             return None, None, None, None, None, None
         dev = grad_rows.device
@@ -172,7 +180,7 @@ class _GroupConcat(torch.autograd.Function):
         L = npnt * ns
         ws, ws_bytes = _lib.scatter_workspace(B, L, N, False, dev)
         with torch.cuda.device(dev):
-            _lib.call("tp3d_rows_scatter_bwd_f32", _lib.ptr(grad_rows), _lib.ptr(idx), None, B, L, 1, N, C + 3, 3, C,
+            _lib.call("tp3d_rows_scatter_bwd_f32", _lib.ptr(grad_rows), _lib.ptr(idx), None, B, L, 1, N, ld, 3, C,
                       _lib.ptr(g), _lib.ptr(ws), ws_bytes, _lib.stream_ptr(dev))
         return None, None, g, None, None, None
 
@@ -192,18 +200,19 @@ class _InterpConcat(torch.autograd.Function):
         C2 = 0 if skip_cl is None else skip_cl.shape[2]
         feat_cl, idx, weight = feat_cl.contiguous(), idx.contiguous(), weight.contiguous()
         sk = None if skip_cl is None else skip_cl.contiguous()
-        out = torch.empty((B * n, C1 + C2), dtype=torch.float32, device=dev)
+        ld = _pad4(C1 + C2)
+        out = torch.empty((B * n, ld), dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
             _lib.call("tp3d_interp_concat_fwd_f32", _lib.ptr(feat_cl), _lib.ptr(idx), _lib.ptr(weight), _lib.ptr(sk), B,
-                      m, n, C1, C2, _lib.ptr(out), _lib.stream_ptr(dev))
+                      m, n, C1, C2, ld, _lib.ptr(out), _lib.stream_ptr(dev))
         ctx.save_for_backward(idx, weight)
-        ctx.dims = (B, m, n, C1, C2)
+        ctx.dims = (B, m, n, C1, C2, ld)
         return out
 
     @staticmethod
     def backward(ctx, grad_rows):
         idx, weight = ctx.saved_tensors
-        B, m, n, C1, C2 = ctx.dims
+        B, m, n, C1, C2, ld = ctx.dims
         dev = grad_rows.device
         grad_rows = grad_rows.contiguous()
         g_feat = None
@@ -212,15 +221,24 @@ class _InterpConcat(torch.autograd.Function):
             ws, ws_bytes = _lib.scatter_workspace(B, 3 * n, m, True, dev)
             with torch.cuda.device(dev):
                 _lib.call("tp3d_rows_scatter_bwd_f32", _lib.ptr(grad_rows), _lib.ptr(idx), _lib.ptr(weight), B, 3 * n,
-                          3, m, C1 + C2, 0, C1, _lib.ptr(g_feat), _lib.ptr(ws), ws_bytes, _lib.stream_ptr(dev))
+                          3, m, ld, 0, C1, _lib.ptr(g_feat), _lib.ptr(ws), ws_bytes, _lib.stream_ptr(dev))
         g_skip = None
         if C2 and ctx.needs_input_grad[3]:
-            g_skip = grad_rows.view(B, n, C1 + C2)[:, :, C1:]
+            g_skip = grad_rows.view(B, n, ld)[:, :, C1:C1 + C2]
         return g_feat, None, None, g_skip
 
 
 def interp_concat(feat_cl, idx, weight, skip_cl):
     return _InterpConcat.apply(feat_cl, idx, weight, skip_cl)
+
+
+def cat_rows(parts):
+    """cat of (B, n, C_i) tensors on the channel axis -> (B*n, pad4(sum C_i)) rows with zero padding columns."""
+    B, n = parts[0].shape[0], parts[0].shape[1]
+    width = sum(p.shape[2] for p in parts)
+    if _pad4(width) != width:
+        parts = list(parts) + [parts[0].new_zeros((B, n, _pad4(width) - width))]
+    return torch.cat(parts, 2).reshape(B * n, -1)
 
 
 def idw_weights(dist):
