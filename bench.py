@@ -29,6 +29,7 @@ N_POINTS = 16384
 FEAT = 3
 NUM_CLASSES = 10
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
+MFMA_F32_PEAK_TFLOPS = 157.3  # dense fp32-input MFMA peak (MI355X_MICROARCH.md, "Peak FP32 (matrix)")
 
 
 class SegStep(nn.Module):
@@ -88,6 +89,40 @@ def algorithmic_bytes(name, a):
     if name in ("tp3d_group_fwd_f32", "tp3d_group_bwd_f32"):  # B, C, N, np, ns
         B, C, N, npnt, ns = a[:5]
         return B * (C * N * 4 + npnt * ns * 8 + C * npnt * ns * 4)
+    # ---- channel-last grouped-MLP kernels ("algorithmic bytes")
+    if name == "tp3d_group_concat_fwd_f32":  # B, N, np, ns, C, ld
+        B, N, npnt, ns, C, ld = a[:6]
+        return B * (N * 12 + npnt * 12 + N * C * 4 + npnt * ns * 8 + npnt * ns * ld * 4)
+    if name == "tp3d_rows_scatter_bwd_f32":  # B, L, div, nbins, ld, col0, C
+        B, L, div, nbins, ld, col0, C = a[:7]
+        return B * (L * 8 + (L // div) * C * 4 + nbins * C * 4)
+    if name == "tp3d_bn_stats_f32":  # M, C, training
+        M, C = a[:2]
+        return M * C * 4
+    if name == "tp3d_bn_act_f32":  # M, C
+        M, C = a[:2]
+        return 2 * M * C * 4
+    if name == "tp3d_bn_act_maxpool_f32":  # G, ns, C
+        G, ns, C = a[:3]
+        return G * ns * C * 4 + G * C * 8
+    if name == "tp3d_bn_act_bwd_f32":  # M, ns, C, training  (dA + Y read twice, dY written)
+        M, ns, C = a[:3]
+        return 3 * M * C * 4 + (M // ns) * C * 8
+    if name == "tp3d_interp_concat_fwd_f32":  # B, m, n, C1, C2, ld
+        B, m, n, C1, C2, ld = a[:6]
+        return B * (m * C1 * 4 + n * 36 + n * C2 * 4 + n * ld * 4)
+    if name == "tp3d_idw_weights_f32":  # rows
+        return a[0] * 24
+    if name == "tp3d_gemm_tn_f32":  # M, N, K
+        M, N, K = a[:3]
+        return (M * (N + K) + N * K) * 4
+    return 0
+
+
+def algorithmic_flops(name, a):
+    if name == "tp3d_gemm_tn_f32":  # M, N, K
+        M, N, K = a[:3]
+        return 2 * M * N * K
     return 0
 
 
@@ -224,21 +259,45 @@ def main():
                 "ms_per_step": round(total_ms / args.steps, 4), "algorithmic_MB": round(nbytes / 1e6, 3),
                 "GBps": round(nbytes / 1e9 / (avg_ms / 1e3), 2) if avg_ms > 0 else None,
             })
-        # dominant HIP kernel = the (entry point, shape) with the largest share of device time
+        # dominant HIP kernel = the entry point with the largest share of device time over the timed region
+        # (all its launch shapes together, which is also how the rocprofv3 --stats summary groups them)
+        per_entry = {}
+        for (name, a), (launches, total_ms) in summ.items():
+            e = per_entry.setdefault(name, {"ms": 0.0, "launches": 0, "bytes": 0, "flops": 0})
+            e["ms"] += total_ms
+            e["launches"] += launches
+            e["bytes"] += launches * algorithmic_bytes(name, a)
+            e["flops"] += launches * algorithmic_flops(name, a)
         roofline = None
-        if kernels:
-            k = kernels[0]
+        if per_entry:
+            dom = max(per_entry, key=lambda n: per_entry[n]["ms"])
+            e = per_entry[dom]
+            avg_ms = e["ms"] / e["launches"]
             traffic = None
             tpath = os.path.join(ROOT, "profiles", "traffic.json")
             if os.path.exists(tpath):
                 try:
-                    traffic = json.load(open(tpath)).get("%s%s" % (k["entry"], k["sizes"]))
+                    traffic = json.load(open(tpath)).get(dom)
                 except (OSError, ValueError):
                     traffic = None
-            roofline = {"kernel": k["entry"], "sizes": k["sizes"], "bound": "hbm", "achieved": k["GBps"],
-                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(k["GBps"] / HBM_PEAK_GBS, 6),
-                        "traffic": traffic, "avg_launch_ms": k["avg_ms"], "launches": k["launches"],
-                        "algorithmic_bytes_per_launch": int(k["algorithmic_MB"] * 1e6)}
+            if e["flops"]:  # a dense contraction: priced against the fp32 MFMA peak
+                achieved = e["flops"] / 1e12 / (e["ms"] / 1e3)
+                roofline = {"kernel": dom, "bound": "mfma", "achieved": round(achieved, 2),
+                            "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                            "frac": round(achieved / MFMA_F32_PEAK_TFLOPS, 4), "traffic": traffic,
+                            "algorithmic_flops_per_launch": int(e["flops"] / e["launches"])}
+            else:
+                achieved = e["bytes"] / 1e9 / (e["ms"] / 1e3)
+                roofline = {"kernel": dom, "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+                            "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                            "algorithmic_bytes_per_launch": int(e["bytes"] / e["launches"])}
+            roofline.update({"avg_launch_ms": round(avg_ms, 4), "launches": e["launches"],
+                             "ms_per_step": round(e["ms"] / args.steps, 4)})
+        entries = [{"entry": n, "ms_per_step": round(v["ms"] / args.steps, 4), "launches_per_step":
+                    v["launches"] // args.steps,
+                    "GBps": round(v["bytes"] / 1e9 / (v["ms"] / 1e3), 1) if v["ms"] > 0 else None,
+                    "TFLOPs": round(v["flops"] / 1e12 / (v["ms"] / 1e3), 2) if v["flops"] else None}
+                   for n, v in sorted(per_entry.items(), key=lambda kv: -kv[1]["ms"])]
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline(args.cpu_sample_clouds, args.cpu_sample_iters)
@@ -262,6 +321,7 @@ def main():
                        "parallelism": "dp%d (batch shards, DDP gradient all-reduce over RCCL)" % world},
             "roofline": roofline,
             "cpu_baseline": cpu,
+            "entry_points": entries,
             "kernels": kernels,
         }
         if cpu:

@@ -1,0 +1,76 @@
+"""N > 1 path on CPU: world_size 2, gloo.  The batch is sharded by cloud (no data-path collective); the only
+exchange is DDP's gradient all-reduce.  Kernels are the CPU oracle here (the HIP path needs a GPU), the
+sharding / all-reduce logic is the product's (bench.py uses the same wrapper and DDP settings)."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+CFG = dict(npoint=[48, 12], radii=[[0.45], [0.9]], nsample=[[8], [8]],
+           down_conv_nn=[[[3 + 3, 8, 8, 12]], [[12 + 3, 12, 12, 16]]], innermost=[16 + 3, 16, 24],
+           up_conv_nn=[[24 + 16, 16, 16], [16 + 12, 16, 12], [12 + 3, 12, 12, 12]],
+           normalize_xyz=[False, False], save_sampling_id=[False, False])
+
+
+def _make(seed=0):
+    sys.path.insert(0, ROOT)
+    import bench
+    from oracle import tpk_ref
+    from torch_points3d_amd.pointnet2 import PointNet2Unet
+    torch.manual_seed(seed)
+    net = PointNet2Unet(3, output_nc=5, config=CFG, kernels=tpk_ref)
+    return bench.SegStep(net).train()
+
+
+def _inputs():
+    g = torch.Generator().manual_seed(42)
+    pos = torch.rand(4, 200, 3, generator=g) * 2 - 1
+    x = torch.randn(4, 200, 3, generator=g)
+    y = torch.randint(0, 5, (4, 200), generator=g)
+    return pos, x, y
+
+
+def _worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    model = torch.nn.parallel.DistributedDataParallel(_make(), bucket_cap_mb=16, gradient_as_bucket_view=True)
+    pos, x, y = _inputs()
+    sl = slice(rank * 2, rank * 2 + 2)  # each rank owns whole clouds
+    loss = torch.nn.functional.cross_entropy(model(pos[sl], x[sl]), y[sl])
+    loss.backward()
+    grads = torch.cat([p.grad.reshape(-1) for p in model.parameters()])
+    gathered = [torch.zeros_like(grads) for _ in range(world)]
+    dist.all_gather(gathered, grads)
+    if rank == 0:
+        torch.save({"grads": grads, "same": bool(torch.equal(gathered[0], gathered[1]))}, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_ddp_two_ranks_average_shard_gradients(tmp_path):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = str(tmp_path / "r0.pt")
+    mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
+    res = torch.load(out, weights_only=True)
+    assert res["same"], "ranks hold different gradients after the all-reduce"
+    # expectation: mean over ranks of the gradient each shard produces on its own (BatchNorm stays per rank)
+    pos, x, y = _inputs()
+    torch.set_num_threads(1)
+    local = []
+    for r in range(2):
+        m = _make()
+        sl = slice(r * 2, r * 2 + 2)
+        torch.nn.functional.cross_entropy(m(pos[sl], x[sl]), y[sl]).backward()
+        local.append(torch.cat([p.grad.reshape(-1) for p in m.parameters()]))
+    want = (local[0] + local[1]) / 2
+    torch.testing.assert_close(res["grads"], want, rtol=1e-5, atol=1e-6)

@@ -15,7 +15,7 @@ namespace tp3d {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int TN_BLOCK = 256;  // 4 waves as 2 x 2
-constexpr int TN_BR = 16;      // rows staged per step
+constexpr int TN_BR_MAX = 64;  // most rows staged per step (narrow tiles stage more rows per barrier)
 
 // Each wave owns WM x WN MFMA tiles of 32x32; the workgroup tile is (2*WM*32) x (2*WN*32).
 template <int WM, int WN>
@@ -25,6 +25,7 @@ __global__ __launch_bounds__(TN_BLOCK) void gemm_tn_partial_kernel(const float *
                                                                     float *__restrict__ partial /*[S][N][K]*/)
 {
     constexpr int TN = 2 * WM * 32, TK = 2 * WN * 32;
+    constexpr int TN_BR = 64 / (WM * WN);  // ~16-32 KiB staged per step whatever the tile shape
     constexpr int LDN = TN + 4, LDK = TK + 4;  // +4 floats: keeps float4 stores aligned, spreads rows over banks
     __shared__ __attribute__((aligned(16))) float sY[TN_BR * LDN];
     __shared__ __attribute__((aligned(16))) float sA[TN_BR * LDK];
@@ -152,7 +153,7 @@ static TnPlan plan_tn(int64_t M, int N, int K)
     int64_t s = want < max_by_rows ? want : max_by_rows;
     if (s < 1) s = 1;
     if (s > 512) s = 512;
-    p.rows_per_split = ((M + s - 1) / s + TN_BR - 1) / TN_BR * TN_BR;
+    p.rows_per_split = ((M + s - 1) / s + TN_BR_MAX - 1) / TN_BR_MAX * TN_BR_MAX;
     p.splits = (int)((M + p.rows_per_split - 1) / p.rows_per_split);
     return p;
 }

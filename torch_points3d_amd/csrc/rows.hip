@@ -46,6 +46,11 @@ __global__ __launch_bounds__(RW_BLOCK) void group_concat_fwd_kernel(const float 
     }
 }
 
+__device__ __forceinline__ float rl_f(float x, int lane)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), lane));
+}
+
 // grad_x_cl[b,k,:] = sum over slots l (ascending) with idx[b,l]==k of grad_rows[(b,l), col0 + :]   (CSR gather)
 // one wave per destination point, lanes over channels: every read is a contiguous row segment.
 __global__ __launch_bounds__(RW_BLOCK) void rows_gather_sum_kernel(const float *__restrict__ grad_rows,
@@ -65,15 +70,36 @@ __global__ __launch_bounds__(RW_BLOCK) void rows_gather_sum_kernel(const float *
     const int lo = st[dest], hi = st[dest + 1];
     const float *base = grad_rows + (size_t)b * rows_per_cloud * ld + col0;
     for (int c0 = 0; c0 < C; c0 += 64) {
-        const int c = c0 + lane;
+        const int c = min(c0 + lane, C - 1);
         float acc = 0.0f;
-        if (c < C) {
-            for (int j = lo; j < hi; ++j) {
-                const float v = base[(size_t)od[j] * ld + c];
-                acc = acc + (ws ? ws[j] * v : v);
+        // the run's (row, weight) pairs are fetched 64 at a time with one coalesced load, then broadcast lane by
+        // lane (v_readlane), so four independent row reads are in flight instead of a dependent index->row chain
+        for (int j0 = lo; j0 < hi; j0 += 64) {
+            const int cnt = min(64, hi - j0);
+            const int my_r = (lane < cnt) ? od[j0 + lane] : 0;
+            const float my_w = (ws && lane < cnt) ? ws[j0 + lane] : 1.0f;
+            int t = 0;
+            for (; t + 4 <= cnt; t += 4) {
+                const int r0 = __builtin_amdgcn_readlane(my_r, t), r1 = __builtin_amdgcn_readlane(my_r, t + 1);
+                const int r2 = __builtin_amdgcn_readlane(my_r, t + 2), r3 = __builtin_amdgcn_readlane(my_r, t + 3);
+                const float v0 = base[(size_t)r0 * ld + c], v1 = base[(size_t)r1 * ld + c];
+                const float v2 = base[(size_t)r2 * ld + c], v3 = base[(size_t)r3 * ld + c];
+                if (ws) {
+                    acc = acc + rl_f(my_w, t) * v0;
+                    acc = acc + rl_f(my_w, t + 1) * v1;
+                    acc = acc + rl_f(my_w, t + 2) * v2;
+                    acc = acc + rl_f(my_w, t + 3) * v3;
+                } else {
+                    acc = ((acc + v0) + v1) + v2;
+                    acc = acc + v3;
+                }
             }
-            out[((size_t)b * nbins + dest) * C + c] = acc;
+            for (; t < cnt; ++t) {
+                const float v = base[(size_t)__builtin_amdgcn_readlane(my_r, t) * ld + c];
+                acc = acc + (ws ? rl_f(my_w, t) * v : v);
+            }
         }
+        if (c0 + lane < C) out[((size_t)b * nbins + dest) * C + c0 + lane] = acc;
     }
 }
 
