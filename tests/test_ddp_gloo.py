@@ -65,12 +65,16 @@ def test_ddp_two_ranks_average_shard_gradients(tmp_path):
     assert res["same"], "ranks hold different gradients after the all-reduce"
     # expectation: mean over ranks of the gradient each shard produces on its own (BatchNorm stays per rank)
     pos, x, y = _inputs()
-    torch.set_num_threads(1)
+    nthreads = torch.get_num_threads()
+    torch.set_num_threads(1)  # same summation order as the workers
     local = []
-    for r in range(2):
-        m = _make()
-        sl = slice(r * 2, r * 2 + 2)
-        torch.nn.functional.cross_entropy(m(pos[sl], x[sl]), y[sl]).backward()
-        local.append(torch.cat([p.grad.reshape(-1) for p in m.parameters()]))
+    try:
+        for r in range(2):
+            m = _make()
+            sl = slice(r * 2, r * 2 + 2)
+            torch.nn.functional.cross_entropy(m(pos[sl], x[sl]), y[sl]).backward()
+            local.append(torch.cat([p.grad.reshape(-1) for p in m.parameters()]))
+    finally:
+        torch.set_num_threads(nthreads)
     want = (local[0] + local[1]) / 2
     torch.testing.assert_close(res["grads"], want, rtol=1e-5, atol=1e-6)
