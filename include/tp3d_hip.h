@@ -35,7 +35,7 @@ extern "C" {
 #define TP3D_E_UNSORTED (-3) /* reserved: batch vector not sorted (checked by the host wrapper) */
 #define TP3D_E_TOOBIG (-4)   /* size exceeds what the kernel's index arithmetic supports */
 
-#define TP3D_ABI_VERSION 5
+#define TP3D_ABI_VERSION 6
 
 int tp3d_abi_version(void);
 const char *tp3d_strerror(int code);
@@ -163,6 +163,16 @@ int tp3d_interp_concat_fwd_f32(const float *feat_cl, const int64_t *idx, const f
 size_t tp3d_gemm_tn_workspace_floats(int64_t M, int N, int K);
 int tp3d_gemm_tn_f32(const float *dY, const float *A, int64_t M, int N, int K, float *out, float *workspace,
                      void *stream);
+
+/* KPConv rigid convolution, stage 1 (reference modules/KPConv/convolution_ops.py:19-98):
+ *   weighted[q, k, :] = sum_n h(|(support[nbr[q,n]] - query[q]) - k_points[k]|) * features[nbr[q,n], :]
+ * query (Nq,3), support (M,3), neighbors (Nq,Mn) int64 with -1 (or >= M) = shadow neighbour, features (M,Cin),
+ * k_points (KP,3), KP <= 16 -> weighted (Nq, KP, Cin).  influence: 0 constant, 1 linear (max(1 - d/extent, 0)),
+ * 2 gaussian (sigma = 0.3*extent); closest != 0 keeps only the nearest kernel point per neighbour.
+ * Stage 2 (:101-105) is one GEMM  (Nq, KP*Cin) x (KP*Cin, Cout)  issued by the host wrapper. */
+int tp3d_kpconv_weighted_f32(const float *query, const float *support, const int64_t *neighbors,
+                             const float *features, const float *k_points, int64_t Nq, int64_t M, int Mn, int Cin,
+                             int KP, float extent, int influence, int closest, float *weighted, void *stream);
 
 /* inverse-distance weights of DenseFPModule (core/base_conv/dense.py:137-139): dist (rows,3) -> weight (rows,3) */
 int tp3d_idw_weights_f32(const float *dist, int64_t rows, float *weight, void *stream);

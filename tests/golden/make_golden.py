@@ -188,8 +188,46 @@ def make_case(name, cfg, feat, output_nc, pos, x, seed, store_weights, activatio
     print("wrote %s (%.1f KiB)" % (path, os.path.getsize(path) / 1024.0))
 
 
+def make_kpconv_case():
+    """KPConv_ops of the reference (modules/KPConv/convolution_ops.py:19-107, loaded by file path) on a small
+    partial-dense neighbourhood table with -1 shadows, all influence / aggregation modes."""
+    import importlib.util
+
+    def by_path(name, rel):
+        spec = importlib.util.spec_from_file_location(name, os.path.join(REF, rel))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        return mod
+
+    ops = by_path("ref_kpconv_ops", "torch_points3d/modules/KPConv/convolution_ops.py")
+    ply = by_path("ref_plyutils", "torch_points3d/modules/KPConv/plyutils.py")
+    kp = ply.read_ply(os.path.join(REF, "torch_points3d/modules/KPConv/kernels/dispositions/k_015_center.ply"))
+    kp = np.vstack((kp["x"], kp["y"], kp["z"])).T.astype(np.float32)  # (15, 3) unit disposition
+    g = torch.Generator().manual_seed(2024)
+    M, Nq, Mn, Cin, Cout = 260, 200, 25, 8, 16
+    support = torch.rand(M, 3, generator=g)
+    query = support[torch.randperm(M, generator=g)[:Nq]].contiguous()
+    point_influence = 0.12
+    K_points = torch.from_numpy(kp) * (1.5 * point_influence)  # kernel radius = 1.5 * influence (kernels.py:35,51)
+    idx, _ = tpk_ref.ball_query(0.3, Mn, support, query, mode="partial_dense", batch_x=torch.zeros(M, dtype=torch.long),
+                                batch_y=torch.zeros(Nq, dtype=torch.long))
+    assert (idx == -1).any()
+    feats = torch.randn(M, Cin, generator=g)
+    W = torch.randn(15, Cin, Cout, generator=g) * 0.2
+    arrays = {"support": support, "query": query, "neighbors": idx, "features": feats, "K_points": K_points,
+              "K_values": W, "extent": torch.tensor([point_influence])}
+    for infl in ("constant", "linear", "gaussian"):
+        for aggr in ("sum", "closest"):
+            out = ops.KPConv_ops(query, support, idx.clone(), feats, K_points, W, point_influence, infl, aggr)
+            arrays["out_%s_%s" % (infl, aggr)] = out
+    path = os.path.join(HERE, "kpconv_ops.npz")
+    np.savez_compressed(path, **to_np(arrays))
+    print("wrote %s (%.1f KiB)" % (path, os.path.getsize(path) / 1024.0))
+
+
 def main():
     install_stubs()
+    make_kpconv_case()
     from torch_points3d_amd.pointnet2 import unet_config
 
     # (1) BASELINE config 1: examples/pointnet2_segmentation_forward.py:5-19 -- randn cloud duplicated to B=2,

@@ -33,10 +33,11 @@ SIGNATURES = {
     "tp3d_interp_concat_fwd_f32": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _p],
     "tp3d_idw_weights_f32": [_p, _l, _p, _p],
     "tp3d_gemm_tn_f32": [_p, _p, _l, _i, _i, _p, _p, _p],
+    "tp3d_kpconv_weighted_f32": [_p, _p, _p, _p, _p, _l, _l, _i, _i, _i, _f, _i, _i, _p, _p],
 }
 MISC = ("tp3d_abi_version", "tp3d_strerror", "tp3d_last_hip_error", "tp3d_scatter_workspace_bytes",
         "tp3d_bn_workspace_floats", "tp3d_gemm_tn_workspace_floats")
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 _handle = None
 
