@@ -35,7 +35,7 @@ extern "C" {
 #define TP3D_E_UNSORTED (-3) /* reserved: batch vector not sorted (checked by the host wrapper) */
 #define TP3D_E_TOOBIG (-4)   /* size exceeds what the kernel's index arithmetic supports */
 
-#define TP3D_ABI_VERSION 6
+#define TP3D_ABI_VERSION 7
 
 int tp3d_abi_version(void);
 const char *tp3d_strerror(int code);
@@ -57,19 +57,27 @@ int tp3d_fps_f32(const float *xyz, int B, int N, int npoint, float *scratch, int
  *   sort=0: hits (d2 < r*r, strict) in ascending index order, first nsample; remaining slots repeat the
  *           first hit (0 if none); dist2 = -1 in padded slots.
  *   sort=1: the nsample closest hits, closest first (ties by index), padded with the closest.
+ *   workspace (optional, tp3d_ball_query_workspace_bytes(B, B*N, N) bytes): with it, clouds of >= 2048 points are
+ *   searched through a uniform grid (27 cells per query) with bit-identical output; NULL = brute force.
  */
 int tp3d_ball_query_dense_f32(const float *x, const float *y, int B, int N, int np, float radius, int nsample,
-                              int sort, int64_t *idx, float *dist2, void *stream);
+                              int sort, int64_t *idx, float *dist2, void *workspace, size_t workspace_bytes,
+                              void *stream);
+size_t tp3d_ball_query_workspace_bytes(int num_clouds, int64_t rows, int max_cloud_points);
 
 /*
  * ball_query(..., mode="partial_dense", batch_x, batch_y)
  *                                               [reference call: core/spatial_ops/neighbour_finder.py:31-37]
  *   x (M,3) with ascending batch_x (M) int64, y (Nq,3) with batch_y (Nq) int64.
  *   idx (Nq,nsample) int64 = global rows of x, padded with -1; dist2 padded with -1.
+ *   Optional grid acceleration: seg_x (num_clouds+1) int64 device array of cloud row offsets into x,
+ *   max_cloud_points = the largest cloud, workspace = tp3d_ball_query_workspace_bytes(num_clouds, M,
+ *   max_cloud_points) bytes; pass NULL / 0 for the brute-force scan of each query's cloud segment.
  */
 int tp3d_ball_query_partial_dense_f32(const float *x, const float *y, const int64_t *batch_x,
                                       const int64_t *batch_y, int64_t M, int64_t Nq, float radius, int nsample,
-                                      int sort, int64_t *idx, float *dist2, void *stream);
+                                      int sort, int64_t *idx, float *dist2, const int64_t *seg_x, int num_clouds,
+                                      int max_cloud_points, void *workspace, size_t workspace_bytes, void *stream);
 
 /*
  * three_nn(unknown, known) -> (dist, idx)       [reference call: core/base_conv/dense.py:136]

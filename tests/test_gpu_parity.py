@@ -59,12 +59,13 @@ def test_fps_kat_and_errors(hip):
     (2, 1024, 512, 0.2, 64, "randn"), (2, 512, 128, 0.4, 64, "randn"), (3, 2048, 300, 0.2, 32, "uniform"),
     (2, 1000, 77, 0.1, 16, "uniform"), (2, 1500, 64, 0.45, 8, "clustered"), (2, 900, 50, 0.26, 128, "lattice"),
     (1, 3, 3, 1.01, 32, "uniform"), (2, 5000, 33, 2.5, 64, "uniform"), (1, 70, 70, 0.5, 1, "uniform"),
-    (4, 16384, 512, 0.2, 64, "uniform"),
+    (4, 16384, 512, 0.2, 64, "uniform"), (2, 2048, 100, 3.0, 16, "uniform"), (2, 4096, 256, 0.3, 48, "clustered"),
+    (2, 3000, 128, 0.26, 200, "lattice"), (1, 30000, 700, 0.05, 32, "randn"), (2, 8192, 64, 0.01, 8, "uniform"),
 ])
 @pytest.mark.parametrize("sort", [False, True])
 def test_ball_query_dense_bit_exact(hip, oracle, B, N, npnt, r, ns, kind, sort):
-    if sort and N > 4096:
-        pytest.skip("sorted path is the rare dirichlet_loss path; covered at small sizes")
+    if sort and N > 4096 and r > 1.0:
+        pytest.skip("every point in every ball, sorted: quadratic selection fallback, covered at N=2048")
     x = cloud(B, N, 20 + N, kind)
     y = x[:, torch.randperm(N, generator=torch.Generator().manual_seed(N))[:npnt]].contiguous()
     y[:, -1] = 50.0  # one query with an empty ball
@@ -100,6 +101,23 @@ def test_ball_query_partial_dense_bit_exact(hip, oracle, sort):
         ri, rd = oracle.ball_query(r, ns, x, y, mode="partial_dense", batch_x=bx, batch_y=by, sort=sort)
         assert torch.equal(gi.cpu(), ri) and torch.equal(gd.cpu(), rd)
         assert (ri == -1).any()
+
+
+@pytest.mark.parametrize("sort", [False, True])
+def test_ball_query_partial_dense_grid_bit_exact(hip, oracle, sort):
+    """clouds large enough for the uniform-grid path (>= 2048 points), ragged, with queries outside the boxes"""
+    g = torch.Generator().manual_seed(11)
+    sizes = [5000, 300, 0, 9000, 2048]
+    x = torch.cat([torch.rand(n, 3, generator=g) * (1 + i) for i, n in enumerate(sizes)])
+    bx = torch.cat([torch.full((n,), i, dtype=torch.long) for i, n in enumerate(sizes)])
+    qsizes = [700, 50, 4, 900, 333]
+    y = torch.cat([torch.rand(n, 3, generator=g) * (1 + i) * 1.2 - 0.1 for i, n in enumerate(qsizes)])
+    by = torch.cat([torch.full((n,), i, dtype=torch.long) for i, n in enumerate(qsizes)])
+    for r, ns in [(0.12, 25), (0.4, 16), (0.03, 40)]:
+        gi, gd = hip.ball_query(r, ns, x.to(DEV), y.to(DEV), mode="partial_dense", batch_x=bx.to(DEV),
+                                batch_y=by.to(DEV), sort=sort)
+        ri, rd = oracle.ball_query(r, ns, x, y, mode="partial_dense", batch_x=bx, batch_y=by, sort=sort)
+        assert torch.equal(gi.cpu(), ri) and torch.equal(gd.cpu(), rd)
 
 
 # ------------------------------------------------------------------------------------------ three_nn

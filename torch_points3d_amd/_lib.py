@@ -17,8 +17,9 @@ _f = ctypes.c_float
 # name -> argtypes; every function returns int (0 = ok). Mirrors include/tp3d_hip.h one to one.
 SIGNATURES = {
     "tp3d_fps_f32": [_p, _i, _i, _i, _p, _p, _p],
-    "tp3d_ball_query_dense_f32": [_p, _p, _i, _i, _i, _f, _i, _i, _p, _p, _p],
-    "tp3d_ball_query_partial_dense_f32": [_p, _p, _p, _p, _l, _l, _f, _i, _i, _p, _p, _p],
+    "tp3d_ball_query_dense_f32": [_p, _p, _i, _i, _i, _f, _i, _i, _p, _p, _p, ctypes.c_size_t, _p],
+    "tp3d_ball_query_partial_dense_f32": [_p, _p, _p, _p, _l, _l, _f, _i, _i, _p, _p, _p, _i, _i, _p, ctypes.c_size_t,
+                                          _p],
     "tp3d_three_nn_f32": [_p, _p, _i, _i, _i, _p, _p, _p],
     "tp3d_three_interpolate_fwd_f32": [_p, _p, _p, _i, _i, _i, _i, _p, _p],
     "tp3d_three_interpolate_bwd_f32": [_p, _p, _p, _i, _i, _i, _i, _p, _p, ctypes.c_size_t, _p],
@@ -36,8 +37,8 @@ SIGNATURES = {
     "tp3d_kpconv_weighted_f32": [_p, _p, _p, _p, _p, _l, _l, _i, _i, _i, _f, _i, _i, _p, _p],
 }
 MISC = ("tp3d_abi_version", "tp3d_strerror", "tp3d_last_hip_error", "tp3d_scatter_workspace_bytes",
-        "tp3d_bn_workspace_floats", "tp3d_gemm_tn_workspace_floats")
-ABI_VERSION = 6
+        "tp3d_bn_workspace_floats", "tp3d_gemm_tn_workspace_floats", "tp3d_ball_query_workspace_bytes")
+ABI_VERSION = 7
 
 _handle = None
 
@@ -75,6 +76,8 @@ def load():
     h.tp3d_bn_workspace_floats.argtypes = [_l, _i]
     h.tp3d_gemm_tn_workspace_floats.restype = ctypes.c_size_t
     h.tp3d_gemm_tn_workspace_floats.argtypes = [_l, _i, _i]
+    h.tp3d_ball_query_workspace_bytes.restype = ctypes.c_size_t
+    h.tp3d_ball_query_workspace_bytes.argtypes = [_i, _l, _i]
     if h.tp3d_abi_version() != ABI_VERSION:
         raise Tp3dError("libtp3d_hip.so ABI %d != binding ABI %d" % (h.tp3d_abi_version(), ABI_VERSION))
     _handle = h
@@ -130,6 +133,19 @@ def scatter_workspace(B, L, nbins, with_weights, device):
     """Device scratch for the atomic-free scatter-add backward ops (size dictated by the library)."""
     nbytes = load().tp3d_scatter_workspace_bytes(B, L, nbins, int(with_weights))
     return torch.empty(max(nbytes, 16), dtype=torch.uint8, device=device), nbytes
+
+
+GRID_MIN_POINTS = 2048  # BQ_GRID_MIN_POINTS of csrc/ball_query.hip
+
+
+def ball_query_workspace(num_clouds, rows, max_cloud_points, device):
+    """(buffer, nbytes) for the uniform-grid radius search, or (None, 0) when the brute-force kernels serve it."""
+    if max_cloud_points < GRID_MIN_POINTS:
+        return None, 0
+    nbytes = load().tp3d_ball_query_workspace_bytes(num_clouds, rows, max_cloud_points)
+    if nbytes == 0:
+        return None, 0
+    return torch.empty(nbytes, dtype=torch.uint8, device=device), nbytes
 
 
 def bn_workspace(M, C, device):

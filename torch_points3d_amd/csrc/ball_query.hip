@@ -215,8 +215,13 @@ __global__ __launch_bounds__(BQ_BLOCK) void ball_query_partial_kernel(
 
 }  // namespace tp3d
 
+// Clouds at least this large go through the uniform grid (csrc/grid.hip) when a workspace is supplied; below it
+// the whole cloud fits a few LDS tiles and the brute-force kernels win.
+constexpr int BQ_GRID_MIN_POINTS = 2048;
+
 TP3D_EXPORT int tp3d_ball_query_dense_f32(const float *x, const float *y, int B, int N, int np, float radius,
-                                          int nsample, int sort, int64_t *idx, float *dist2, void *stream)
+                                          int nsample, int sort, int64_t *idx, float *dist2, void *workspace,
+                                          size_t workspace_bytes, void *stream)
 {
     using namespace tp3d;
     if (B < 0 || N < 0 || np < 0 || nsample <= 0) return TP3D_E_BADARG;
@@ -225,6 +230,9 @@ TP3D_EXPORT int tp3d_ball_query_dense_f32(const float *x, const float *y, int B,
     if ((int64_t)N * 3 > INT32_MAX || B > 65535) return TP3D_E_TOOBIG;
     const float r2 = radius * radius;
     hipStream_t s = (hipStream_t)stream;
+    if (workspace && N >= BQ_GRID_MIN_POINTS && grid_edge_for(N) >= 2)
+        return grid_ball_query(x, y, nullptr, nullptr, B, (int64_t)B * N, N, np, (int64_t)B * np, N, radius, nsample,
+                               sort, idx, dist2, workspace, workspace_bytes, s);
     if (sort) {
         const int64_t total = (int64_t)B * np;
         const int block = 64;
@@ -241,7 +249,9 @@ TP3D_EXPORT int tp3d_ball_query_dense_f32(const float *x, const float *y, int B,
 
 TP3D_EXPORT int tp3d_ball_query_partial_dense_f32(const float *x, const float *y, const int64_t *batch_x,
                                                   const int64_t *batch_y, int64_t M, int64_t Nq, float radius,
-                                                  int nsample, int sort, int64_t *idx, float *dist2, void *stream)
+                                                  int nsample, int sort, int64_t *idx, float *dist2,
+                                                  const int64_t *seg_x, int num_clouds, int max_cloud_points,
+                                                  void *workspace, size_t workspace_bytes, void *stream)
 {
     using namespace tp3d;
     if (M < 0 || Nq < 0 || nsample <= 0) return TP3D_E_BADARG;
@@ -249,6 +259,10 @@ TP3D_EXPORT int tp3d_ball_query_partial_dense_f32(const float *x, const float *y
     if (!y || !batch_y || !idx || !dist2 || (M > 0 && (!x || !batch_x))) return TP3D_E_BADARG;
     const float r2 = radius * radius;
     hipStream_t s = (hipStream_t)stream;
+    if (workspace && seg_x && num_clouds > 0 && max_cloud_points >= BQ_GRID_MIN_POINTS &&
+        grid_edge_for(max_cloud_points) >= 2)
+        return grid_ball_query(x, y, seg_x, batch_y, num_clouds, M, 0, 0, Nq, max_cloud_points, radius, nsample, sort,
+                               idx, dist2, workspace, workspace_bytes, s);
     if (sort) {
         const int block = 64;
         // batch_x must be non-null to select the partial-dense branch even when M == 0

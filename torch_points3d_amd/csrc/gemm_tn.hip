@@ -8,6 +8,8 @@
 //
 // Reference semantics: the weight gradient of Conv2d 1x1 (bias=False) inside MLP2D
 // (torch_points3d/core/common_modules/dense_modules.py:5-12,25-29) -- computed by autograd in the reference.
+#include <type_traits>
+
 #include "tp3d_common.h"
 
 namespace tp3d {
@@ -18,7 +20,7 @@ constexpr int TN_BLOCK = 256;  // 4 waves as 2 x 2
 constexpr int TN_BR_MAX = 64;  // most rows staged per step (narrow tiles stage more rows per barrier)
 
 // Each wave owns WM x WN MFMA tiles of 32x32; the workgroup tile is (2*WM*32) x (2*WN*32).
-template <int WM, int WN>
+template <int WM, int WN, bool VECY, bool VECA>
 __global__ __launch_bounds__(TN_BLOCK) void gemm_tn_partial_kernel(const float *__restrict__ dY,
                                                                     const float *__restrict__ A, int64_t M, int N,
                                                                     int K, int64_t rows_per_split, int tiles_k,
@@ -47,39 +49,56 @@ __global__ __launch_bounds__(TN_BLOCK) void gemm_tn_partial_kernel(const float *
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
 
-    const bool vecY = ((N & 3) == 0) && (n0 + TN <= N);
-    const bool vecA = ((K & 3) == 0) && (k0 + TK <= K);
+    // VECY / VECA: that operand's rows are 16-byte aligned (ld % 4 == 0) -> float4 loads, else 4 scalar loads
 
-    for (int64_t r0 = r_begin; r0 < r_end; r0 += TN_BR) {
-        // ---- stage TN_BR rows of both operands (zero-filled past the matrix edge / row range)
-        if (vecY) {
-            for (int e = tid; e < TN_BR * (TN / 4); e += TN_BLOCK) {
-                const int rr = e / (TN / 4), c4 = (e % (TN / 4)) * 4;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (r0 + rr < r_end) v = *reinterpret_cast<const float4 *>(dY + (r0 + rr) * N + n0 + c4);
-                *reinterpret_cast<float4 *>(&sY[rr * LDN + c4]) = v;
-            }
-        } else {
-            for (int e = tid; e < TN_BR * TN; e += TN_BLOCK) {
-                const int rr = e / TN, c = e % TN;
-                sY[rr * LDN + c] = (r0 + rr < r_end && n0 + c < N) ? dY[(r0 + rr) * N + n0 + c] : 0.0f;
+    // four consecutive floats of row r starting at column c (zero past the row range / matrix edge)
+    auto load4 = [&](const float *base, int64_t r, int c, int ld, auto aligned_tag) -> float4 {
+        constexpr bool aligned = decltype(aligned_tag)::value;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (r < r_end) {
+            const float *src = base + r * ld + c;
+            if (aligned) {
+                if (c < ld) v = *reinterpret_cast<const float4 *>(src);  // ld % 4 == 0: all four inside
+            } else {
+                if (c + 0 < ld) v.x = src[0];
+                if (c + 1 < ld) v.y = src[1];
+                if (c + 2 < ld) v.z = src[2];
+                if (c + 3 < ld) v.w = src[3];
             }
         }
-        if (vecA) {
-            for (int e = tid; e < TN_BR * (TK / 4); e += TN_BLOCK) {
-                const int rr = e / (TK / 4), c4 = (e % (TK / 4)) * 4;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (r0 + rr < r_end) v = *reinterpret_cast<const float4 *>(A + (r0 + rr) * K + k0 + c4);
-                *reinterpret_cast<float4 *>(&sA[rr * LDK + c4]) = v;
-            }
-        } else {
-            for (int e = tid; e < TN_BR * TK; e += TN_BLOCK) {
-                const int rr = e / TK, c = e % TK;
-                sA[rr * LDK + c] = (r0 + rr < r_end && k0 + c < K) ? A[(r0 + rr) * K + k0 + c] : 0.0f;
-            }
+        return v;
+    };
+
+    // ---- software pipeline: the loads of step i+1 are in flight while step i runs on the MFMA pipe
+    constexpr int PY = TN_BR * (TN / 4) / TN_BLOCK, PA = TN_BR * (TK / 4) / TN_BLOCK;  // float4 slots per thread
+    static_assert(PY >= 1 && PA >= 1, "tile too small for the thread count");
+    float4 ry[PY], ra[PA];
+    auto fetch = [&](int64_t r0) {
+#pragma unroll
+        for (int i = 0; i < PY; ++i) {
+            const int e = tid + i * TN_BLOCK;
+            ry[i] = load4(dY, r0 + e / (TN / 4), n0 + (e % (TN / 4)) * 4, N, std::integral_constant<bool, VECY>());
+        }
+#pragma unroll
+        for (int i = 0; i < PA; ++i) {
+            const int e = tid + i * TN_BLOCK;
+            ra[i] = load4(A, r0 + e / (TK / 4), k0 + (e % (TK / 4)) * 4, K, std::integral_constant<bool, VECA>());
+        }
+    };
+    if (r_begin < r_end) fetch(r_begin);
+    for (int64_t r0 = r_begin; r0 < r_end; r0 += TN_BR) {
+#pragma unroll
+        for (int i = 0; i < PY; ++i) {
+            const int e = tid + i * TN_BLOCK;
+            *reinterpret_cast<float4 *>(&sY[(e / (TN / 4)) * LDN + (e % (TN / 4)) * 4]) = ry[i];
+        }
+#pragma unroll
+        for (int i = 0; i < PA; ++i) {
+            const int e = tid + i * TN_BLOCK;
+            *reinterpret_cast<float4 *>(&sA[(e / (TK / 4)) * LDK + (e % (TK / 4)) * 4]) = ra[i];
         }
         __syncthreads();
-        // ---- contraction over the staged rows, two rows per MFMA
+        if (r0 + TN_BR < r_end) fetch(r0 + TN_BR);
 #pragma unroll
         for (int rr = 0; rr < TN_BR; rr += 2) {
             float a[WM], b[WN];
@@ -179,18 +198,23 @@ TP3D_EXPORT int tp3d_gemm_tn_f32(const float *dY, const float *A, int64_t M, int
     const TnPlan p = plan_tn(M, N, K);
     if (p.splits > 65535) return TP3D_E_TOOBIG;
     dim3 grid(p.tiles_n * p.tiles_k, p.splits);
-    if (p.wm == 2 && p.wn == 2)
-        hipLaunchKernelGGL((gemm_tn_partial_kernel<2, 2>), grid, dim3(TN_BLOCK), 0, s, dY, A, M, N, K, p.rows_per_split,
-                           p.tiles_k, workspace);
-    else if (p.wm == 2)
-        hipLaunchKernelGGL((gemm_tn_partial_kernel<2, 1>), grid, dim3(TN_BLOCK), 0, s, dY, A, M, N, K, p.rows_per_split,
-                           p.tiles_k, workspace);
-    else if (p.wn == 2)
-        hipLaunchKernelGGL((gemm_tn_partial_kernel<1, 2>), grid, dim3(TN_BLOCK), 0, s, dY, A, M, N, K, p.rows_per_split,
-                           p.tiles_k, workspace);
-    else
-        hipLaunchKernelGGL((gemm_tn_partial_kernel<1, 1>), grid, dim3(TN_BLOCK), 0, s, dY, A, M, N, K, p.rows_per_split,
-                           p.tiles_k, workspace);
+    const bool vy = (N & 3) == 0, va = (K & 3) == 0;
+#define TP3D_TN_LAUNCH(WM_, WN_, VY_, VA_)                                                                          \
+    hipLaunchKernelGGL((gemm_tn_partial_kernel<WM_, WN_, VY_, VA_>), grid, dim3(TN_BLOCK), 0, s, dY, A, M, N, K,      \
+                       p.rows_per_split, p.tiles_k, workspace)
+#define TP3D_TN_ALIGN(WM_, WN_)                                                                                     \
+    do {                                                                                                            \
+        if (vy && va) TP3D_TN_LAUNCH(WM_, WN_, true, true);                                                         \
+        else if (vy) TP3D_TN_LAUNCH(WM_, WN_, true, false);                                                         \
+        else if (va) TP3D_TN_LAUNCH(WM_, WN_, false, true);                                                         \
+        else TP3D_TN_LAUNCH(WM_, WN_, false, false);                                                                \
+    } while (0)
+    if (p.wm == 2 && p.wn == 2) TP3D_TN_ALIGN(2, 2);
+    else if (p.wm == 2) TP3D_TN_ALIGN(2, 1);
+    else if (p.wn == 2) TP3D_TN_ALIGN(1, 2);
+    else TP3D_TN_ALIGN(1, 1);
+#undef TP3D_TN_ALIGN
+#undef TP3D_TN_LAUNCH
     if (int rc = check_launch()) return rc;
     const int64_t NK = (int64_t)N * K;
     hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3((unsigned)((NK + RD_E - 1) / RD_E)), dim3(RD_E * RD_S), 0, s, workspace,

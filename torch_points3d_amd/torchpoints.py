@@ -86,10 +86,20 @@ def ball_query(radius, nsample, x, y, mode="dense", batch_x=None, batch_y=None, 
         Nq = y.shape[0]
         idx = torch.empty((Nq, nsample), dtype=torch.int64, device=dev)
         d2 = torch.empty((Nq, nsample), dtype=torch.float32, device=dev)
+        seg, ws, ws_bytes, nclouds, nmax = None, None, 0, 0, 0
+        if x.shape[0] >= _lib.GRID_MIN_POINTS:
+            # cloud sizes decide between the uniform grid and the segment scan (one host read, like the reference's
+            # own batch bookkeeping); seg = row offsets of the clouds in x
+            counts = torch.bincount(bx)
+            nclouds, nmax = counts.numel(), int(counts.max())
+            ws, ws_bytes = _lib.ball_query_workspace(nclouds, x.shape[0], nmax, dev)
+            if ws is not None:
+                seg = torch.zeros(nclouds + 1, dtype=torch.int64, device=dev)
+                seg[1:] = torch.cumsum(counts, 0)
         with torch.cuda.device(dev):
             _lib.call("tp3d_ball_query_partial_dense_f32", _lib.ptr(x), _lib.ptr(y), _lib.ptr(bx), _lib.ptr(by),
                       x.shape[0], Nq, float(radius), int(nsample), int(bool(sort)), _lib.ptr(idx), _lib.ptr(d2),
-                      _lib.stream_ptr(dev))
+                      _lib.ptr(seg), nclouds, nmax, _lib.ptr(ws), ws_bytes, _lib.stream_ptr(dev))
         return idx, d2
     if m == "dense":
         if batch_x is not None or batch_y is not None:
@@ -102,9 +112,10 @@ def ball_query(radius, nsample, x, y, mode="dense", batch_x=None, batch_y=None, 
         np_ = y.shape[1]
         idx = torch.empty((B, np_, nsample), dtype=torch.int64, device=dev)
         d2 = torch.empty((B, np_, nsample), dtype=torch.float32, device=dev)
+        ws, ws_bytes = _lib.ball_query_workspace(B, B * N, N, dev)
         with torch.cuda.device(dev):
             _lib.call("tp3d_ball_query_dense_f32", _lib.ptr(x), _lib.ptr(y), B, N, np_, float(radius), int(nsample),
-                      int(bool(sort)), _lib.ptr(idx), _lib.ptr(d2), _lib.stream_ptr(dev))
+                      int(bool(sort)), _lib.ptr(idx), _lib.ptr(d2), _lib.ptr(ws), ws_bytes, _lib.stream_ptr(dev))
         return idx, d2
     raise Exception("unrecognized mode {}".format(mode))
 
