@@ -190,6 +190,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-clouds", type=int, default=8)
     ap.add_argument("--cpu-sample-iters", type=int, default=8)
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse "
+                    "the multi-process path on a box with fewer GPUs than ranks)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -203,11 +205,17 @@ def main():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
 
     import torch.distributed as dist
-    device = torch.device("cuda", local_rank)
+    ndev = torch.cuda.device_count()
+    if args.backend == "nccl" and local_rank >= ndev:
+        raise SystemExit("rank %d needs its own GPU (%d visible)" % (local_rank, ndev))
+    device = torch.device("cuda", local_rank % ndev)
     torch.cuda.set_device(device)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=device)
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=device)
+        else:
+            dist.init_process_group(backend=args.backend)
 
     from torch_points3d_amd import _lib
     _lib.load()  # fail loudly if the HIP extension is missing
@@ -215,7 +223,7 @@ def main():
     model = build_model(None, device)
     if world > 1:
         # ~1.38 M fp32 parameters = 5.5 MB: a single bucket, one all-reduce per step over xGMI
-        model = nn.parallel.DistributedDataParallel(model, device_ids=[local_rank], bucket_cap_mb=16,
+        model = nn.parallel.DistributedDataParallel(model, device_ids=[device.index], bucket_cap_mb=16,
                                                     gradient_as_bucket_view=True)
     opt = torch.optim.Adam(model.parameters(), lr=1e-3)
     pos, x, y = make_inputs(B_PER_GPU, N_POINTS, 1234 + rank, device)
@@ -235,13 +243,15 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         train_step(model, opt, pos, x, y)
+    t_enqueued = time.perf_counter() - t0  # host time to enqueue the steps (diagnostic only)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     _lib.set_timer(None)
-    log("timed region done: %.2f ms/step" % (dt / args.steps * 1e3))
+    log("timed region done: %.2f ms/step (host enqueue %.2f ms/step)" % (dt / args.steps * 1e3,
+                                                                          t_enqueued / args.steps * 1e3))
 
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=device)

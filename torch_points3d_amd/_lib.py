@@ -113,26 +113,74 @@ def set_timer(timer):
     return prev
 
 
+_fn_cache = {}
+
+
 def call(name, *args):
-    h = load()
+    """Invoke a C-ABI entry point; pointers travel as plain ints (ptr()), sizes as ints/floats."""
+    fn = _fn_cache.get(name)
+    if fn is None:
+        fn = _fn_cache[name] = getattr(load(), name)
     if _timer is not None:
         a = torch.cuda.Event(enable_timing=True)
         b = torch.cuda.Event(enable_timing=True)
         a.record()
-        rc = getattr(h, name)(*args)
+        rc = fn(*args)
         b.record()
-        _timer.records.append(((name, tuple(v for v in args if isinstance(v, int))), a, b))
+        # size arguments only (device addresses are far above 2**40)
+        _timer.records.append(((name, tuple(v for v in args if type(v) is int and v < (1 << 40))), a, b))
     else:
-        rc = getattr(h, name)(*args)
+        rc = fn(*args)
     if rc != 0:
+        h = load()
         raise Tp3dError("%s failed: %s (code %d, hipError %d)" % (
             name, h.tp3d_strerror(rc).decode(), rc, h.tp3d_last_hip_error()))
+
+
+class on_device(object):
+    """`with on_device(dev):` -- switches the current HIP device only when it is not `dev` already (the common
+    one-process-per-GPU case costs one integer compare instead of a context-manager round trip)."""
+
+    __slots__ = ("idx", "prev")
+
+    def __init__(self, dev):
+        self.idx = dev.index if dev.index is not None else torch.cuda.current_device()
+        self.prev = -1
+
+    def __enter__(self):
+        cur = torch.cuda.current_device()
+        if cur != self.idx:
+            self.prev = cur
+            torch.cuda.set_device(self.idx)
+
+    def __exit__(self, *exc):
+        if self.prev >= 0:
+            torch.cuda.set_device(self.prev)
+        return False
+
+
+_ws_cache = {}
+
+
+def workspace(tag, nbytes, device):
+    """Grow-only scratch buffer per (device, stream, purpose).  Kernels of one stream run in order and every entry
+    point consumes its workspace before returning control to the stream's next kernel, so reuse is safe."""
+    key = (device.index, _raw_stream(device), tag)
+    buf = _ws_cache.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = _ws_cache[key] = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+    return buf
+
+
+def _raw_stream(device):
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    return torch._C._cuda_getCurrentRawStream(idx)
 
 
 def scatter_workspace(B, L, nbins, with_weights, device):
     """Device scratch for the atomic-free scatter-add backward ops (size dictated by the library)."""
     nbytes = load().tp3d_scatter_workspace_bytes(B, L, nbins, int(with_weights))
-    return torch.empty(max(nbytes, 16), dtype=torch.uint8, device=device), nbytes
+    return workspace("scatter", nbytes, device), nbytes
 
 
 GRID_MIN_POINTS = 2048  # BQ_GRID_MIN_POINTS of csrc/ball_query.hip
@@ -145,19 +193,24 @@ def ball_query_workspace(num_clouds, rows, max_cloud_points, device):
     nbytes = load().tp3d_ball_query_workspace_bytes(num_clouds, rows, max_cloud_points)
     if nbytes == 0:
         return None, 0
-    return torch.empty(nbytes, dtype=torch.uint8, device=device), nbytes
+    return workspace("grid", nbytes, device), nbytes
 
 
 def bn_workspace(M, C, device):
     n = load().tp3d_bn_workspace_floats(M, C)
-    return torch.empty(max(n, 4), dtype=torch.float32, device=device)
+    return workspace("bn", 4 * n, device)
+
+
+def gemm_tn_workspace(M, N, K, device):
+    n = load().tp3d_gemm_tn_workspace_floats(M, N, K)
+    return workspace("gemm_tn", 4 * n, device)
 
 
 def ptr(t):
-    """Device pointer of a tensor (None -> NULL)."""
-    return None if t is None else ctypes.c_void_p(t.data_ptr())
+    """Device pointer of a tensor as an int (None -> NULL)."""
+    return None if t is None else t.data_ptr()
 
 
 def stream_ptr(device):
     """hipStream_t of torch's current stream on `device`, so launches order with surrounding torch ops."""
-    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+    return _raw_stream(device)

@@ -92,7 +92,7 @@ __global__ __launch_bounds__(BLOCK) void fps_reg_kernel(const float *__restrict_
     constexpr int NW = BLOCK / kWave;
     constexpr int H = P / 2;
     static_assert(P % 2 == 0, "points are processed in packed pairs");
-    static_assert(NW == 1 || NW == 4 || NW == 16, "cross-wave exchange assumes the partials fit one DPP row");
+    static_assert(NW == 1 || NW == 4 || NW == 8 || NW == 16, "cross-wave exchange assumes the partials fit one DPP row");
     __shared__ float s_v[2][NW], s_x[2][NW], s_y[2][NW], s_z[2][NW];
     __shared__ int s_i[2][NW];
 
@@ -256,13 +256,16 @@ TP3D_EXPORT int tp3d_fps_f32(const float *xyz, int B, int N, int npoint, float *
     if (!xyz || !out_idx) return TP3D_E_BADARG;
     if ((int64_t)N * 3 > INT32_MAX) return TP3D_E_TOOBIG;
     hipStream_t s = (hipStream_t)stream;
+    // Block size per cloud size, measured on MI355X (tools/microbench.py fps): a step is a serial chain
+    // (scan -> DPP arg-max -> LDS exchange -> barrier) of ~0.55 us plus ~0.06 ns per point; 8 waves (512 lanes,
+    // 2 per SIMD) beat 16 waves for every N <= 16384 because the barrier and the VALU issue queue are shorter.
     if (N <= 128) launch_reg<64, 2>(xyz, B, N, npoint, out_idx, s);
     else if (N <= 512) launch_reg<256, 2>(xyz, B, N, npoint, out_idx, s);
     else if (N <= 1024) launch_reg<256, 4>(xyz, B, N, npoint, out_idx, s);
-    else if (N <= 2048) launch_reg<1024, 2>(xyz, B, N, npoint, out_idx, s);
-    else if (N <= 4096) launch_reg<1024, 4>(xyz, B, N, npoint, out_idx, s);
-    else if (N <= 8192) launch_reg<1024, 8>(xyz, B, N, npoint, out_idx, s);
-    else if (N <= 16384) launch_reg<1024, 16>(xyz, B, N, npoint, out_idx, s);
+    else if (N <= 2048) launch_reg<512, 4>(xyz, B, N, npoint, out_idx, s);
+    else if (N <= 4096) launch_reg<512, 8>(xyz, B, N, npoint, out_idx, s);
+    else if (N <= 8192) launch_reg<512, 16>(xyz, B, N, npoint, out_idx, s);
+    else if (N <= 16384) launch_reg<512, 32>(xyz, B, N, npoint, out_idx, s);
     else if (N <= TP3D_FPS_MAX_REG_POINTS) launch_reg<1024, 32>(xyz, B, N, npoint, out_idx, s);
     else {
         if (!scratch) return TP3D_E_BADARG;

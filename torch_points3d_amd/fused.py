@@ -69,9 +69,8 @@ def gemm_tn(dY, A):
     M, N = dY.shape
     K = A.shape[1]
     out = torch.empty((N, K), dtype=torch.float32, device=dev)
-    nws = _lib.load().tp3d_gemm_tn_workspace_floats(M, N, K)
-    ws = torch.empty(max(nws, 4), dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev):
+    ws = _lib.gemm_tn_workspace(M, N, K, dev)
+    with _lib.on_device(dev):
         _lib.call("tp3d_gemm_tn_f32", _lib.ptr(dY), _lib.ptr(A), M, N, K, _lib.ptr(out), _lib.ptr(ws),
                   _lib.stream_ptr(dev))
     return out
@@ -95,7 +94,7 @@ class _LinearBNAct(torch.autograd.Function):
         stats = torch.empty((4, Cout), dtype=torch.float32, device=dev)  # mean, invstd, scale, shift
         ws = _lib.bn_workspace(M, Cout, dev)
         st = _lib.stream_ptr(dev)
-        with torch.cuda.device(dev):
+        with _lib.on_device(dev):
             _lib.call("tp3d_bn_stats_f32", _lib.ptr(Y), M, Cout, float(bn.eps), float(bn.momentum),
                       _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(bn.running_mean), _lib.ptr(bn.running_var),
                       int(training), _lib.ptr(stats[0]), _lib.ptr(stats[1]), _lib.ptr(stats[2]), _lib.ptr(stats[3]),
@@ -127,7 +126,7 @@ class _LinearBNAct(torch.autograd.Function):
         dY = torch.empty_like(Y)
         dgb = torch.empty((2, Cout), dtype=torch.float32, device=dev)  # dbeta, dgamma
         ws = _lib.bn_workspace(M, Cout, dev)
-        with torch.cuda.device(dev):
+        with _lib.on_device(dev):
             _lib.call("tp3d_bn_act_bwd_f32", _lib.ptr(grad_out), _lib.ptr(arg), _lib.ptr(Y), _lib.ptr(stats[2]),
                       _lib.ptr(stats[3]), _lib.ptr(stats[0]), _lib.ptr(stats[1]), slope, M, max(pool_ns, 1), Cout,
                       int(training), _lib.ptr(dgb[0]), _lib.ptr(dgb[1]), _lib.ptr(dY), _lib.ptr(ws),
@@ -161,7 +160,7 @@ class _GroupConcat(torch.autograd.Function):
         xc = None if x_cl is None else x_cl.contiguous()
         ld = _pad4(C + 3)
         out = torch.empty((B * npnt * ns, ld), dtype=torch.float32, device=dev)
-        with torch.cuda.device(dev):
+        with _lib.on_device(dev):
             _lib.call("tp3d_group_concat_fwd_f32", _lib.ptr(pos), _lib.ptr(new_pos), _lib.ptr(xc), _lib.ptr(idx), B, N,
                       npnt, ns, C, ld, float(radius), int(bool(normalize)), _lib.ptr(out), _lib.stream_ptr(dev))
         ctx.save_for_backward(idx)
@@ -179,7 +178,7 @@ class _GroupConcat(torch.autograd.Function):
         g = torch.empty((B, N, C), dtype=torch.float32, device=dev)
         L = npnt * ns
         ws, ws_bytes = _lib.scatter_workspace(B, L, N, False, dev)
-        with torch.cuda.device(dev):
+        with _lib.on_device(dev):
             _lib.call("tp3d_rows_scatter_bwd_f32", _lib.ptr(grad_rows), _lib.ptr(idx), None, B, L, 1, N, ld, 3, C,
                       _lib.ptr(g), _lib.ptr(ws), ws_bytes, _lib.stream_ptr(dev))
         return None, None, g, None, None, None
@@ -202,7 +201,7 @@ class _InterpConcat(torch.autograd.Function):
         sk = None if skip_cl is None else skip_cl.contiguous()
         ld = _pad4(C1 + C2)
         out = torch.empty((B * n, ld), dtype=torch.float32, device=dev)
-        with torch.cuda.device(dev):
+        with _lib.on_device(dev):
             _lib.call("tp3d_interp_concat_fwd_f32", _lib.ptr(feat_cl), _lib.ptr(idx), _lib.ptr(weight), _lib.ptr(sk), B,
                       m, n, C1, C2, ld, _lib.ptr(out), _lib.stream_ptr(dev))
         ctx.save_for_backward(idx, weight)
@@ -219,7 +218,7 @@ class _InterpConcat(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             g_feat = torch.empty((B, m, C1), dtype=torch.float32, device=dev)
             ws, ws_bytes = _lib.scatter_workspace(B, 3 * n, m, True, dev)
-            with torch.cuda.device(dev):
+            with _lib.on_device(dev):
                 _lib.call("tp3d_rows_scatter_bwd_f32", _lib.ptr(grad_rows), _lib.ptr(idx), _lib.ptr(weight), B, 3 * n,
                           3, m, ld, 0, C1, _lib.ptr(g_feat), _lib.ptr(ws), ws_bytes, _lib.stream_ptr(dev))
         g_skip = None
@@ -246,6 +245,6 @@ def idw_weights(dist):
     dev = dist.device
     dist = dist.contiguous()
     w = torch.empty_like(dist)
-    with torch.cuda.device(dev):
+    with _lib.on_device(dev):
         _lib.call("tp3d_idw_weights_f32", _lib.ptr(dist), dist.numel() // 3, _lib.ptr(w), _lib.stream_ptr(dev))
     return w

@@ -37,7 +37,7 @@ def KPConv_ops(query_points, support_points, neighbors_indices, features, K_poin
     M, Cin = x.shape
     KP = kp.shape[0]
     wf = torch.empty((Nq, KP * Cin), dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev):
+    with _lib.on_device(dev):
         _lib.call("tp3d_kpconv_weighted_f32", _lib.ptr(q), _lib.ptr(s), _lib.ptr(nbr), _lib.ptr(x), _lib.ptr(kp), Nq,
                   M, Mn, Cin, KP, float(KP_extent), _INFLUENCE[KP_influence], int(aggregation_mode == "closest"),
                   _lib.ptr(wf), _lib.stream_ptr(dev))

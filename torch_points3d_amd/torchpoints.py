@@ -56,7 +56,7 @@ def furthest_point_sample(xyz, npoint):
     scratch = None
     if N > 32768:  # TP3D_FPS_MAX_REG_POINTS: larger clouds keep the running min-distance in HBM
         scratch = torch.empty((B, N), dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev):
+    with _lib.on_device(dev):
         _lib.call("tp3d_fps_f32", _lib.ptr(xyz), B, N, int(npoint), _lib.ptr(scratch), _lib.ptr(out),
                   _lib.stream_ptr(dev))
     return out
@@ -96,7 +96,7 @@ def ball_query(radius, nsample, x, y, mode="dense", batch_x=None, batch_y=None, 
             if ws is not None:
                 seg = torch.zeros(nclouds + 1, dtype=torch.int64, device=dev)
                 seg[1:] = torch.cumsum(counts, 0)
-        with torch.cuda.device(dev):
+        with _lib.on_device(dev):
             _lib.call("tp3d_ball_query_partial_dense_f32", _lib.ptr(x), _lib.ptr(y), _lib.ptr(bx), _lib.ptr(by),
                       x.shape[0], Nq, float(radius), int(nsample), int(bool(sort)), _lib.ptr(idx), _lib.ptr(d2),
                       _lib.ptr(seg), nclouds, nmax, _lib.ptr(ws), ws_bytes, _lib.stream_ptr(dev))
@@ -113,7 +113,7 @@ def ball_query(radius, nsample, x, y, mode="dense", batch_x=None, batch_y=None, 
         idx = torch.empty((B, np_, nsample), dtype=torch.int64, device=dev)
         d2 = torch.empty((B, np_, nsample), dtype=torch.float32, device=dev)
         ws, ws_bytes = _lib.ball_query_workspace(B, B * N, N, dev)
-        with torch.cuda.device(dev):
+        with _lib.on_device(dev):
             _lib.call("tp3d_ball_query_dense_f32", _lib.ptr(x), _lib.ptr(y), B, N, np_, float(radius), int(nsample),
                       int(bool(sort)), _lib.ptr(idx), _lib.ptr(d2), _lib.ptr(ws), ws_bytes, _lib.stream_ptr(dev))
         return idx, d2
@@ -130,7 +130,7 @@ def three_nn(unknown, known):
     m = known.shape[1]
     dist = torch.empty((B, n, 3), dtype=torch.float32, device=dev)
     idx = torch.empty((B, n, 3), dtype=torch.int64, device=dev)
-    with torch.cuda.device(dev):
+    with _lib.on_device(dev):
         _lib.call("tp3d_three_nn_f32", _lib.ptr(unknown), _lib.ptr(known), B, n, m, _lib.ptr(dist), _lib.ptr(idx),
                   _lib.stream_ptr(dev))
     return dist, idx
@@ -146,7 +146,7 @@ class _ThreeInterpolate(torch.autograd.Function):
         ctx.save_for_backward(idx, weight)
         ctx.m = m
         out = torch.empty((B, C, n), dtype=torch.float32, device=dev)
-        with torch.cuda.device(dev):
+        with _lib.on_device(dev):
             _lib.call("tp3d_three_interpolate_fwd_f32", _lib.ptr(features), _lib.ptr(idx), _lib.ptr(weight), B, C,
                       m, n, _lib.ptr(out), _lib.stream_ptr(dev))
         return out
@@ -159,7 +159,7 @@ class _ThreeInterpolate(torch.autograd.Function):
         B, C, n = grad_out.shape
         g = torch.empty((B, C, ctx.m), dtype=torch.float32, device=dev)
         ws, ws_bytes = _lib.scatter_workspace(B, 3 * n, ctx.m, True, dev)
-        with torch.cuda.device(dev):
+        with _lib.on_device(dev):
             _lib.call("tp3d_three_interpolate_bwd_f32", _lib.ptr(grad_out), _lib.ptr(idx), _lib.ptr(weight), B, C,
                       ctx.m, n, _lib.ptr(g), _lib.ptr(ws), ws_bytes, _lib.stream_ptr(dev))
         return g, None, None
@@ -180,7 +180,7 @@ class _Grouping(torch.autograd.Function):
         ctx.save_for_backward(idx)
         ctx.N = N
         out = torch.empty((B, C, np_, ns), dtype=torch.float32, device=dev)
-        with torch.cuda.device(dev):
+        with _lib.on_device(dev):
             _lib.call("tp3d_group_fwd_f32", _lib.ptr(features), _lib.ptr(idx), B, C, N, np_, ns, _lib.ptr(out),
                       _lib.stream_ptr(dev))
         return out
@@ -193,7 +193,7 @@ class _Grouping(torch.autograd.Function):
         B, C, np_, ns = grad_out.shape
         g = torch.empty((B, C, ctx.N), dtype=torch.float32, device=dev)
         ws, ws_bytes = _lib.scatter_workspace(B, np_ * ns, ctx.N, False, dev)
-        with torch.cuda.device(dev):
+        with _lib.on_device(dev):
             _lib.call("tp3d_group_bwd_f32", _lib.ptr(grad_out), _lib.ptr(idx), B, C, ctx.N, np_, ns, _lib.ptr(g),
                       _lib.ptr(ws), ws_bytes, _lib.stream_ptr(dev))
         return g, None
