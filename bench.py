@@ -4,8 +4,8 @@
 One "step" = one training pass of the hot path over one synthetic batch: zero_grad -> forward (FPS,
 ball_query, grouping, grouped MLP, three_nn, three_interpolate, FP MLPs, head) -> cross-entropy -> backward
 -> Adam step.  Inputs are resident in HBM before the timed region.  One process per GPU; with N > 1 the batch
-is sharded per rank (B=32 per GPU, weak scaling) and the only collective is DDP's gradient all-reduce over
-RCCL.  Rank 0 prints ONE JSON line.
+is sharded per rank (B=32 per GPU, weak scaling) and the only collective is one flat gradient all-reduce over
+RCCL per step (torch_points3d_amd/dp.py).  Rank 0 prints ONE JSON line.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--no-cpu-baseline]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
@@ -190,6 +190,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-clouds", type=int, default=8)
     ap.add_argument("--cpu-sample-iters", type=int, default=8)
+    ap.add_argument("--no-graph", action="store_true", help="single-GPU runs replay the train step from a captured "
+                    "HIP graph (same kernels, no per-launch host cost); this flag keeps eager launches")
+    ap.add_argument("--force-ddp", action="store_true", help="initialise the process group even with one rank "
+                    "(rehearsal of the multi-process code path on a single-GPU box)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse "
                     "the multi-process path on a box with fewer GPUs than ranks)")
     args = ap.parse_args()
@@ -210,50 +214,63 @@ def main():
         raise SystemExit("rank %d needs its own GPU (%d visible)" % (local_rank, ndev))
     device = torch.device("cuda", local_rank % ndev)
     torch.cuda.set_device(device)
-    if world > 1:
+    multi = world > 1 or args.force_ddp
+    if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         if args.backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=device)
         else:
             dist.init_process_group(backend=args.backend)
 
     from torch_points3d_amd import _lib
+    from torch_points3d_amd.dp import ShardedStep
     _lib.load()  # fail loudly if the HIP extension is missing
 
+    # identical initial weights on every rank (same seed); whole clouds per rank; BatchNorm stays per rank
     model = build_model(None, device)
-    if world > 1:
-        # ~1.38 M fp32 parameters = 5.5 MB: a single bucket, one all-reduce per step over xGMI
-        model = nn.parallel.DistributedDataParallel(model, device_ids=[device.index], bucket_cap_mb=16,
-                                                    gradient_as_bucket_view=True)
-    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
     pos, x, y = make_inputs(B_PER_GPU, N_POINTS, 1234 + rank, device)
-
+    use_graph = not args.no_graph
+    trainer = ShardedStep(model, lambda params: torch.optim.Adam(params, lr=1e-3, capturable=use_graph),
+                          lambda: F.cross_entropy(model(pos, x), y), world_size=world, use_graph=use_graph, log=log)
     log("model built; warm-up")
-    for i in range(args.warmup):
-        train_step(model, opt, pos, x, y)
-        torch.cuda.synchronize()
-        log("warm-up step %d done" % i)
+    graphed = trainer.warmup_and_capture(args.warmup)
+    torch.cuda.synchronize()
+    log("warm-up done (%s)" % ("hip-graph replay" if graphed else "eager launches"))
 
     timer = _lib.KernelTimer()
     torch.cuda.synchronize()
-    if world > 1:
+    if multi:
         dist.barrier()
     torch.cuda.synchronize()
-    _lib.set_timer(timer)
+    if not graphed:
+        _lib.set_timer(timer)
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        train_step(model, opt, pos, x, y)
+        trainer.step()
     t_enqueued = time.perf_counter() - t0  # host time to enqueue the steps (diagnostic only)
     torch.cuda.synchronize()
-    if world > 1:
+    if multi:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     _lib.set_timer(None)
+    if graphed and rank == 0:
+        # per-kernel HIP-event timing needs eager launches: the same K steps again, outside the headline region
+        # (rank 0 only; no collective is involved in this pass)
+        world_saved, trainer.world = trainer.world, 1
+        _lib.set_timer(timer)
+        for _ in range(args.steps):
+            trainer.eager_step()
+        torch.cuda.synchronize()
+        _lib.set_timer(None)
+        trainer.world = world_saved
     log("timed region done: %.2f ms/step (host enqueue %.2f ms/step)" % (dt / args.steps * 1e3,
                                                                           t_enqueued / args.steps * 1e3))
 
-    if world > 1:
+    if multi:
         t = torch.tensor([dt], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -327,8 +344,10 @@ def main():
             "data": "synthetic",
             "config": {"workload": "PointNet++ SSG (unet_3_ss) train step fwd+bwd+Adam, B=32 per GPU, N=16384, "
                                    "FEAT=3, 10 classes, pos~U[-1,1]^3 (BASELINE configs[1])",
+                       "launch": "hip-graph replay" if graphed else "eager",
                        "global_batch": world * B_PER_GPU, "points": N_POINTS,
-                       "parallelism": "dp%d (batch shards, DDP gradient all-reduce over RCCL)" % world},
+                       "parallelism": "dp%d (whole clouds per rank, one flat gradient all-reduce over RCCL "
+                                      "per step)" % world},
             "roofline": roofline,
             "cpu_baseline": cpu,
             "entry_points": entries,
@@ -337,7 +356,8 @@ def main():
         if cpu:
             line["gpu_over_cpu"] = round(value / cpu["value"], 1)
         print(json.dumps(line))
-    if world > 1:
+    if multi:
+        dist.barrier()
         dist.destroy_process_group()
 
 

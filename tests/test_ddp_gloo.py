@@ -78,3 +78,52 @@ def test_ddp_two_ranks_average_shard_gradients(tmp_path):
         torch.set_num_threads(nthreads)
     want = (local[0] + local[1]) / 2
     torch.testing.assert_close(res["grads"], want, rtol=1e-5, atol=1e-6)
+
+
+def _sharded_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from torch_points3d_amd.dp import ShardedStep
+    model = _make()
+    pos, x, y = _inputs()
+    sl = slice(rank * 2, rank * 2 + 2)
+    tr = ShardedStep(model, lambda ps: torch.optim.SGD(ps, lr=0.1),
+                     lambda: torch.nn.functional.cross_entropy(model(pos[sl], x[sl]), y[sl]), world_size=world,
+                     use_graph=False)
+    tr._forward_backward()
+    tr._reduce()
+    grads = tr.flat.clone()
+    tr.opt.step()
+    weights = torch.cat([p.detach().reshape(-1) for p in model.parameters()])
+    gathered = [torch.zeros_like(weights) for _ in range(world)]
+    dist.all_gather(gathered, weights)
+    if rank == 0:
+        torch.save({"grads": grads, "same_weights": bool(torch.equal(gathered[0], gathered[1]))}, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_step_flat_allreduce(tmp_path):
+    """bench.py's multi-GPU path (torch_points3d_amd.dp.ShardedStep): one flat gradient all-reduce per step."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = str(tmp_path / "r0.pt")
+    mp.spawn(_sharded_worker, args=(2, port, out), nprocs=2, join=True)
+    res = torch.load(out, weights_only=True)
+    assert res["same_weights"], "ranks diverged after one optimizer step"
+    pos, x, y = _inputs()
+    nthreads = torch.get_num_threads()
+    torch.set_num_threads(1)
+    local = []
+    try:
+        for r in range(2):
+            m = _make()
+            sl = slice(r * 2, r * 2 + 2)
+            torch.nn.functional.cross_entropy(m(pos[sl], x[sl]), y[sl]).backward()
+            local.append(torch.cat([p.grad.reshape(-1) for p in m.parameters()]))
+    finally:
+        torch.set_num_threads(nthreads)
+    torch.testing.assert_close(res["grads"], (local[0] + local[1]) / 2, rtol=1e-5, atol=1e-6)

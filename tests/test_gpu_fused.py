@@ -182,3 +182,31 @@ def test_gemm_tn_matches_fp64(M, N, K):
     Ai = torch.randint(-3, 4, (M, K), generator=g).float().to(DEV)
     if M <= 70000:
         assert torch.equal(fused.gemm_tn(dYi, Ai), torch.mm(dYi.double().t(), Ai.double()).float())
+
+
+def test_sharded_step_same_trajectory():
+    """one graph replay and one eager step from identical states give identical parameters and BN buffers"""
+    import copy
+    import torch.nn.functional as F
+    from torch_points3d_amd.dense import Data
+    from torch_points3d_amd.dp import ShardedStep
+    from torch_points3d_amd.pointnet2 import PointNet2Unet
+
+    g = torch.Generator().manual_seed(6)
+    pos = (torch.rand(2, 2048, 3, generator=g) * 2 - 1).to(DEV)
+    x = torch.randn(2, 2048, 3, generator=g).to(DEV)
+    y = torch.randint(0, 7, (2, 2048), generator=g).to(DEV)
+    torch.manual_seed(0)
+    net = PointNet2Unet(3, output_nc=7, config="unet_3_ss").to(DEV).train()
+    tr = ShardedStep(net, lambda ps: torch.optim.SGD(ps, lr=0.05), lambda: F.cross_entropy(net(Data(pos=pos, x=x)).x, y),
+                     world_size=1, use_graph=True)
+    assert tr.warmup_and_capture(1)
+    state = copy.deepcopy(net.state_dict())
+    tr.step()  # graph replay
+    torch.cuda.synchronize()
+    after_graph = copy.deepcopy(net.state_dict())
+    net.load_state_dict(state)
+    tr.eager_step()
+    torch.cuda.synchronize()
+    for k, v in net.state_dict().items():
+        torch.testing.assert_close(v.float(), after_graph[k].float(), rtol=1e-6, atol=1e-7, msg=lambda m, k=k: k + m)

@@ -1,0 +1,96 @@
+"""Batch-sharded data parallelism for the hot path: one process per GPU, whole clouds per rank, and ONE
+gradient all-reduce per step over RCCL (SURVEY.md 8e -- the reference itself has no distributed path).
+
+Every op of the path is per cloud, so ranks never exchange activations.  All trainable parameters share one
+flat fp32 gradient buffer (their `.grad` are views into it): a step is
+
+    [zero flat, forward, loss, backward]  ->  all_reduce(flat) / world  ->  [optimizer step]
+
+The two bracketed phases are pure device work on static tensors, so each is captured once into a HIP graph and
+replayed (no per-launch host cost); the collective runs between them as a normal RCCL call on the same stream.
+The model has 1.38 M parameters (5.5 MB): a single all-reduce of ~50-100 us per ~12 ms step, so overlapping it
+with backward (what DDP's bucketing buys) is not worth giving up graph replay for.
+BatchNorm statistics stay per rank (the reference has no SyncBN).
+"""
+import torch
+import torch.distributed as dist
+
+
+class ShardedStep(object):
+    def __init__(self, model, make_optimizer, loss_fn, world_size=1, use_graph=True, log=None):
+        """loss_fn() -> scalar loss of this rank's shard (closes over static input tensors)."""
+        self.model = model
+        self.loss_fn = loss_fn
+        self.world = world_size
+        self.log = log or (lambda msg: None)
+        params = [p for p in model.parameters() if p.requires_grad]
+        dev = params[0].device
+        self.flat = torch.zeros(sum(p.numel() for p in params), dtype=torch.float32, device=dev)
+        off = 0
+        for p in params:
+            n = p.numel()
+            p.grad = self.flat[off:off + n].view_as(p)  # autograd accumulates in place into these views
+            off += n
+        self.opt = make_optimizer(params)
+        self.graph_fb = None
+        self.graph_opt = None
+        self.graphed = False
+        self._want_graph = use_graph and dev.type == "cuda"
+
+    # -- phases ------------------------------------------------------------------------------------------
+    def _forward_backward(self):
+        self.flat.zero_()
+        loss = self.loss_fn()
+        loss.backward()
+        return loss
+
+    def _reduce(self):
+        if self.world > 1:
+            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
+            self.flat.div_(self.world)
+
+    def _eager_step(self):
+        self._forward_backward()
+        self._reduce()
+        self.opt.step()
+
+    # -- capture -----------------------------------------------------------------------------------------
+    def warmup_and_capture(self, warmup_steps=3):
+        for _ in range(warmup_steps):
+            self._eager_step()
+        if not self._want_graph:
+            return False
+        try:
+            torch.cuda.synchronize()
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(2):  # allocator / lazy-init warm-up on a non-default stream
+                    self._eager_step()
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            g1 = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g1):
+                self._forward_backward()
+            g2 = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g2):
+                self.opt.step()
+            torch.cuda.synchronize()
+            self.graph_fb, self.graph_opt, self.graphed = g1, g2, True
+            self.log("train step captured into two HIP graphs (forward+backward, optimizer)")
+        except Exception as exc:  # stay on the eager path rather than lose the run
+            self.log("graph capture unavailable (%s: %s); eager launches" % (type(exc).__name__, exc))
+            torch.cuda.synchronize()
+            self.graphed = False
+        return self.graphed
+
+    def step(self):
+        if self.graphed:
+            self.graph_fb.replay()
+            self._reduce()
+            self.graph_opt.replay()
+        else:
+            self._eager_step()
+
+    def eager_step(self):
+        self._eager_step()
