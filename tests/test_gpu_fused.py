@@ -210,3 +210,27 @@ def test_sharded_step_same_trajectory():
     torch.cuda.synchronize()
     for k, v in net.state_dict().items():
         torch.testing.assert_close(v.float(), after_graph[k].float(), rtol=1e-6, atol=1e-7, msg=lambda m, k=k: k + m)
+
+
+@pytest.mark.parametrize("M,N,K", [(1000, 64, 8), (4096, 128, 132), (70000, 128, 128), (33, 8, 4), (20000, 256, 260),
+                                   (5000, 1024, 512), (262144, 128, 64), (129, 132, 68), (4096, 256, 1280)])
+def test_gemm_rows_matches_fp64_and_stats(M, N, K):
+    """fp32 MFMA rows GEMM (forward / input-gradient contraction) + fused BatchNorm statistics epilogue"""
+    from torch_points3d_amd import fused
+    g = torch.Generator().manual_seed(M + N + K)
+    A = torch.randn(M, K, generator=g).to(DEV)
+    Bm = torch.randn(K, N, generator=g).to(DEV)
+    C, part = fused.gemm_rows(A, Bm, want_stats=True)
+    ref = torch.mm(A.double(), Bm.double())
+    err = float((C.double() - ref).abs().max())
+    lib = float((torch.mm(A, Bm).double() - ref).abs().max())
+    assert err <= max(2.0 * lib, 1e-5 * float(ref.abs().max())), (err, lib)
+    chunks = (M + 127) // 128
+    p = part[: chunks * 2 * N * 4].view(torch.float32).view(chunks, 2, N)
+    torch.testing.assert_close(p[:, 0].double().sum(0), ref.sum(0), rtol=1e-4, atol=1e-3 * float(ref.abs().max()))
+    torch.testing.assert_close(p[:, 1].double().sum(0), (ref * ref).sum(0), rtol=1e-4, atol=1e-2)
+    # exact integer data: any operand / accumulator layout mix-up shows up as a wrong integer
+    Ai = torch.randint(-3, 4, (M, K), generator=g).float().to(DEV)
+    Bi = torch.randint(-3, 4, (K, N), generator=g).float().to(DEV)
+    Ci, _ = fused.gemm_rows(Ai, Bi)
+    assert torch.equal(Ci, torch.mm(Ai.double(), Bi.double()).float())

@@ -38,6 +38,20 @@ def bench_gemm_tn(reps):
             M, N, K, t * 1e3, fl / t / 1e9, by / t / 1e9, t2 * 1e3))
 
 
+def bench_gemm_rows(reps):
+    for M, N, K in [(524288, 128, 132), (524288, 128, 128), (1048576, 64, 8), (1048576, 64, 64), (1048576, 128, 64),
+                    (262144, 128, 132), (262144, 128, 128), (262144, 256, 128), (16384, 256, 1280), (16384, 128, 384),
+                    (524288, 132, 128), (1048576, 8, 64), (4096, 1024, 512)]:
+        A = torch.randn(M, K, device=DEV)
+        Bm = torch.randn(K, N, device=DEV)
+        t = timeit(lambda: fused.gemm_rows(A, Bm, want_stats=True), reps)
+        t0 = timeit(lambda: fused.gemm_rows(A, Bm, want_stats=False), reps)
+        t2 = timeit(lambda: torch.mm(A, Bm), reps)
+        fl = 2.0 * M * N * K
+        print("gemm_rows M=%8d N=%4d K=%4d  %8.1f us (+stats %8.1f)  %6.1f TF/s   torch.mm %8.1f us %6.1f TF/s" % (
+            M, N, K, t0 * 1e3, t * 1e3, fl / t0 / 1e9, t2 * 1e3, fl / t2 / 1e9))
+
+
 def bench_fps(reps):
     for B, N, n in [(32, 16384, 512), (32, 512, 128), (32, 2048, 512), (32, 4096, 1024), (8, 16384, 2048)]:
         pos = torch.rand(B, N, 3, device=DEV) * 2 - 1
@@ -62,6 +76,8 @@ if __name__ == "__main__":
     _lib.load()
     if what in ("gemm_tn", "all"):
         bench_gemm_tn(reps)
+    if what in ("gemm_rows", "all"):
+        bench_gemm_rows(reps)
     if what in ("fps", "all"):
         bench_fps(reps)
     if what in ("ball", "all"):

@@ -598,6 +598,18 @@ TP3D_EXPORT int tp3d_bn_stats_f32(const float *Y, int64_t M, int C, float eps, f
     return check_launch();
 }
 
+// training-mode statistics from per-chunk (sum, sum of squares) partials written by another kernel's epilogue
+// (tp3d_gemm_rows_f32): partial[chunk][2][C]
+TP3D_EXPORT int tp3d_bn_finalize_f32(const float *partial, int chunks, int64_t M, int C, float eps, float momentum,
+                                     const float *gamma, const float *beta, float *running_mean, float *running_var,
+                                     float *mean, float *invstd, float *scale, float *shift, void *stream)
+{
+    if (M <= 0 || C <= 0 || chunks <= 0 || !partial || !mean || !invstd || !scale || !shift) return TP3D_E_BADARG;
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(RW_BLOCK), 0, (hipStream_t)stream, partial, chunks, M, C, eps,
+                       momentum, gamma, beta, running_mean, running_var, 1, mean, invstd, scale, shift);
+    return check_launch();
+}
+
 TP3D_EXPORT int tp3d_bn_act_f32(const float *Y, const float *scale, const float *shift, float slope, int64_t M, int C,
                                 float *out, void *stream)
 {

@@ -14,6 +14,9 @@ import torch.nn as nn
 from . import _lib
 
 
+USE_ROWS_GEMM = True  # False: forward / input-gradient contractions through torch.mm (library GEMM)
+
+
 def _cl(x):
     """(B, C, N) tensor -> its (B, N, C) contiguous channel-last form (free when x is a transposed view)."""
     return x.transpose(1, 2).contiguous()
@@ -76,6 +79,22 @@ def gemm_tn(dY, A):
     return out
 
 
+def gemm_rows(A, Bm, want_stats=False):
+    """A (M,K) @ Bm (K,N) -> (M,N) with the fp32 MFMA rows kernel (csrc/gemm_rows.hip); optionally also the
+    per-128-row-block column sums / sums of squares for BatchNorm.  K and N must be multiples of 4."""
+    dev = A.device
+    M, K = A.shape
+    N = Bm.shape[1]
+    C = torch.empty((M, N), dtype=torch.float32, device=dev)
+    part = None
+    if want_stats:
+        part = _lib.workspace("gemm_rows_stats", 4 * _lib.load().tp3d_gemm_rows_stat_floats(M, N), dev)
+    with _lib.on_device(dev):
+        _lib.call("tp3d_gemm_rows_f32", _lib.ptr(A), _lib.ptr(Bm), M, N, K, _lib.ptr(C), _lib.ptr(part),
+                  _lib.stream_ptr(dev))
+    return C, part
+
+
 class _LinearBNAct(torch.autograd.Function):
     """out = LeakyReLU(BatchNorm(A @ W^T)) on rows; with pool_ns > 0 also the max over groups of pool_ns rows."""
 
@@ -89,16 +108,31 @@ class _LinearBNAct(torch.autograd.Function):
         Cin = W2.shape[1]
         if Kp != Cin:
             W2 = torch.nn.functional.pad(W2, (0, Kp - Cin))
-        Y = torch.mm(A, W2.t())  # the dense contraction: a plain library GEMM
         training = bn.training
         stats = torch.empty((4, Cout), dtype=torch.float32, device=dev)  # mean, invstd, scale, shift
-        ws = _lib.bn_workspace(M, Cout, dev)
         st = _lib.stream_ptr(dev)
+        # measured on MI355X (tools/microbench.py gemm_rows): with the statistics fused, the rows kernel beats
+        # "library GEMM + separate statistics pass" when its 128-wide column tiles are full; for other widths
+        # (64, 132, the 10-class head) the library GEMM plus tp3d_bn_stats_f32 is faster
+        own_gemm = USE_ROWS_GEMM and training and Cout % 128 == 0 and Kp % 4 == 0
+        if own_gemm:
+            # the dense contraction on the fp32 MFMA rows kernel; BatchNorm statistics come out of its epilogue
+            Y, part = gemm_rows(A, W2.t().contiguous(), want_stats=training)
+        else:
+            Y = torch.mm(A, W2.t())  # plain library GEMM (unaligned channel counts, e.g. the 10-class head)
+            part = None
         with _lib.on_device(dev):
-            _lib.call("tp3d_bn_stats_f32", _lib.ptr(Y), M, Cout, float(bn.eps), float(bn.momentum),
-                      _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(bn.running_mean), _lib.ptr(bn.running_var),
-                      int(training), _lib.ptr(stats[0]), _lib.ptr(stats[1]), _lib.ptr(stats[2]), _lib.ptr(stats[3]),
-                      _lib.ptr(ws), st)
+            if part is not None:
+                _lib.call("tp3d_bn_finalize_f32", _lib.ptr(part), (M + 127) // 128, M, Cout, float(bn.eps),
+                          float(bn.momentum), _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(bn.running_mean),
+                          _lib.ptr(bn.running_var), _lib.ptr(stats[0]), _lib.ptr(stats[1]), _lib.ptr(stats[2]),
+                          _lib.ptr(stats[3]), st)
+            else:
+                ws = _lib.bn_workspace(M, Cout, dev)
+                _lib.call("tp3d_bn_stats_f32", _lib.ptr(Y), M, Cout, float(bn.eps), float(bn.momentum),
+                          _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(bn.running_mean), _lib.ptr(bn.running_var),
+                          int(training), _lib.ptr(stats[0]), _lib.ptr(stats[1]), _lib.ptr(stats[2]),
+                          _lib.ptr(stats[3]), _lib.ptr(ws), st)
             if pool_ns:
                 G = M // pool_ns
                 out = torch.empty((G, Cout), dtype=torch.float32, device=dev)
@@ -132,6 +166,8 @@ class _LinearBNAct(torch.autograd.Function):
                       int(training), _lib.ptr(dgb[0]), _lib.ptr(dgb[1]), _lib.ptr(dY), _lib.ptr(ws),
                       _lib.stream_ptr(dev))
         dW = gemm_tn(dY, A)[:, :Cin].reshape(wshape) if ctx.needs_input_grad[1] else None
+        # input gradient: nothing to fuse into its epilogue, and the library GEMM is 10-25 % faster than the rows
+        # kernel on these shapes (same measurement), so it stays a plain library GEMM
         dA = torch.mm(dY, W2) if ctx.needs_input_grad[0] else None
         return dA, dW, dgb[1], dgb[0], None, None, None
 
