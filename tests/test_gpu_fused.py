@@ -220,7 +220,7 @@ def test_gemm_rows_matches_fp64_and_stats(M, N, K):
     g = torch.Generator().manual_seed(M + N + K)
     A = torch.randn(M, K, generator=g).to(DEV)
     Bm = torch.randn(K, N, generator=g).to(DEV)
-    C, part = fused.gemm_rows(A, Bm, want_stats=True)
+    C, part = fused.gemm_rows(A, Bm.t().contiguous(), want_stats=True)
     ref = torch.mm(A.double(), Bm.double())
     err = float((C.double() - ref).abs().max())
     lib = float((torch.mm(A, Bm).double() - ref).abs().max())
@@ -232,5 +232,5 @@ def test_gemm_rows_matches_fp64_and_stats(M, N, K):
     # exact integer data: any operand / accumulator layout mix-up shows up as a wrong integer
     Ai = torch.randint(-3, 4, (M, K), generator=g).float().to(DEV)
     Bi = torch.randint(-3, 4, (K, N), generator=g).float().to(DEV)
-    Ci, _ = fused.gemm_rows(Ai, Bi)
+    Ci, _ = fused.gemm_rows(Ai, Bi.t().contiguous())
     assert torch.equal(Ci, torch.mm(Ai.double(), Bi.double()).float())

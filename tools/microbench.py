@@ -44,8 +44,9 @@ def bench_gemm_rows(reps):
                     (524288, 132, 128), (1048576, 8, 64), (4096, 1024, 512)]:
         A = torch.randn(M, K, device=DEV)
         Bm = torch.randn(K, N, device=DEV)
-        t = timeit(lambda: fused.gemm_rows(A, Bm, want_stats=True), reps)
-        t0 = timeit(lambda: fused.gemm_rows(A, Bm, want_stats=False), reps)
+        Bt = Bm.t().contiguous()
+        t = timeit(lambda: fused.gemm_rows(A, Bt, want_stats=True), reps)
+        t0 = timeit(lambda: fused.gemm_rows(A, Bt, want_stats=False), reps)
         t2 = timeit(lambda: torch.mm(A, Bm), reps)
         fl = 2.0 * M * N * K
         print("gemm_rows M=%8d N=%4d K=%4d  %8.1f us (+stats %8.1f)  %6.1f TF/s   torch.mm %8.1f us %6.1f TF/s" % (

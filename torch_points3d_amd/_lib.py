@@ -41,7 +41,7 @@ SIGNATURES = {
 MISC = ("tp3d_abi_version", "tp3d_strerror", "tp3d_last_hip_error", "tp3d_scatter_workspace_bytes",
         "tp3d_bn_workspace_floats", "tp3d_gemm_tn_workspace_floats", "tp3d_ball_query_workspace_bytes",
         "tp3d_gemm_rows_stat_floats")
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 _handle = None
 

@@ -1,15 +1,16 @@
 // Tall-skinny fp32 GEMM of the shared MLPs with the BatchNorm statistics fused into its epilogue:
-//     C[M,N] = A[M,K] * B[K,N]          M = B*npoint*nsample rows (up to ~1e6), N, K <= ~1300
-//     stats (optional): per 128-row block, per column: sum and sum of squares of C  -> bn_finalize
-// Forward pass:  Y = rows @ W^T   (B = W^T, K = Cin, N = Cout)  + column statistics of Y (saves a full read of Y)
-// Input grad:    dA = dY @ W      (B = W,   K = Cout, N = Cin)
+//     C[M,N] = A[M,K] * Bt[N,K]^T       M = B*npoint*nsample rows (up to ~1e6), N, K <= ~1300, K contiguous in both
+//     stats (optional): per 128-row block, per column: sum and sum of squares of C  -> tp3d_bn_finalize_f32
+// Forward pass:  Y = rows @ W^T   (Bt = W as stored: Cout x Cin)  + column statistics of Y (saves a full read of Y)
 // Reference semantics: Conv2d 1x1 (bias=False) followed by BatchNorm2d in training mode
 // (torch_points3d/core/common_modules/dense_modules.py:5-12,25-29).
 //
-// 4 waves per workgroup as 2x2, each wave 2x2 MFMA tiles of 32x32 (v_mfma_f32_32x32x2_f32, exact fp32):
-// a 128 x 128 output tile per workgroup, K walked in steps of 32 through LDS with the global loads of step i+1
-// in flight during the MFMAs of step i.  A is staged row-major with a 33-float pitch so that the MFMA operand
-// fetch (32 consecutive ROWS at one k) is bank-conflict free; B rows are contiguous in n already.
+// 4 waves per workgroup as 2x2, each wave 2x2 MFMA tiles of 32x32 (v_mfma_f32_32x32x2_f32, exact fp32): a 128 x 128
+// output tile per workgroup, K walked in steps of 32 through LDS, the global loads of step i+1 in flight during the
+// MFMAs of step i.  Both operands are staged as [row][k] with a 36-float pitch: float4 stores stay aligned and the
+// ds_read_b128 operand fetch (lane = row) is bank-conflict free (36*r mod 64 hits 16 disjoint 4-bank slots).
+// Which physical k feeds which MFMA k-slot is free as long as A and B agree: in every group of 8 k's the lower
+// half-wave takes k0..k0+3 and the upper half-wave k0+4..k0+7, so one 16-byte LDS read feeds four MFMAs.
 #include "tp3d_common.h"
 
 namespace tp3d {
@@ -18,128 +19,146 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int GR_BLOCK_T = 256;
 constexpr int GR_BM = 128, GR_BN = 128, GR_BK = 32;
-constexpr int GR_LDA = GR_BK + 1;   // 33: odd pitch -> lanes (consecutive rows) hit distinct banks
-constexpr int GR_LDB = GR_BN + 4;   // 132: keeps float4 stores aligned
+constexpr int GR_LD = GR_BK + 4;  // 36-float pitch
 
 template <bool STATS>
-__global__ __launch_bounds__(GR_BLOCK_T) void gemm_rows_kernel(const float *__restrict__ A, const float *__restrict__ B,
-                                                                int64_t M, int N, int K, int tiles_n,
+__global__ __launch_bounds__(GR_BLOCK_T) void gemm_rows_kernel(const float *__restrict__ A, const float *__restrict__ Bt,
+                                                                int64_t M, int N, int K, int tiles_n, int64_t items,
                                                                 float *__restrict__ C, float *__restrict__ partial)
 {
-    __shared__ float sA[GR_BM * GR_LDA];
-    __shared__ __attribute__((aligned(16))) float sB[GR_BK * GR_LDB];
+    __shared__ __attribute__((aligned(16))) float sA[GR_BM * GR_LD];
+    __shared__ __attribute__((aligned(16))) float sB[GR_BN * GR_LD];
     __shared__ float s_st[2][2][GR_BN];  // [sum|sumsq][wave row][column]
-
-    // XCD-aware order: the column tiles of one row block are 8 ids apart, i.e. on the same XCD (shared L2 for A)
-    const int id = blockIdx.x;
-    const int grp = id / (8 * tiles_n), rem = id % (8 * tiles_n);
-    const int64_t rb = (int64_t)grp * 8 + (rem & 7);
-    const int ct = rem >> 3;
-    const int64_t m0 = rb * GR_BM;
-    const int n0 = ct * GR_BN;
-    if (m0 >= M) return;  // uniform for the workgroup (grid is rounded up to a multiple of 8 row blocks)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
     const int l31 = lane & 31, lh = lane >> 5;
+    const int ksteps = (K + GR_BK - 1) / GR_BK;
 
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+    // Work items = (row block, column tile) in an XCD-aware order: the column tiles of one row block are 8 ids
+    // apart, i.e. on the same XCD (shared L2 for A).  Workgroups are PERSISTENT: each walks items id, id + G, ...
+    // (G a multiple of 8) as one flat sequence of K-steps, so the loads of the next item's first K-step are already
+    // in flight while this item's epilogue stores drain -- no exposed prologue/epilogue latency per tile.
+    auto decode = [&](int64_t item, int64_t &m0, int &n0, int64_t &rb) {
+        const int64_t grp = item / (8 * tiles_n);
+        const int rem = (int)(item % (8 * tiles_n));
+        rb = grp * 8 + (rem & 7);
+        m0 = rb * GR_BM;
+        n0 = (rem >> 3) * GR_BN;
+    };
 
-    // staging registers: A tile 128 x 32 = 1024 float4 (4 per thread), B tile 32 x 128 = 1024 float4 (4 per thread)
+    // staging registers: each tile is 128 rows x 32 k = 1024 float4 (4 per thread and operand)
     float4 ra[4], rbv[4];
-    auto fetch = [&](int k0) {
+    auto fetch = [&](int64_t m0, int n0, int k0) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int e = tid + i * GR_BLOCK_T;
-            const int row = e >> 3, k4 = (e & 7) * 4;  // 8 float4 per A row
+            const int row = e >> 3, k4 = (e & 7) * 4;  // 8 float4 per row
             const int64_t m = m0 + row;
             ra[i] = (m < M && k0 + k4 < K) ? *reinterpret_cast<const float4 *>(A + m * K + k0 + k4)
                                            : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int e = tid + i * GR_BLOCK_T;
-            const int kr = e >> 5, c4 = (e & 31) * 4;  // 32 float4 per B row
-            rbv[i] = (k0 + kr < K && n0 + c4 < N) ? *reinterpret_cast<const float4 *>(B + (size_t)(k0 + kr) * N + n0 + c4)
-                                                  : make_float4(0.f, 0.f, 0.f, 0.f);
+            const int n = n0 + row;
+            rbv[i] = (n < N && k0 + k4 < K) ? *reinterpret_cast<const float4 *>(Bt + (size_t)n * K + k0 + k4)
+                                            : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
-    fetch(0);
-    for (int k0 = 0; k0 < K; k0 += GR_BK) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int e = tid + i * GR_BLOCK_T;
-            float *d = &sA[(e >> 3) * GR_LDA + (e & 7) * 4];
-            d[0] = ra[i].x;
-            d[1] = ra[i].y;
-            d[2] = ra[i].z;
-            d[3] = ra[i].w;
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int e = tid + i * GR_BLOCK_T;
-            *reinterpret_cast<float4 *>(&sB[(e >> 5) * GR_LDB + (e & 31) * 4]) = rbv[i];
-        }
-        __syncthreads();
-        if (k0 + GR_BK < K) fetch(k0 + GR_BK);
-#pragma unroll
-        for (int kk = 0; kk < GR_BK; kk += 2) {
-            float a[2], b[2];
-#pragma unroll
-            for (int i = 0; i < 2; ++i) a[i] = sA[((wr * 2 + i) * 32 + l31) * GR_LDA + kk + lh];
-#pragma unroll
-            for (int j = 0; j < 2; ++j) b[j] = sB[(kk + lh) * GR_LDB + (wc * 2 + j) * 32 + l31];
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
-        }
-        __syncthreads();
-    }
 
-    // ---- epilogue: D[row][col], col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+    int64_t item = blockIdx.x;
+    if (item >= items) return;
+    int64_t m0, rb;
+    int n0;
+    decode(item, m0, n0, rb);
+    fetch(m0, n0, 0);
+
+    f32x16 acc[2][2];
+    while (item < items) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int n = n0 + (wc * 2 + j) * 32 + l31;
+            for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int64_t m = m0 + (wr * 2 + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-                if (m < M && n < N) C[m * N + n] = acc[i][j][e];
+                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+        const int64_t next_item = item + gridDim.x;
+        int64_t nm0 = 0, nrb = 0;
+        int nn0 = 0;
+        if (next_item < items) decode(next_item, nm0, nn0, nrb);
+
+        for (int ks = 0; ks < ksteps; ++ks) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int e = tid + i * GR_BLOCK_T;
+                const int o = (e >> 3) * GR_LD + (e & 7) * 4;
+                *reinterpret_cast<float4 *>(&sA[o]) = ra[i];
+                *reinterpret_cast<float4 *>(&sB[o]) = rbv[i];
             }
+            __syncthreads();
+            if (ks + 1 < ksteps) fetch(m0, n0, (ks + 1) * GR_BK);
+            else if (next_item < items) fetch(nm0, nn0, 0);  // next item's first K-step rides under this epilogue
+#pragma unroll
+            for (int g = 0; g < GR_BK / 8; ++g) {
+                float4 a[2], b[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+                    a[i] = *reinterpret_cast<const float4 *>(&sA[((wr * 2 + i) * 32 + l31) * GR_LD + g * 8 + lh * 4]);
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    b[j] = *reinterpret_cast<const float4 *>(&sB[((wc * 2 + j) * 32 + l31) * GR_LD + g * 8 + lh * 4]);
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].x, b[j].x, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].y, b[j].y, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].z, b[j].z, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, b[j].w, acc[i][j], 0, 0, 0);
+                    }
+            }
+            __syncthreads();
         }
-    if (STATS) {
-        // rows past M were staged as zeros, so they add nothing to either sum
+
+        // ---- epilogue: D[row][col], col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            float s1 = 0.0f, s2 = 0.0f;
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int j = 0; j < 2; ++j) {
+                const int n = n0 + (wc * 2 + j) * 32 + l31;
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
-                    const float v = acc[i][j][e];
-                    s1 += v;
-                    s2 += v * v;
+                    const int64_t m = m0 + (wr * 2 + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                    if (m < M && n < N) C[m * N + n] = acc[i][j][e];
                 }
-            s1 += __shfl_xor(s1, 32);  // the two half-waves hold different rows of the same column
-            s2 += __shfl_xor(s2, 32);
-            if (lh == 0) {
-                s_st[0][wr][(wc * 2 + j) * 32 + l31] = s1;
-                s_st[1][wr][(wc * 2 + j) * 32 + l31] = s2;
             }
+        if (STATS) {
+            // rows past M were staged as zeros, so they add nothing to either sum
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                float s1 = 0.0f, s2 = 0.0f;
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const float v = acc[i][j][e];
+                        s1 += v;
+                        s2 += v * v;
+                    }
+                s1 += __shfl_xor(s1, 32);  // the two half-waves hold different rows of the same column
+                s2 += __shfl_xor(s2, 32);
+                if (lh == 0) {
+                    s_st[0][wr][(wc * 2 + j) * 32 + l31] = s1;
+                    s_st[1][wr][(wc * 2 + j) * 32 + l31] = s2;
+                }
+            }
+            __syncthreads();
+            if (tid < GR_BN && n0 + tid < N) {
+                partial[((size_t)rb * 2 + 0) * N + n0 + tid] = s_st[0][0][tid] + s_st[0][1][tid];
+                partial[((size_t)rb * 2 + 1) * N + n0 + tid] = s_st[1][0][tid] + s_st[1][1][tid];
+            }
+            // (the next write to s_st is separated from these reads by the K-loop barriers of the next item)
         }
-        __syncthreads();
-        if (tid < GR_BN && n0 + tid < N) {
-            partial[((size_t)rb * 2 + 0) * N + n0 + tid] = s_st[0][0][tid] + s_st[0][1][tid];
-            partial[((size_t)rb * 2 + 1) * N + n0 + tid] = s_st[1][0][tid] + s_st[1][1][tid];
-        }
+        item = next_item;
+        m0 = nm0;
+        n0 = nn0;
+        rb = nrb;
     }
 }
 
@@ -154,23 +173,23 @@ TP3D_EXPORT size_t tp3d_gemm_rows_stat_floats(int64_t M, int N)
     return (size_t)((M + GR_BM - 1) / GR_BM) * 2 * (size_t)N;
 }
 
-TP3D_EXPORT int tp3d_gemm_rows_f32(const float *A, const float *B, int64_t M, int N, int K, float *C,
+TP3D_EXPORT int tp3d_gemm_rows_f32(const float *A, const float *Bt, int64_t M, int N, int K, float *C,
                                    float *stat_partial, void *stream)
 {
-    if (M < 0 || N <= 0 || K <= 0 || (N & 3) || (K & 3)) return TP3D_E_BADARG;  // rows must be 16-byte aligned
+    if (M < 0 || N <= 0 || K <= 0 || (K & 3)) return TP3D_E_BADARG;  // operand rows must be 16-byte aligned
     if (M == 0) return TP3D_OK;
-    if (!A || !B || !C) return TP3D_E_BADARG;
+    if (!A || !Bt || !C) return TP3D_E_BADARG;
     const int tiles_n = (N + GR_BN - 1) / GR_BN;
     const int64_t row_blocks = (M + GR_BM - 1) / GR_BM;
     const int64_t groups = (row_blocks + 7) / 8;
-    const int64_t blocks = groups * 8 * tiles_n;
-    if (blocks > 0x7fffffff) return TP3D_E_TOOBIG;
+    const int64_t items = groups * 8 * tiles_n;  // items past the last row block stage zeros and store nothing
+    const int64_t blocks = items < 1024 ? items : 1024;  // persistent: 4 workgroups per CU, a multiple of 8
     hipStream_t s = (hipStream_t)stream;
     if (stat_partial)
-        hipLaunchKernelGGL(gemm_rows_kernel<true>, dim3((unsigned)blocks), dim3(GR_BLOCK_T), 0, s, A, B, M, N, K, tiles_n,
-                           C, stat_partial);
+        hipLaunchKernelGGL(gemm_rows_kernel<true>, dim3((unsigned)blocks), dim3(GR_BLOCK_T), 0, s, A, Bt, M, N, K, tiles_n,
+                           items, C, stat_partial);
     else
-        hipLaunchKernelGGL(gemm_rows_kernel<false>, dim3((unsigned)blocks), dim3(GR_BLOCK_T), 0, s, A, B, M, N, K, tiles_n,
-                           C, stat_partial);
+        hipLaunchKernelGGL(gemm_rows_kernel<false>, dim3((unsigned)blocks), dim3(GR_BLOCK_T), 0, s, A, Bt, M, N, K, tiles_n,
+                           items, C, stat_partial);
     return check_launch();
 }

@@ -79,12 +79,13 @@ def gemm_tn(dY, A):
     return out
 
 
-def gemm_rows(A, Bm, want_stats=False):
-    """A (M,K) @ Bm (K,N) -> (M,N) with the fp32 MFMA rows kernel (csrc/gemm_rows.hip); optionally also the
-    per-128-row-block column sums / sums of squares for BatchNorm.  K and N must be multiples of 4."""
+def gemm_rows(A, Bt, want_stats=False):
+    """A (M,K) @ Bt (N,K)^T -> (M,N) with the fp32 MFMA rows kernel (csrc/gemm_rows.hip); optionally also the
+    per-128-row-block column sums / sums of squares for BatchNorm.  K must be a multiple of 4."""
     dev = A.device
     M, K = A.shape
-    N = Bm.shape[1]
+    N = Bt.shape[0]
+    Bm = Bt.contiguous()
     C = torch.empty((M, N), dtype=torch.float32, device=dev)
     part = None
     if want_stats:
@@ -117,7 +118,7 @@ class _LinearBNAct(torch.autograd.Function):
         own_gemm = USE_ROWS_GEMM and training and Cout % 128 == 0 and Kp % 4 == 0
         if own_gemm:
             # the dense contraction on the fp32 MFMA rows kernel; BatchNorm statistics come out of its epilogue
-            Y, part = gemm_rows(A, W2.t().contiguous(), want_stats=training)
+            Y, part = gemm_rows(A, W2, want_stats=training)
         else:
             Y = torch.mm(A, W2.t())  # plain library GEMM (unaligned channel counts, e.g. the 10-class head)
             part = None
