@@ -52,10 +52,13 @@ def make_inputs(B, N, seed, device):
     return pos.to(device), x.to(device), y.to(device)
 
 
+MODEL_CONFIG = "unet_3_ss"  # the reference's default SSG (applications/conf/pointnet2/unet_3_ss.yaml)
+
+
 def build_model(kernels, device):
     from torch_points3d_amd.pointnet2 import PointNet2Unet
     torch.manual_seed(0)
-    net = PointNet2Unet(FEAT, output_nc=NUM_CLASSES, config="unet_3_ss", kernels=kernels)
+    net = PointNet2Unet(FEAT, output_nc=NUM_CLASSES, config=MODEL_CONFIG, kernels=kernels)
     return SegStep(net).to(device).train()
 
 
@@ -113,14 +116,17 @@ def algorithmic_bytes(name, a):
         return B * (m * C1 * 4 + n * 36 + n * C2 * 4 + n * ld * 4)
     if name == "tp3d_idw_weights_f32":  # rows
         return a[0] * 24
-    if name == "tp3d_gemm_tn_f32":  # M, N, K
+    if name in ("tp3d_gemm_tn_f32", "tp3d_gemm_rows_f32"):  # M, N, K
         M, N, K = a[:3]
         return (M * (N + K) + N * K) * 4
+    if name == "tp3d_bn_finalize_f32":  # chunks, M, C
+        chunks, M, C = a[:3]
+        return chunks * 2 * C * 4
     return 0
 
 
 def algorithmic_flops(name, a):
-    if name == "tp3d_gemm_tn_f32":  # M, N, K
+    if name in ("tp3d_gemm_tn_f32", "tp3d_gemm_rows_f32"):  # M, N, K
         M, N, K = a[:3]
         return 2 * M * N * K
     return 0
@@ -190,6 +196,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-clouds", type=int, default=8)
     ap.add_argument("--cpu-sample-iters", type=int, default=8)
+    ap.add_argument("--model", default="unet_3_ss", choices=["unet_3_ss", "unet_4_ss", "unet_3_ms"],
+                    help="PointNet++ config; the BASELINE metric is unet_3_ss, the others are side measurements")
     ap.add_argument("--no-graph", action="store_true", help="single-GPU runs replay the train step from a captured "
                     "HIP graph (same kernels, no per-launch host cost); this flag keeps eager launches")
     ap.add_argument("--force-ddp", action="store_true", help="initialise the process group even with one rank "
@@ -198,6 +206,8 @@ def main():
                     "the multi-process path on a box with fewer GPUs than ranks)")
     args = ap.parse_args()
 
+    global MODEL_CONFIG
+    MODEL_CONFIG = args.model
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -342,8 +352,8 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": "PointNet++ SSG (unet_3_ss) train step fwd+bwd+Adam, B=32 per GPU, N=16384, "
-                                   "FEAT=3, 10 classes, pos~U[-1,1]^3 (BASELINE configs[1])",
+            "config": {"workload": "PointNet++ SSG (%s) train step fwd+bwd+Adam, B=32 per GPU, N=16384, "
+                                   "FEAT=3, 10 classes, pos~U[-1,1]^3 (BASELINE configs[1])" % MODEL_CONFIG,
                        "launch": "hip-graph replay" if graphed else "eager",
                        "global_batch": world * B_PER_GPU, "points": N_POINTS,
                        "parallelism": "dp%d (whole clouds per rank, one flat gradient all-reduce over RCCL "

@@ -71,6 +71,26 @@ def bench_ball(reps):
         print("three_nn   n=%d m=%d  %8.1f us" % (N, n, t * 1e3))
 
 
+def bench_kpconv(reps):
+    """BASELINE config 4 shapes: one cloud of 65536 points, partial-dense radius search + KPConv rigid forward."""
+    from torch_points3d_amd.kpconv import KPConv_ops
+    N = 65536
+    pos = torch.rand(N, 3, device=DEV) * 2.0  # 2 m cube
+    batch = torch.zeros(N, dtype=torch.long, device=DEV)
+    for Mn, Cin, Cout, r in [(25, 64, 128, 0.06), (25, 1, 64, 0.06), (38, 128, 256, 0.08)]:
+        t = timeit(lambda: tp.ball_query(r, Mn, pos, pos, mode="partial_dense", batch_x=batch, batch_y=batch), reps)
+        nbr, _ = tp.ball_query(r, Mn, pos, pos, mode="partial_dense", batch_x=batch, batch_y=batch)
+        filled = float((nbr >= 0).float().mean())
+        print("partial_dense ball_query N=%d r=%.2f max_num=%d  %8.1f us  (slots filled %.0f%%)" % (N, r, Mn, t * 1e3, 100 * filled))
+        x = torch.randn(N, Cin, device=DEV)
+        kp = (torch.rand(15, 3, device=DEV) - 0.5) * r
+        W = torch.randn(15, Cin, Cout, device=DEV) * 0.1
+        with torch.no_grad():
+            t = timeit(lambda: KPConv_ops(pos, pos, nbr, x, kp, W, r / 2.5, "linear", "sum"), reps)
+        by = N * Mn * (8 + 4 * Cin) + N * 15 * Cin * 4
+        print("KPConv_ops   N=%d Mn=%d Cin=%d Cout=%d  %8.1f us  (stage-1 algorithmic %.0f MB)" % (N, Mn, Cin, Cout, t * 1e3, by / 1e6))
+
+
 if __name__ == "__main__":
     what = sys.argv[1] if len(sys.argv) > 1 else "all"
     reps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
@@ -79,6 +99,8 @@ if __name__ == "__main__":
         bench_gemm_tn(reps)
     if what in ("gemm_rows", "all"):
         bench_gemm_rows(reps)
+    if what in ("kpconv", "all"):
+        bench_kpconv(reps)
     if what in ("fps", "all"):
         bench_fps(reps)
     if what in ("ball", "all"):

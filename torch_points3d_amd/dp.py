@@ -4,7 +4,7 @@ gradient all-reduce per step over RCCL (SURVEY.md 8e -- the reference itself has
 Every op of the path is per cloud, so ranks never exchange activations.  All trainable parameters share one
 flat fp32 gradient buffer (their `.grad` are views into it): a step is
 
-    [zero flat, forward, loss, backward]  ->  all_reduce(flat) / world  ->  [optimizer step]
+    [forward, loss, backward, pack gradients into flat]  ->  all_reduce(flat) / world  ->  [optimizer step]
 
 The two bracketed phases are pure device work on static tensors, so each is captured once into a HIP graph and
 replayed (no per-launch host cost); the collective runs between them as a normal RCCL call on the same stream.
@@ -25,11 +25,12 @@ class ShardedStep(object):
         self.log = log or (lambda msg: None)
         params = [p for p in model.parameters() if p.requires_grad]
         dev = params[0].device
+        self.params = params
         self.flat = torch.zeros(sum(p.numel() for p in params), dtype=torch.float32, device=dev)
         off = 0
         for p in params:
             n = p.numel()
-            p.grad = self.flat[off:off + n].view_as(p)  # autograd accumulates in place into these views
+            p.grad = self.flat[off:off + n].view_as(p)  # the optimizer reads these views of the flat buffer
             off += n
         self.opt = make_optimizer(params)
         self.graph_fb = None
@@ -39,9 +40,10 @@ class ShardedStep(object):
 
     # -- phases ------------------------------------------------------------------------------------------
     def _forward_backward(self):
-        self.flat.zero_()
         loss = self.loss_fn()
-        loss.backward()
+        # fresh gradient tensors (no per-parameter "+=" kernels), packed into the flat buffer by one concatenation
+        grads = torch.autograd.grad(loss, self.params)
+        torch.cat([g.reshape(-1) for g in grads], out=self.flat)
         return loss
 
     def _reduce(self):
