@@ -7,9 +7,16 @@
 // The reference materialises (Nq, Mn, KP, 3) differences and (Nq, KP, Mn) weights in HBM; here one wave owns a
 // query: the KP x Mn influence weights live in LDS, neighbour feature rows are read as coalesced row segments
 // and KP accumulators per lane stay in registers, so HBM sees the neighbour rows once and wf once.
+#include <algorithm>
+
 #include "tp3d_common.h"
 
 namespace tp3d {
+
+__device__ __forceinline__ float rl_bcast(float x, int lane)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), lane));
+}
 
 constexpr int KP_BLOCK = 256;  // 4 waves, one query per wave
 constexpr int KP_MAX = 16;     // kernel points (15 in every reference config)
@@ -121,5 +128,169 @@ TP3D_EXPORT int tp3d_kpconv_weighted_f32(const float *query, const float *suppor
     hipLaunchKernelGGL(kpconv_weighted_kernel, dim3((unsigned)blocks), dim3(KP_BLOCK), 0, (hipStream_t)stream, query,
                        support, neighbors, features, k_points, Nq, M, Mn, Cin, KP, extent, influence, closest,
                        weighted);
+    return check_launch();
+}
+
+// =====================================================================================================
+// Backward of stage 1 with respect to the input features:
+//   d_x[m, :] = sum over slots (q, n) with nbr[q,n] == m of  sum_k h(|(s_m - q) - K_k|) * d_wf[q, k, :]
+// (reference: autograd through convolution_ops.py:92-98).  No float atomics: the neighbour table is inverted first
+// (global counting sort over the Nq*Mn slots: integer histogram -> scan -> fill -> per-point sort of its short run,
+// which makes the summation order ascending in (q, n) whatever the timing), then one wave per support point
+// recomputes the KP influence weights of each of its slots and accumulates coalesced d_wf row segments.
+namespace tp3d {
+
+__global__ void nbr_hist_kernel(const int64_t *__restrict__ nbr, int64_t slots, int64_t M, int *__restrict__ cnt)
+{
+    for (int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; s < slots; s += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t m = nbr[s];
+        if (m >= 0 && m < M) atomicAdd(&cnt[m], 1);
+    }
+}
+
+// exclusive scan of cnt[0..M) into start[0..M] (one workgroup), cursor := start
+__global__ __launch_bounds__(1024) void nbr_scan_kernel(const int *__restrict__ cnt, int64_t M, int *__restrict__ start,
+                                                         int *__restrict__ cursor)
+{
+    __shared__ int s_w[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t per = (M + 1023) / 1024;
+    const int64_t k0 = min((int64_t)tid * per, M), k1 = min(k0 + per, M);
+    int sum = 0;
+    for (int64_t k = k0; k < k1; ++k) sum += cnt[k];
+    int incl = sum;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int v = __shfl_up(incl, off);
+        if (lane >= off) incl += v;
+    }
+    if (lane == 63) s_w[wave] = incl;
+    __syncthreads();
+    if (tid == 0) {
+        int run = 0;
+        for (int w = 0; w < 16; ++w) {
+            const int v = s_w[w];
+            s_w[w] = run;
+            run += v;
+        }
+    }
+    __syncthreads();
+    int run = s_w[wave] + incl - sum;
+    for (int64_t k = k0; k < k1; ++k) {
+        const int v = cnt[k];
+        start[k] = run;
+        cursor[k] = run;
+        run += v;
+    }
+    if (k1 == M) start[M] = run;  // every thread whose range ends at M holds the grand total
+}
+
+__global__ void nbr_fill_kernel(const int64_t *__restrict__ nbr, int64_t slots, int64_t M, int *__restrict__ cursor,
+                                int *__restrict__ order)
+{
+    for (int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; s < slots; s += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t m = nbr[s];
+        if (m >= 0 && m < M) order[atomicAdd(&cursor[m], 1)] = (int)s;
+    }
+}
+
+__global__ void nbr_sort_kernel(const int *__restrict__ start, int64_t M, int *__restrict__ order)
+{
+    const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= M) return;
+    const int s0 = start[m], s1 = start[m + 1];
+    for (int a = s0 + 1; a < s1; ++a) {
+        const int v = order[a];
+        int p = a;
+        while (p > s0 && order[p - 1] > v) {
+            order[p] = order[p - 1];
+            --p;
+        }
+        order[p] = v;
+    }
+}
+
+__global__ __launch_bounds__(KP_BLOCK) void kpconv_bwd_features_kernel(
+    const float *__restrict__ query, const float *__restrict__ support, const float *__restrict__ kpts,
+    const float *__restrict__ d_wf, const int *__restrict__ start, const int *__restrict__ order, int64_t M, int Mn,
+    int Cin, int KP, float extent, int influence, int closest, float *__restrict__ d_x)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t m = (int64_t)blockIdx.x * (KP_BLOCK / 64) + (threadIdx.x >> 6);
+    if (m >= M) return;  // wave-uniform; no workgroup barrier in this kernel
+    const float sx = support[m * 3 + 0], sy = support[m * 3 + 1], sz = support[m * 3 + 2];
+    const int kl = min(lane, KP - 1);
+    const float kx = kpts[kl * 3 + 0], ky = kpts[kl * 3 + 1], kz = kpts[kl * 3 + 2];
+    const float sigma = extent * 0.3f;
+    const float gden = 2.0f * sigma * sigma + 1e-9f;
+    const int s0 = start[m], s1 = start[m + 1];
+    for (int c0 = 0; c0 < Cin; c0 += 64) {
+        const int c = min(c0 + lane, Cin - 1);
+        float acc = 0.0f;
+        for (int j = s0; j < s1; ++j) {
+            const int64_t q = order[j] / Mn;  // wave-uniform
+            // lane k < KP: influence of kernel point k for this (query, support point) pair
+            const float dx = (sx - query[q * 3 + 0]) - kx, dy = (sy - query[q * 3 + 1]) - ky,
+                        dz = (sz - query[q * 3 + 2]) - kz;
+            const float d2 = (dx * dx + dy * dy) + dz * dz;
+            float w;
+            if (influence == 0) w = 1.0f;
+            else if (influence == 1) w = fmaxf(1.0f - sqrtf(d2) / extent, 0.0f);
+            else w = expf(-d2 / gden);
+            if (closest) {
+                // first minimum of d2 over the KP kernel points keeps its weight, the others are masked
+                float best = lane < KP ? d2 : 3.0e38f;
+#pragma unroll
+                for (int off = 8; off >= 1; off >>= 1) best = fminf(best, __shfl_xor(best, off));
+                const unsigned long long eq = __ballot(lane < KP && d2 == best);
+                if (lane != __builtin_ctzll(eq | (1ull << 63))) w = 0.0f;
+            }
+            const float *row = d_wf + (size_t)q * KP * Cin + c;
+            for (int k = 0; k < KP; ++k) acc = acc + rl_bcast(w, k) * row[(size_t)k * Cin];
+        }
+        if (c0 + lane < Cin) d_x[(size_t)m * Cin + c0 + lane] = acc;
+    }
+}
+
+}  // namespace tp3d
+
+TP3D_EXPORT size_t tp3d_kpconv_bwd_workspace_bytes(int64_t M, int64_t slots)
+{
+    if (M < 0 || slots < 0) return 0;
+    auto up = [](size_t v) { return (v + 15) & ~(size_t)15; };
+    return up((size_t)M * 4) + up((size_t)(M + 1) * 4) + up((size_t)M * 4) + up((size_t)slots * 4);
+}
+
+TP3D_EXPORT int tp3d_kpconv_bwd_features_f32(const float *query, const float *support, const int64_t *neighbors,
+                                             const float *k_points, const float *d_weighted, int64_t Nq, int64_t M,
+                                             int Mn, int Cin, int KP, float extent, int influence, int closest,
+                                             float *d_features, void *workspace, size_t workspace_bytes, void *stream)
+{
+    if (Nq < 0 || M < 0 || Mn < 0 || Cin <= 0 || KP <= 0 || influence < 0 || influence > 2) return TP3D_E_BADARG;
+    if (KP > KP_MAX) return TP3D_E_TOOBIG;
+    if (M == 0) return TP3D_OK;
+    if (!d_features) return TP3D_E_BADARG;
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t slots = Nq * Mn;
+    if (slots == 0) return zero_async(d_features, (size_t)M * Cin * sizeof(float), s);
+    if (!query || !support || !neighbors || !k_points || !d_weighted || !workspace) return TP3D_E_BADARG;
+    if (slots > INT32_MAX || M > INT32_MAX / 2) return TP3D_E_TOOBIG;
+    if (workspace_bytes < tp3d_kpconv_bwd_workspace_bytes(M, slots)) return TP3D_E_BADARG;
+    auto up = [](size_t v) { return (v + 15) & ~(size_t)15; };
+    char *p = static_cast<char *>(workspace);
+    int *cnt = reinterpret_cast<int *>(p);
+    int *start = reinterpret_cast<int *>(p + up((size_t)M * 4));
+    int *cursor = reinterpret_cast<int *>(p + up((size_t)M * 4) + up((size_t)(M + 1) * 4));
+    int *order = reinterpret_cast<int *>(p + up((size_t)M * 4) + up((size_t)(M + 1) * 4) + up((size_t)M * 4));
+    if (int rc = zero_async(cnt, (size_t)M * 4, s)) return rc;
+    const unsigned gs = (unsigned)std::min<int64_t>((slots + 255) / 256, 4096);
+    hipLaunchKernelGGL(nbr_hist_kernel, dim3(gs), dim3(256), 0, s, neighbors, slots, M, cnt);
+    hipLaunchKernelGGL(nbr_scan_kernel, dim3(1), dim3(1024), 0, s, cnt, M, start, cursor);
+    hipLaunchKernelGGL(nbr_fill_kernel, dim3(gs), dim3(256), 0, s, neighbors, slots, M, cursor, order);
+    hipLaunchKernelGGL(nbr_sort_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, s, start, M, order);
+    if (int rc = check_launch()) return rc;
+    hipLaunchKernelGGL(kpconv_bwd_features_kernel, dim3((unsigned)((M + KP_BLOCK / 64 - 1) / (KP_BLOCK / 64))),
+                       dim3(KP_BLOCK), 0, s, query, support, k_points, d_weighted, start, order, M, Mn, Cin, KP, extent,
+                       influence, closest, d_features);
     return check_launch();
 }
