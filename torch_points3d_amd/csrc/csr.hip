@@ -138,12 +138,9 @@ int csr_transpose(const int64_t *idx, int B, int L, int nbins, int div, const fl
 {
     const size_t lds = csr_lds_bytes(L, nbins);
     if (L <= 65536 && lds <= (size_t)CSR_LDS_BYTES) {
-        static bool attr_set = false;  // dynamic LDS above 64 KiB must be opted into once per process
-        if (!attr_set) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&csr_transpose_kernel<uint16_t, true>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, CSR_LDS_BYTES);
-            attr_set = true;
-        }
+        static bool attr_set[64] = {false};
+        allow_large_dynamic_lds(reinterpret_cast<const void *>(&csr_transpose_kernel<uint16_t, true>), CSR_LDS_BYTES,
+                                attr_set);
         hipLaunchKernelGGL((csr_transpose_kernel<uint16_t, true>), dim3(B), dim3(CSR_BLOCK), lds, s, idx, L, nbins, div,
                            weight, start, order, wsorted, scratch_ord);
     } else {
@@ -216,12 +213,9 @@ static void launch_gather(const float *rows, const int *start, const int *order,
 {
     const size_t lds = IN_LDS ? (size_t)CC * Lrow * sizeof(float) : 0;
     if (lds > 64 * 1024) {
-        static bool attr_set = false;
-        if (!attr_set) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gather_sum_kernel<CC, WEIGHTED, IN_LDS>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, CSR_LDS_BYTES);
-            attr_set = true;
-        }
+        static bool attr_set[64] = {false};
+        allow_large_dynamic_lds(reinterpret_cast<const void *>(&gather_sum_kernel<CC, WEIGHTED, IN_LDS>), CSR_LDS_BYTES,
+                                attr_set);
     }
     dim3 grid((C + CC - 1) / CC, B);
     hipLaunchKernelGGL((gather_sum_kernel<CC, WEIGHTED, IN_LDS>), grid, dim3(GS_BLOCK), lds, s, rows, start, order,

@@ -395,12 +395,8 @@ int grid_ball_query(const float *x, const float *y, const int64_t *seg, const in
     GridWorkspace w = carve_grid_workspace(workspace, num_clouds, rows, G);
     if (workspace_bytes < w.bytes) return TP3D_E_BADARG;
     const size_t lds = (((size_t)G * G * G * 4 + 15) & ~(size_t)15) + (size_t)Lmax * 2;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&grid_build_kernel),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)GRID_LDS_BUDGET);
-        attr_set = true;
-    }
+    static bool attr_set[64] = {false};
+    allow_large_dynamic_lds(reinterpret_cast<const void *>(&grid_build_kernel), (int)GRID_LDS_BUDGET, attr_set);
     hipLaunchKernelGGL(grid_build_kernel, dim3(num_clouds), dim3(GB_BLOCK), lds, s, x, seg, N, radius, G, w.info,
                        w.cell_start, w.sorted_id, w.sorted_xyz);
     if (int rc = check_launch()) return rc;

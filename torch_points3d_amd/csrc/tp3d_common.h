@@ -24,6 +24,17 @@ inline int check_launch()
     return TP3D_OK;
 }
 
+// Kernels that need more than 64 KiB of dynamic LDS must opt in once per (function, device).
+inline void allow_large_dynamic_lds(const void *func, int bytes, bool *done_per_device /*[64]*/)
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    if (!done_per_device[dev]) {
+        (void)hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        done_per_device[dev] = true;
+    }
+}
+
 // Zero-fills a device buffer on the stream (used by the scatter-add backward entry points).
 inline int zero_async(void *ptr, size_t bytes, hipStream_t s)
 {

@@ -1,0 +1,200 @@
+"""Partial-dense KPConv blocks on top of the HIP radius search and kernel-point convolution.
+
+Mirrors torch_points3d/modules/KPConv/blocks.py:15-292 (`SimpleBlock`, `ResnetBBlock`, `KPDualBlock`) and
+`FastBatchNorm1d` (core/common_modules/base_modules.py:128-153): same constructor arguments, attribute names (hence
+state_dict keys), radius rule (2.5 * sigma * prev_grid_size, blocks.py:23,52), BatchNorm momentum 0.02,
+LeakyReLU(0.1), bottleneck unaries and the strided shortcut (max over neighbours with a zero shadow row,
+blocks.py:206-210).
+
+Two things the reference pulls from packages that are not part of this build are injected instead:
+  * the strided blocks' `GridSampling3D` (torch_cluster / torch_scatter): pass `sampler=callable`
+    (data -> query data) or feed `precomputed` query data exactly like the reference's MultiScaleTransform path
+    (blocks.py:71-82);
+  * the kernel-point disposition file: pass `kernel_points` (KP, 3) in unit scale; it is scaled by the kernel radius
+    (1.5 * point influence, kernels.py:35,51).  The reference additionally applies a random rotation at construction
+    (kernel_utils.py:251-280); a checkpoint's `K_points` overrides either choice on load.
+Parity: unpinned (the reference block file cannot be imported here: it needs torch_cluster); the convolution inside is
+pinned by tests/golden/kpconv_ops.npz.
+"""
+import copy
+
+import torch
+import torch.nn as nn
+
+from . import torchpoints as _tp
+from .kpconv import KPConvLayer
+
+
+class PDData(object):
+    """Attribute bag for partial-dense data: pos (N,3), x (N,C), batch (N,), + whatever the blocks attach."""
+
+    def __init__(self, **kw):
+        for k, v in kw.items():
+            setattr(self, k, v)
+
+    def clone(self):
+        out = PDData()
+        for k, v in self.__dict__.items():
+            setattr(out, k, v.clone() if torch.is_tensor(v) else copy.copy(v))
+        return out
+
+
+class FastBatchNorm1d(nn.Module):
+    """BatchNorm1d over (N, C) rows or (B, N, C) dense tensors; parameters live under `.batch_norm`."""
+
+    def __init__(self, num_features, momentum=0.1, **kwargs):
+        super().__init__()
+        self.batch_norm = nn.BatchNorm1d(num_features, momentum=momentum, **kwargs)
+
+    def forward(self, x):
+        if x.dim() == 2:
+            return self.batch_norm(x)
+        if x.dim() == 3:
+            return self.batch_norm(x.permute(0, 2, 1)).permute(0, 2, 1)
+        raise ValueError("Non supported number of dimensions {}".format(x.dim()))
+
+
+class RadiusNeighbourFinder(object):
+    """partial_dense radius search (reference core/spatial_ops/neighbour_finder.py:25-39): (Nq, max_num) int64, -1 padded"""
+
+    def __init__(self, radius, max_num_neighbors=64):
+        self._radius = radius
+        self._max_num_neighbors = max_num_neighbors
+
+    def __call__(self, x, y, batch_x, batch_y):
+        return _tp.ball_query(self._radius, self._max_num_neighbors, x, y, mode="partial_dense", batch_x=batch_x,
+                              batch_y=batch_y)[0]
+
+
+class SimpleBlock(nn.Module):
+    """KPConv -> BatchNorm -> LeakyReLU(0.1); strided when prev_grid_size != grid_size."""
+
+    RIGID_DENSITY = 2.5
+
+    def __init__(self, down_conv_nn=None, grid_size=None, prev_grid_size=None, sigma=1.0, max_num_neighbors=16,
+                 activation=None, bn_momentum=0.02, bn=FastBatchNorm1d, add_one=False, kernel_points=None, sampler=None,
+                 **kwargs):
+        super().__init__()
+        assert len(down_conv_nn) == 2
+        if kernel_points is None:
+            raise ValueError("kernel_points (KP, 3) in unit scale is required (see module docstring)")
+        num_inputs, num_outputs = down_conv_nn
+        influence = prev_grid_size * sigma
+        kp = torch.as_tensor(kernel_points, dtype=torch.float32) * (KPConvLayer._INFLUENCE_TO_RADIUS * influence)
+        self.kp_conv = KPConvLayer(num_inputs, num_outputs, point_influence=influence, K_points=kp, add_one=add_one,
+                                   **kwargs)
+        self.neighbour_finder = RadiusNeighbourFinder(self.RIGID_DENSITY * sigma * prev_grid_size, max_num_neighbors)
+        self.bn = bn(num_outputs, momentum=bn_momentum) if bn else None
+        self.activation = activation if activation is not None else nn.LeakyReLU(negative_slope=0.1)
+        self.is_strided = prev_grid_size != grid_size
+        self.sampler = sampler if self.is_strided else None
+
+    def forward(self, data, precomputed=None, **kwargs):
+        if not hasattr(data, "block_idx"):
+            data.block_idx = 0
+        if precomputed:
+            query_data = precomputed[data.block_idx]
+            idx_neighboors, q_pos = query_data.idx_neighboors, query_data.pos
+        else:
+            if self.is_strided:
+                if self.sampler is None:
+                    raise RuntimeError("strided block without a sampler: pass sampler= or precomputed query data "
+                                       "(GridSampling3D is not part of this build)")
+                query_data = self.sampler(data.clone())
+            else:
+                query_data = data.clone()
+            q_pos = query_data.pos
+            idx_neighboors = self.neighbour_finder(data.pos, q_pos, batch_x=data.batch, batch_y=query_data.batch)
+            query_data.idx_neighboors = idx_neighboors
+        x = self.kp_conv(q_pos, data.pos, idx_neighboors, data.x)
+        if self.bn:
+            x = self.bn(x)
+        query_data.x = self.activation(x)
+        query_data.block_idx = data.block_idx + 1
+        return query_data
+
+
+class ResnetBBlock(nn.Module):
+    """unary -> SimpleBlock -> unary, plus shortcut (neighbourhood max-pool when strided), summed."""
+
+    def __init__(self, down_conv_nn=None, grid_size=None, prev_grid_size=None, sigma=1, max_num_neighbors=16,
+                 activation=None, has_bottleneck=True, bn_momentum=0.02, bn=FastBatchNorm1d, add_one=False, **kwargs):
+        super().__init__()
+        assert len(down_conv_nn) in (2, 3), "down_conv_nn should be of size 2 or 3"
+        if len(down_conv_nn) == 2:
+            num_inputs, num_outputs = down_conv_nn
+            d_2 = num_outputs // 4
+        else:
+            num_inputs, d_2, num_outputs = down_conv_nn
+        activation = activation if activation is not None else nn.LeakyReLU(negative_slope=0.1)
+        self.is_strided = prev_grid_size != grid_size
+        self.has_bottleneck = has_bottleneck
+        kp_size = [d_2, d_2] if has_bottleneck else [num_inputs, num_outputs]
+        self.kp_conv = SimpleBlock(down_conv_nn=kp_size, grid_size=grid_size, prev_grid_size=prev_grid_size, sigma=sigma,
+                                   max_num_neighbors=max_num_neighbors, activation=activation, bn_momentum=bn_momentum,
+                                   bn=bn, add_one=add_one, **kwargs)
+        if has_bottleneck:
+            if bn:
+                self.unary_1 = nn.Sequential(nn.Linear(num_inputs, d_2, bias=False), bn(d_2, momentum=bn_momentum),
+                                             activation)
+                self.unary_2 = nn.Sequential(nn.Linear(d_2, num_outputs, bias=False),
+                                             bn(num_outputs, momentum=bn_momentum), activation)
+            else:
+                self.unary_1 = nn.Sequential(nn.Linear(num_inputs, d_2, bias=False), activation)
+                self.unary_2 = nn.Sequential(nn.Linear(d_2, num_outputs, bias=False), activation)
+        if num_inputs != num_outputs:
+            if bn:
+                self.shortcut_op = nn.Sequential(nn.Linear(num_inputs, num_outputs, bias=False),
+                                                 bn(num_outputs, momentum=bn_momentum))
+            else:
+                self.shortcut_op = nn.Linear(num_inputs, num_outputs, bias=False)
+        else:
+            self.shortcut_op = nn.Identity()
+        self.activation = activation
+
+    def forward(self, data, precomputed=None, **kwargs):
+        output = data.clone()
+        shortcut_x = data.x
+        if self.has_bottleneck:
+            output.x = self.unary_1(output.x)
+        output = self.kp_conv(output, precomputed=precomputed)
+        if self.has_bottleneck:
+            output.x = self.unary_2(output.x)
+        if self.is_strided:
+            idx = output.idx_neighboors
+            padded = torch.cat([shortcut_x, torch.zeros_like(shortcut_x[:1, :])], dim=0)  # shadow feature row
+            idx = torch.where(idx < 0, torch.full_like(idx, shortcut_x.shape[0]), idx)
+            shortcut_x = padded[idx].max(dim=1)[0]
+        output.x = output.x + self.shortcut_op(shortcut_x)
+        return output
+
+    @property
+    def sampler(self):
+        return self.kp_conv.sampler
+
+    @property
+    def neighbour_finder(self):
+        return self.kp_conv.neighbour_finder
+
+
+class KPDualBlock(nn.Module):
+    """Sequence of blocks built from per-block lists (reference blocks.py:217-292)."""
+
+    def __init__(self, block_names=None, down_conv_nn=None, grid_size=None, prev_grid_size=None, has_bottleneck=None,
+                 max_num_neighbors=None, add_one=False, **kwargs):
+        super().__init__()
+        assert len(block_names) == len(down_conv_nn)
+        classes = {"SimpleBlock": SimpleBlock, "ResnetBBlock": ResnetBBlock}
+        self.blocks = nn.ModuleList()
+        for i, name in enumerate(block_names):
+            block_kwargs = {k: (v[i] if isinstance(v, (list, tuple)) else v) for k, v in kwargs.items()}
+            extra = {} if name == "SimpleBlock" else {"has_bottleneck": has_bottleneck[i]}
+            self.blocks.append(classes[name](
+                down_conv_nn=down_conv_nn[i], grid_size=grid_size[i], prev_grid_size=prev_grid_size[i],
+                max_num_neighbors=max_num_neighbors[i],
+                add_one=add_one[i] if isinstance(add_one, (list, tuple)) else add_one, **extra, **block_kwargs))
+
+    def forward(self, data, precomputed=None, **kwargs):
+        for block in self.blocks:
+            data = block(data, precomputed=precomputed)
+        return data
