@@ -35,7 +35,7 @@ extern "C" {
 #define TP3D_E_UNSORTED (-3) /* reserved: batch vector not sorted (checked by the host wrapper) */
 #define TP3D_E_TOOBIG (-4)   /* size exceeds what the kernel's index arithmetic supports */
 
-#define TP3D_ABI_VERSION 10
+#define TP3D_ABI_VERSION 12
 
 int tp3d_abi_version(void);
 const char *tp3d_strerror(int code);
@@ -206,6 +206,56 @@ int tp3d_kpconv_bwd_features_f32(const float *query, const float *support, const
 
 /* inverse-distance weights of DenseFPModule (core/base_conv/dense.py:137-139): dist (rows,3) -> weight (rows,3) */
 int tp3d_idw_weights_f32(const float *dist, int64_t rows, float *weight, void *stream);
+
+/* GridSampling3D (reference core/data_transform/grid_transform.py:84-141; sampler of the strided KPConv blocks,
+ * modules/KPConv/blocks.py:60-61,79).  pos (N,3) f32, batch (N) int64 or NULL, voxel edge `size`:
+ *   coords = round_half_even(pos / size);  points sharing (batch, coords) form a cluster;  clusters are numbered in
+ *   ascending (batch, z, y, x) order (torch_cluster grid_cluster key + torch.unique(sorted), :117-122).
+ * Three steps, because the reference's own pipeline has two device->host waits (extent of the key, number of
+ * clusters) and this library never synchronises:
+ *   1. tp3d_voxel_bounds_f32   -> bounds[8] int32 on the DEVICE: min xyz, max xyz of coords, max batch, bad-input flag;
+ *                                 the host copies them back and passes them to step 2 as a HOST array;
+ *   2. tp3d_voxel_cluster_f32  -> cluster (N) id of each point; order (N) point indices sorted by (cluster, index);
+ *                                 cluster_start (N+1; [0..K] valid) slot range of each cluster in `order`;
+ *                                 last (N; [0..K) valid) highest point index of each cluster = the reference's
+ *                                 unique_pos_indices (consecutive_cluster's scatter_, last write wins);
+ *                                 num_clusters (1) int64 on the device = K.  workspace: tp3d_voxel_workspace_bytes(N);
+ *   3. tp3d_cluster_mean_f32   -> out (K,C) = scatter_mean(x (N,C)) summed in ascending point order (:78), and
+ *      tp3d_cluster_majority_i64 -> out (K) = majority label, ties -> lowest (:72-76); num_classes = max-min+1.
+ */
+int tp3d_voxel_bounds_f32(const float *pos, const int64_t *batch, int64_t N, float size, int32_t *bounds, void *stream);
+size_t tp3d_voxel_workspace_bytes(int64_t N);
+int tp3d_voxel_cluster_f32(const float *pos, const int64_t *batch, int64_t N, float size, const int32_t *bounds_host,
+                           int64_t *cluster, int64_t *order, int64_t *cluster_start, int64_t *last,
+                           int64_t *num_clusters, void *workspace, size_t workspace_bytes, void *stream);
+int tp3d_cluster_mean_f32(const float *x, const int64_t *order, const int64_t *cluster_start, int64_t K, int C,
+                          float *out, void *stream);
+int tp3d_cluster_majority_i64(const int64_t *labels, const int64_t *order, const int64_t *cluster_start, int64_t K,
+                              int64_t min_label, int64_t num_classes, int64_t *out, void *stream);
+
+/* Exact k nearest neighbours (reference call sites: core/spatial_ops/interpolate.py:27,69 -- KNNInterpolate /
+ * FPModule_PD, k = 1 in the KPConv decoders; core/spatial_ops/neighbour_finder.py:42-47 -- KNNNeighbourFinder, k = 16
+ * in RandLA-Net; both go through torch_cluster `knn`).
+ *   partial_dense: x (M,3) support with sorted batch ids, seg_x (num_clouds+1) row offsets of the clouds in x,
+ *                  y (Nq,3) queries with batch_y (Nq) -> idx (Nq,k) global rows of x, dist2 (Nq,k) squared distances;
+ *   dense:         x (B,N,3), y (B,np,3) -> idx (B,np,k) cloud-local, dist2 (B,np,k).
+ *   Closest first, ties by lower index; slots a cloud of fewer than k points cannot fill hold -1 / -1.0.
+ *   cell: preferred grid cell edge (e.g. the sampling grid size); <= 0 lets the library choose.
+ *   workspace: tp3d_knn_workspace_bytes(num_clouds, rows of x, largest cloud) bytes. */
+size_t tp3d_knn_workspace_bytes(int num_clouds, int64_t rows, int max_cloud_points);
+int tp3d_knn_partial_dense_f32(const float *x, const float *y, const int64_t *batch_y, const int64_t *seg_x,
+                               int num_clouds, int max_cloud_points, int64_t M, int64_t Nq, int k, float cell,
+                               int64_t *idx, float *dist2, void *workspace, size_t workspace_bytes, void *stream);
+int tp3d_knn_dense_f32(const float *x, const float *y, int B, int N, int np, int k, float cell, int64_t *idx,
+                       float *dist2, void *workspace, size_t workspace_bytes, void *stream);
+
+/* knn_interpolate + skip concatenation of FPModule_PD (core/base_conv/partial_dense.py:136-140):
+ *   w_j = 1 / max(dist2[i,j], 1e-16);  out[i, 0:C] = (sum_j x[idx[i,j], :] * w_j) / (sum_j w_j)   (slot order, -1 skipped)
+ *   out[i, C:C+C2] = skip[i, :];  columns up to ld are zero.   x (M,C), idx/dist2 (Nq,k), skip (Nq,C2) or NULL.
+ *   wnorm (Nq,k) or NULL receives w_j / sum_j w_j (0 in -1 slots): the weights of the backward scatter
+ *   (tp3d_rows_scatter_bwd_f32 with B = 1). */
+int tp3d_knn_interpolate_fwd_f32(const float *x, const int64_t *idx, const float *dist2, const float *skip, int64_t Nq,
+                                 int k, int C, int C2, int ld, float *out, float *wnorm, void *stream);
 
 #ifdef __cplusplus
 }

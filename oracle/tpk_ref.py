@@ -42,6 +42,8 @@ def lib():
         L.tpk_ref_ball_query_dense_f32.argtypes = [_c_f, _c_f, _int, _int, _int, ctypes.c_float, _int, _int, _c_l, _c_f]
         L.tpk_ref_ball_query_partial_dense_f32.argtypes = [
             _c_f, _c_f, _c_l, _c_l, _i64, _i64, ctypes.c_float, _int, _int, _c_l, _c_f]
+        L.tpk_ref_knn_partial_dense_f32.argtypes = [_c_f, _c_f, _c_l, _c_l, _i64, _i64, _int, _c_l, _c_f]
+        L.tpk_ref_knn_partial_dense_f32.restype = _int
         L.tpk_ref_three_nn_f32.argtypes = [_c_f, _c_f, _int, _int, _int, _c_f, _c_l]
         L.tpk_ref_three_interpolate_fwd_f32.argtypes = [_c_f, _c_l, _c_f, _int, _int, _int, _int, _c_f]
         L.tpk_ref_three_interpolate_bwd_f32.argtypes = [_c_f, _c_l, _c_f, _int, _int, _int, _int, _c_f]
@@ -123,6 +125,18 @@ def ball_query(radius, nsample, x, y, mode="dense", batch_x=None, batch_y=None, 
             _f(x), _f(y), B, N, np_, float(radius), nsample, int(sort), _l(idx), _f(d2)), "ball_query_dense")
         return idx, d2
     raise Exception("unrecognized mode {}".format(mode))
+
+
+def knn(k, x, y, batch_x=None, batch_y=None):
+    """k nearest support rows x (M,3) of every query y (Nq,3) inside its own cloud -> (idx (Nq,k), dist2 (Nq,k))"""
+    x, y = _prep(x), _prep(y)
+    bx = torch.zeros(x.shape[0], dtype=torch.int64) if batch_x is None else batch_x.to(torch.int64).contiguous()
+    by = torch.zeros(y.shape[0], dtype=torch.int64) if batch_y is None else batch_y.to(torch.int64).contiguous()
+    idx = torch.empty(y.shape[0], k, dtype=torch.int64)
+    d2 = torch.empty(y.shape[0], k, dtype=torch.float32)
+    _check(lib().tpk_ref_knn_partial_dense_f32(_f(x), _f(y), _l(bx), _l(by), x.shape[0], y.shape[0], int(k), _l(idx),
+                                               _f(d2)), "knn_partial_dense")
+    return idx, d2
 
 
 def three_nn(unknown, known):

@@ -223,6 +223,46 @@ TPK_API int tpk_ref_ball_query_partial_dense_f32(const float *x, const float *y,
 }
 
 /*
+ * kNN over partial-dense clouds: the k support rows of the query's own cloud with the smallest squared distance,
+ * closest first, ties by lower index; -1 / -1.0 in the slots a cloud of fewer than k points cannot fill.
+ * Call sites: core/spatial_ops/interpolate.py:27,69 (KNNInterpolate, via torch_geometric knn / knn_interpolate) and
+ * core/spatial_ops/neighbour_finder.py:42-47 (KNNNeighbourFinder).  The arithmetic lives in torch_cluster 1.5.9
+ * (absent from the container): PARITY UNPINNED; brute force with the library's distance expression.
+ */
+TPK_API int tpk_ref_knn_partial_dense_f32(const float *x, const float *y, const int64_t *batch_x, const int64_t *batch_y,
+                                          int64_t M, int64_t Nq, int k, int64_t *idx, float *dist2)
+{
+    if (M < 0 || Nq < 0 || k <= 0) return -1;
+    for (int64_t i = 1; i < M; ++i)
+        if (batch_x[i] < batch_x[i - 1]) return -2;
+#pragma omp parallel for schedule(static)
+    for (int64_t j = 0; j < Nq; ++j) {
+        int64_t bq = batch_y[j];
+        int64_t a = 0, c = M;
+        while (a < c) {
+            int64_t m = (a + c) / 2;
+            if (batch_x[m] < bq) a = m + 1; else c = m;
+        }
+        int64_t lo = a;
+        c = M;
+        while (a < c) {
+            int64_t m = (a + c) / 2;
+            if (batch_x[m] <= bq) a = m + 1; else c = m;
+        }
+        int64_t hi = a;
+        int64_t *io = idx + (size_t)j * k;
+        float *dd = dist2 + (size_t)j * k;
+        int cnt = 0;
+        for (int64_t i = lo; i < hi; ++i) sorted_insert(dd, io, &cnt, k, sqdist3(x + (size_t)i * 3, y + (size_t)j * 3), i);
+        for (int s = cnt; s < k; ++s) {
+            io[s] = -1;
+            dd[s] = -1.0f;
+        }
+    }
+    return 0;
+}
+
+/*
  * H8  three_nn(unknown, known) -> (dist, idx)
  * Call site: core/base_conv/dense.py:136; dist is consumed as a Euclidean distance
  * (1/(dist+1e-8), dense.py:137) so the sqrt of the squared distance is returned.

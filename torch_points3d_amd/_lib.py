@@ -37,12 +37,19 @@ SIGNATURES = {
     "tp3d_gemm_rows_f32": [_p, _p, _l, _i, _i, _p, _p, _p],
     "tp3d_bn_finalize_f32": [_p, _i, _l, _i, _f, _f, _p, _p, _p, _p, _p, _p, _p, _p, _p],
     "tp3d_kpconv_bwd_features_f32": [_p, _p, _p, _p, _p, _l, _l, _i, _i, _i, _f, _i, _i, _p, _p, ctypes.c_size_t, _p],
+    "tp3d_knn_partial_dense_f32": [_p, _p, _p, _p, _i, _i, _l, _l, _i, _f, _p, _p, _p, ctypes.c_size_t, _p],
+    "tp3d_knn_dense_f32": [_p, _p, _i, _i, _i, _i, _f, _p, _p, _p, ctypes.c_size_t, _p],
+    "tp3d_knn_interpolate_fwd_f32": [_p, _p, _p, _p, _l, _i, _i, _i, _i, _p, _p, _p],
+    "tp3d_voxel_bounds_f32": [_p, _p, _l, _f, _p, _p],
+    "tp3d_voxel_cluster_f32": [_p, _p, _l, _f, _p, _p, _p, _p, _p, _p, _p, ctypes.c_size_t, _p],
+    "tp3d_cluster_mean_f32": [_p, _p, _p, _l, _i, _p, _p],
+    "tp3d_cluster_majority_i64": [_p, _p, _p, _l, _l, _l, _p, _p],
     "tp3d_kpconv_weighted_f32": [_p, _p, _p, _p, _p, _l, _l, _i, _i, _i, _f, _i, _i, _p, _p],
 }
 MISC = ("tp3d_abi_version", "tp3d_strerror", "tp3d_last_hip_error", "tp3d_scatter_workspace_bytes",
         "tp3d_bn_workspace_floats", "tp3d_gemm_tn_workspace_floats", "tp3d_ball_query_workspace_bytes",
-        "tp3d_gemm_rows_stat_floats", "tp3d_kpconv_bwd_workspace_bytes")
-ABI_VERSION = 10
+        "tp3d_gemm_rows_stat_floats", "tp3d_kpconv_bwd_workspace_bytes", "tp3d_voxel_workspace_bytes", "tp3d_knn_workspace_bytes")
+ABI_VERSION = 12
 
 _handle = None
 
@@ -84,6 +91,10 @@ def load():
     h.tp3d_kpconv_bwd_workspace_bytes.argtypes = [_l, _l]
     h.tp3d_gemm_rows_stat_floats.restype = ctypes.c_size_t
     h.tp3d_gemm_rows_stat_floats.argtypes = [_l, _i]
+    h.tp3d_knn_workspace_bytes.restype = ctypes.c_size_t
+    h.tp3d_knn_workspace_bytes.argtypes = [_i, _l, _i]
+    h.tp3d_voxel_workspace_bytes.restype = ctypes.c_size_t
+    h.tp3d_voxel_workspace_bytes.argtypes = [_l]
     h.tp3d_ball_query_workspace_bytes.restype = ctypes.c_size_t
     h.tp3d_ball_query_workspace_bytes.argtypes = [_i, _l, _i]
     if h.tp3d_abi_version() != ABI_VERSION:

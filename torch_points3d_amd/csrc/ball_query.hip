@@ -9,7 +9,7 @@
 // 64-bit __ballot + mbcnt prefix turns the hit mask into output slots, so hits land in ascending index
 // order with no sort and no atomics.  A query that has its nsample hits stops testing; a workgroup whose
 // queries are all full stops streaming.
-#include "tp3d_common.h"
+#include "grid.h"
 
 namespace tp3d {
 
@@ -230,7 +230,7 @@ TP3D_EXPORT int tp3d_ball_query_dense_f32(const float *x, const float *y, int B,
     if ((int64_t)N * 3 > INT32_MAX || B > 65535) return TP3D_E_TOOBIG;
     const float r2 = radius * radius;
     hipStream_t s = (hipStream_t)stream;
-    if (workspace && N >= BQ_GRID_MIN_POINTS && grid_edge_for(N) >= 2)
+    if (workspace && N >= BQ_GRID_MIN_POINTS && grid_plan(N).G >= 2)
         return grid_ball_query(x, y, nullptr, nullptr, B, (int64_t)B * N, N, np, (int64_t)B * np, N, radius, nsample,
                                sort, idx, dist2, workspace, workspace_bytes, s);
     if (sort) {
@@ -260,7 +260,7 @@ TP3D_EXPORT int tp3d_ball_query_partial_dense_f32(const float *x, const float *y
     const float r2 = radius * radius;
     hipStream_t s = (hipStream_t)stream;
     if (workspace && seg_x && num_clouds > 0 && max_cloud_points >= BQ_GRID_MIN_POINTS &&
-        grid_edge_for(max_cloud_points) >= 2)
+        grid_plan(max_cloud_points).G >= 2)
         return grid_ball_query(x, y, seg_x, batch_y, num_clouds, M, 0, 0, Nq, max_cloud_points, radius, nsample, sort,
                                idx, dist2, workspace, workspace_bytes, s);
     if (sort) {

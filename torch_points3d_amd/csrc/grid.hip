@@ -9,7 +9,7 @@
 //
 // Build: one workgroup per cloud, all in LDS: bounding box -> cell histogram (LDS atomics) -> scan -> fill ->
 // cell-ordered ids + a cell-ordered xyz copy for coalesced tests (order inside a cell is irrelevant: hits are ranked).
-#include "tp3d_common.h"
+#include "grid.h"
 
 namespace tp3d {
 
@@ -17,20 +17,38 @@ constexpr int GB_BLOCK = 1024;
 constexpr int GQ_BLOCK = 256;     // 4 waves, one query per wave
 constexpr int GQ_CAP = 1024;      // candidate slots per query (overflow -> exact in-order scan of the cloud)
 
-struct GridInfo {  // per cloud, 8 floats
-    float minx, miny, minz, inv_cs;
-    int gx, gy, gz, pad;
-};
-
-__device__ __forceinline__ int cell_coord(float x, float mn, float inv_cs, int g)
+// Cell edge and cell counts of one cloud from its bounding box (shared by both builders).
+// cell > 0: at least 1.01 * cell (so +-1 cell covers a ball of that radius with margin for the fp32 rounding of the
+// cell coordinate); cell <= 0: sized for `target` points per cell of the box volume.  Never more than G cells per axis.
+__device__ __forceinline__ GridInfo make_grid_info(const float lo3[3], const float hi3[3], int L, float cell, float target,
+                                                   int G)
 {
-    int c = (int)floorf((x - mn) * inv_cs);
-    return min(max(c, 0), g - 1);
+    const float e0 = hi3[0] - lo3[0], e1 = hi3[1] - lo3[1], e2 = hi3[2] - lo3[2];
+    const float ext = fmaxf(fmaxf(e0, e1), e2);
+    float want = cell * 1.01f;
+    if (!(cell > 0.0f)) {
+        const float eps = ext * 1.0e-3f;
+        const float vol = fmaxf(e0, eps) * fmaxf(e1, eps) * fmaxf(e2, eps);
+        want = cbrtf(vol * target / (float)max(L, 1));
+    }
+    float cs = fmaxf(want, ext / (float)G * 1.0001f);
+    if (!(cs > 0.0f)) cs = 1.0f;
+    GridInfo gi;
+    gi.minx = lo3[0];
+    gi.miny = lo3[1];
+    gi.minz = lo3[2];
+    gi.inv_cs = 1.0f / cs;
+    gi.gx = min(G, (int)floorf(e0 * gi.inv_cs) + 1);
+    gi.gy = min(G, (int)floorf(e1 * gi.inv_cs) + 1);
+    gi.gz = min(G, (int)floorf(e2 * gi.inv_cs) + 1);
+    gi.pad = 0;
+    return gi;
 }
 
 // seg == nullptr: dense (cloud b owns rows [b*N, (b+1)*N)); else rows [seg[b], seg[b+1]).
 __global__ __launch_bounds__(GB_BLOCK) void grid_build_kernel(const float *__restrict__ x, const int64_t *__restrict__ seg,
-                                                               int N, float radius, int G, GridInfo *__restrict__ info,
+                                                               int N, float radius, float target, int G,
+                                                               GridInfo *__restrict__ info,
                                                                int *__restrict__ cell_start /*[B][G^3+1]*/,
                                                                int *__restrict__ sorted_id /*[rows]*/,
                                                                float *__restrict__ sorted_xyz /*[rows][3]*/)
@@ -82,20 +100,7 @@ __global__ __launch_bounds__(GB_BLOCK) void grid_build_kernel(const float *__res
             }
         }
         if (L == 0) lo3[0] = lo3[1] = lo3[2] = hi3[0] = hi3[1] = hi3[2] = 0.0f;
-        const float ext = fmaxf(fmaxf(hi3[0] - lo3[0], hi3[1] - lo3[1]), hi3[2] - lo3[2]);
-        // cell edge: at least 1.01 r (so +-1 cell covers the ball with margin for fp32 rounding of the cell
-        // coordinate, |coordinate| <= 32), and coarse enough that no axis needs more than G cells
-        float cs = fmaxf(radius * 1.01f, ext / (float)G * 1.0001f);
-        if (!(cs > 0.0f)) cs = 1.0f;
-        GridInfo gi;
-        gi.minx = lo3[0];
-        gi.miny = lo3[1];
-        gi.minz = lo3[2];
-        gi.inv_cs = 1.0f / cs;
-        gi.gx = min(G, (int)floorf((hi3[0] - lo3[0]) * gi.inv_cs) + 1);
-        gi.gy = min(G, (int)floorf((hi3[1] - lo3[1]) * gi.inv_cs) + 1);
-        gi.gz = min(G, (int)floorf((hi3[2] - lo3[2]) * gi.inv_cs) + 1);
-        gi.pad = 0;
+        const GridInfo gi = make_grid_info(lo3, hi3, L, radius, target, G);
         s_info = gi;
         info[b] = gi;
     }
@@ -199,9 +204,10 @@ __global__ __launch_bounds__(GQ_BLOCK) void grid_query_kernel(
 
     // unclamped cell of the query; cells outside [-1, g] cannot touch the ball
     // (clamped in float first: a far-away query must not overflow the int conversion)
-    const int cx = (int)floorf(fminf(fmaxf((qx - gi.minx) * gi.inv_cs, -4.0f), 40.0f));
-    const int cy = (int)floorf(fminf(fmaxf((qy - gi.miny) * gi.inv_cs, -4.0f), 40.0f));
-    const int cz = (int)floorf(fminf(fmaxf((qz - gi.minz) * gi.inv_cs, -4.0f), 40.0f));
+    const float far = (float)(G + 8);
+    const int cx = (int)floorf(fminf(fmaxf((qx - gi.minx) * gi.inv_cs, -4.0f), far));
+    const int cy = (int)floorf(fminf(fmaxf((qy - gi.miny) * gi.inv_cs, -4.0f), far));
+    const int cz = (int)floorf(fminf(fmaxf((qz - gi.minz) * gi.inv_cs, -4.0f), far));
     int h = 0;  // hits so far (wave-uniform)
     bool overflow = false;
     const int x0 = max(cx - 1, 0), x1 = min(cx + 1, gi.gx - 1);
@@ -347,29 +353,174 @@ __global__ __launch_bounds__(GQ_BLOCK) void grid_query_kernel(
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Sort-based build for clouds that do not fit one workgroup's LDS (any size, any number of workgroups)
+constexpr int GG_BLOCK = 256;
+constexpr int GG_ROWS = GG_BLOCK * 16;  // rows per workgroup in the per-cloud passes
+
+__device__ __forceinline__ int float_order(float f)  // order-preserving map float -> int (for atomicMin/Max)
+{
+    const int i = __float_as_int(f);
+    return i ^ ((i >> 31) & 0x7fffffff);
+}
+__device__ __forceinline__ float order_float(int i) { return __int_as_float(i ^ ((i >> 31) & 0x7fffffff)); }
+
+__global__ void gridg_init_kernel(int *__restrict__ bbox, int num_clouds)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < num_clouds * 6) bbox[t] = (t % 6) < 3 ? 0x7fffffff : (int)0x80000000;
+}
+
+// grid = (chunks, clouds)
+__global__ __launch_bounds__(GG_BLOCK) void gridg_bbox_kernel(const float *__restrict__ x, const int64_t *__restrict__ seg,
+                                                               int N, int *__restrict__ bbox)
+{
+    __shared__ float s_red[6][GG_BLOCK / 64];
+    const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t lo = seg ? seg[b] : (int64_t)b * N;
+    const int64_t L = seg ? seg[b + 1] - seg[b] : N;
+    const int64_t j0 = (int64_t)blockIdx.x * GG_ROWS;
+    if (j0 >= L) return;  // workgroup-uniform
+    const int64_t j1 = min(j0 + GG_ROWS, L);
+    float mn[3] = {3.0e38f, 3.0e38f, 3.0e38f}, mx[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+    for (int64_t j = j0 + tid; j < j1; j += GG_BLOCK)
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const float v = x[(lo + j) * 3 + a];
+            mn[a] = fminf(mn[a], v);
+            mx[a] = fmaxf(mx[a], v);
+        }
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            mn[a] = fminf(mn[a], __shfl_xor(mn[a], off));
+            mx[a] = fmaxf(mx[a], __shfl_xor(mx[a], off));
+        }
+    if (lane == 0)
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            s_red[a][wave] = mn[a];
+            s_red[3 + a][wave] = mx[a];
+        }
+    __syncthreads();
+    if (tid < 6) {
+        float r = s_red[tid][0];
+        for (int w = 1; w < GG_BLOCK / 64; ++w) r = tid < 3 ? fminf(r, s_red[tid][w]) : fmaxf(r, s_red[tid][w]);
+        if (tid < 3) atomicMin(&bbox[b * 6 + tid], float_order(r));
+        else atomicMax(&bbox[b * 6 + tid], float_order(r));
+    }
+}
+
+__global__ void gridg_info_kernel(const int *__restrict__ bbox, const int64_t *__restrict__ seg, int N, int num_clouds,
+                                  float cell, float target, int G, GridInfo *__restrict__ info)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= num_clouds) return;
+    const int L = seg ? (int)(seg[b + 1] - seg[b]) : N;
+    float lo3[3], hi3[3];
+    for (int a = 0; a < 3; ++a) {
+        lo3[a] = L ? order_float(bbox[b * 6 + a]) : 0.0f;
+        hi3[a] = L ? order_float(bbox[b * 6 + 3 + a]) : 0.0f;
+    }
+    info[b] = make_grid_info(lo3, hi3, L, cell, target, G);
+}
+
+// grid = (chunks, clouds): key = cloud * G^3 + cell, value = global row
+__global__ __launch_bounds__(GG_BLOCK) void gridg_key_kernel(const float *__restrict__ x, const int64_t *__restrict__ seg,
+                                                              int N, int G, const GridInfo *__restrict__ info,
+                                                              unsigned long long *__restrict__ keys,
+                                                              unsigned int *__restrict__ vals)
+{
+    const int b = blockIdx.y;
+    const int64_t lo = seg ? seg[b] : (int64_t)b * N;
+    const int64_t L = seg ? seg[b + 1] - seg[b] : N;
+    const int64_t j0 = (int64_t)blockIdx.x * GG_ROWS;
+    if (j0 >= L) return;
+    const int64_t j1 = min(j0 + GG_ROWS, L);
+    const GridInfo gi = info[b];
+    const unsigned long long base = (unsigned long long)b * (unsigned long long)(G * G * G);
+    for (int64_t j = j0 + threadIdx.x; j < j1; j += GG_BLOCK) {
+        const float *p = x + (lo + j) * 3;
+        const int cx = cell_coord(p[0], gi.minx, gi.inv_cs, gi.gx);
+        const int cy = cell_coord(p[1], gi.miny, gi.inv_cs, gi.gy);
+        const int cz = cell_coord(p[2], gi.minz, gi.inv_cs, gi.gz);
+        keys[lo + j] = base + (unsigned long long)((cz * gi.gy + cy) * gi.gx + cx);
+        vals[lo + j] = (unsigned int)(lo + j);
+    }
+}
+
+// Keys are cloud-major, so after the sort cloud b still owns slots [lo_b, lo_b + L_b).
+__global__ __launch_bounds__(GG_BLOCK) void gridg_fill_kernel(const float *__restrict__ x, const int64_t *__restrict__ seg,
+                                                               int N, int G, int64_t rows,
+                                                               const unsigned long long *__restrict__ keys,
+                                                               const unsigned int *__restrict__ vals,
+                                                               int *__restrict__ sorted_id, float *__restrict__ sorted_xyz)
+{
+    const int64_t t = (int64_t)blockIdx.x * GG_BLOCK + threadIdx.x;
+    if (t >= rows) return;
+    const int64_t row = vals[t];
+    const int b = (int)(keys[t] / (unsigned long long)(G * G * G));
+    const int64_t lo = seg ? seg[b] : (int64_t)b * N;
+    sorted_id[t] = (int)(row - lo);
+    sorted_xyz[t * 3 + 0] = x[row * 3 + 0];
+    sorted_xyz[t * 3 + 1] = x[row * 3 + 1];
+    sorted_xyz[t * 3 + 2] = x[row * 3 + 2];
+}
+
+// grid = (cell chunks, clouds): cell_start[b][c] = first slot (cloud-relative) whose key is >= cell c
+__global__ __launch_bounds__(GG_BLOCK) void gridg_cellstart_kernel(const int64_t *__restrict__ seg, int N, int G,
+                                                                    const GridInfo *__restrict__ info,
+                                                                    const unsigned long long *__restrict__ keys,
+                                                                    int *__restrict__ cell_start)
+{
+    const int b = blockIdx.y;
+    const GridInfo gi = info[b];
+    const int nused = gi.gx * gi.gy * gi.gz;
+    const int c = blockIdx.x * GG_BLOCK + threadIdx.x;
+    if (c > nused) return;
+    const int64_t lo = seg ? seg[b] : (int64_t)b * N;
+    const int L = seg ? (int)(seg[b + 1] - seg[b]) : N;
+    const unsigned long long want = (unsigned long long)b * (unsigned long long)(G * G * G) + (unsigned long long)c;
+    int a = 0, z = L;  // lower bound in keys[lo, lo + L)
+    while (a < z) {
+        const int m = (a + z) >> 1;
+        if (keys[lo + m] < want) a = m + 1;
+        else z = m;
+    }
+    cell_start[(size_t)b * ((size_t)G * G * G + 1) + c] = a;
+}
+
 constexpr size_t GRID_LDS_BUDGET = 144 * 1024;
 
 // largest grid edge whose histogram + u16 order array of an Lmax-point cloud fit LDS (0: cloud too large)
 int grid_edge_for(int Lmax)
 {
-    if (Lmax > 65536) return 0;
+    if (Lmax > GRID_LDS_MAX_POINTS) return 0;
     const size_t left = GRID_LDS_BUDGET - (size_t)Lmax * 2 - 64;
     int G = 32;
     while (G > 1 && ((size_t)G * G * G * 4) > left) --G;
     return G;
 }
 
-struct GridWorkspace {
-    GridInfo *info;
-    int *cell_start;
-    int *sorted_id;
-    float *sorted_xyz;
-    size_t bytes;
-};
-
-GridWorkspace carve_grid_workspace(void *ws, int num_clouds, int64_t rows, int G)
+GridPlan grid_plan(int Lmax)
 {
-    auto up = [](size_t v) { return (v + 15) & ~(size_t)15; };
+    GridPlan p;
+    p.global = Lmax > GRID_LDS_MAX_POINTS;
+    if (!p.global) {
+        p.G = grid_edge_for(Lmax);
+    } else {
+        int G = 16;  // about two points per cell of a volume-filling cloud
+        while (G < GRID_GLOBAL_MAX_EDGE && (int64_t)G * G * G * 2 < Lmax) ++G;
+        p.G = G;
+    }
+    return p;
+}
+
+GridWorkspace carve_grid_workspace(void *ws, int num_clouds, int64_t rows, GridPlan plan)
+{
+    auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    const int G = plan.G;
     GridWorkspace w;
     char *p = static_cast<char *>(ws);
     size_t off = 0;
@@ -381,8 +532,63 @@ GridWorkspace carve_grid_workspace(void *ws, int num_clouds, int64_t rows, int G
     off += up((size_t)rows * 4);
     w.sorted_xyz = reinterpret_cast<float *>(p + off);
     off += up((size_t)rows * 12);
+    w.bbox = nullptr;
+    w.keys_in = w.keys_out = nullptr;
+    w.vals_in = w.vals_out = nullptr;
+    w.sort_tmp = nullptr;
+    w.sort_tmp_bytes = 0;
+    if (plan.global) {
+        w.bbox = reinterpret_cast<int *>(p + off);
+        off += up((size_t)num_clouds * 6 * 4);
+        w.keys_in = reinterpret_cast<unsigned long long *>(p + off);
+        off += up((size_t)rows * 8);
+        w.keys_out = reinterpret_cast<unsigned long long *>(p + off);
+        off += up((size_t)rows * 8);
+        w.vals_in = reinterpret_cast<unsigned int *>(p + off);
+        off += up((size_t)rows * 4);
+        w.vals_out = reinterpret_cast<unsigned int *>(p + off);
+        off += up((size_t)rows * 4);
+        w.sort_tmp = p + off;
+        w.sort_tmp_bytes = sort_pairs_tmp_bytes(rows);
+        off += up(w.sort_tmp_bytes + 256);
+    }
     w.bytes = off;
     return w;
+}
+
+int grid_build(const float *x, const int64_t *seg, int num_clouds, int64_t rows, int N, int Lmax, float cell, float target,
+               GridPlan plan, const GridWorkspace &w, hipStream_t s)
+{
+    const int G = plan.G;
+    if (G < 2 || num_clouds <= 0) return TP3D_E_TOOBIG;
+    if (!plan.global) {
+        const size_t lds = (((size_t)G * G * G * 4 + 15) & ~(size_t)15) + (size_t)Lmax * 2;
+        static bool attr_set[64] = {false};
+        allow_large_dynamic_lds(reinterpret_cast<const void *>(&grid_build_kernel), (int)GRID_LDS_BUDGET, attr_set);
+        hipLaunchKernelGGL(grid_build_kernel, dim3(num_clouds), dim3(GB_BLOCK), lds, s, x, seg, N, cell, target, G, w.info,
+                           w.cell_start, w.sorted_id, w.sorted_xyz);
+        return check_launch();
+    }
+    if (rows >= 0x7fffffff || num_clouds > 65535) return TP3D_E_TOOBIG;
+    const unsigned chunks = (unsigned)(((int64_t)Lmax + GG_ROWS - 1) / GG_ROWS);
+    hipLaunchKernelGGL(gridg_init_kernel, dim3((num_clouds * 6 + 255) / 256), dim3(256), 0, s, w.bbox, num_clouds);
+    hipLaunchKernelGGL(gridg_bbox_kernel, dim3(chunks, num_clouds), dim3(GG_BLOCK), 0, s, x, seg, N, w.bbox);
+    hipLaunchKernelGGL(gridg_info_kernel, dim3((num_clouds + 63) / 64), dim3(64), 0, s, w.bbox, seg, N, num_clouds, cell,
+                       target, G, w.info);
+    hipLaunchKernelGGL(gridg_key_kernel, dim3(chunks, num_clouds), dim3(GG_BLOCK), 0, s, x, seg, N, G, w.info, w.keys_in,
+                       w.vals_in);
+    if (int rc = check_launch()) return rc;
+    unsigned bits = 1;
+    const unsigned long long total = (unsigned long long)num_clouds * (unsigned long long)G * G * G;
+    while (bits < 63 && (1ull << bits) < total) ++bits;
+    if (int rc = sort_pairs_u64_u32(w.sort_tmp, w.sort_tmp_bytes, w.keys_in, w.keys_out, w.vals_in, w.vals_out, rows, bits, s))
+        return rc;
+    hipLaunchKernelGGL(gridg_fill_kernel, dim3((unsigned)((rows + GG_BLOCK - 1) / GG_BLOCK)), dim3(GG_BLOCK), 0, s, x, seg,
+                       N, G, rows, w.keys_out, w.vals_out, w.sorted_id, w.sorted_xyz);
+    const unsigned cchunks = (unsigned)(((size_t)G * G * G + 1 + GG_BLOCK - 1) / GG_BLOCK);
+    hipLaunchKernelGGL(gridg_cellstart_kernel, dim3(cchunks, num_clouds), dim3(GG_BLOCK), 0, s, seg, N, G, w.info,
+                       w.keys_out, w.cell_start);
+    return check_launch();
 }
 
 // Enqueue build + query. seg/batch_y null => dense layout.
@@ -390,20 +596,15 @@ int grid_ball_query(const float *x, const float *y, const int64_t *seg, const in
                     int64_t rows, int N, int np, int64_t total_q, int Lmax, float radius, int nsample, int sort,
                     int64_t *idx, float *dist2, void *workspace, size_t workspace_bytes, hipStream_t s)
 {
-    const int G = grid_edge_for(Lmax);
-    if (G < 2) return TP3D_E_TOOBIG;
-    GridWorkspace w = carve_grid_workspace(workspace, num_clouds, rows, G);
+    const GridPlan plan = grid_plan(Lmax);
+    if (plan.G < 2) return TP3D_E_TOOBIG;
+    GridWorkspace w = carve_grid_workspace(workspace, num_clouds, rows, plan);
     if (workspace_bytes < w.bytes) return TP3D_E_BADARG;
-    const size_t lds = (((size_t)G * G * G * 4 + 15) & ~(size_t)15) + (size_t)Lmax * 2;
-    static bool attr_set[64] = {false};
-    allow_large_dynamic_lds(reinterpret_cast<const void *>(&grid_build_kernel), (int)GRID_LDS_BUDGET, attr_set);
-    hipLaunchKernelGGL(grid_build_kernel, dim3(num_clouds), dim3(GB_BLOCK), lds, s, x, seg, N, radius, G, w.info,
-                       w.cell_start, w.sorted_id, w.sorted_xyz);
-    if (int rc = check_launch()) return rc;
+    if (int rc = grid_build(x, seg, num_clouds, rows, N, Lmax, radius, 2.0f, plan, w, s)) return rc;
     const int64_t blocks = (total_q + GQ_BLOCK / 64 - 1) / (GQ_BLOCK / 64);
     if (blocks > 0x7fffffff) return TP3D_E_TOOBIG;
     hipLaunchKernelGGL(grid_query_kernel, dim3((unsigned)blocks), dim3(GQ_BLOCK), 0, s, x, y, seg, batch_y, total_q, N,
-                       np, num_clouds, radius * radius, nsample, sort, G, w.info, w.cell_start, w.sorted_id,
+                       np, num_clouds, radius * radius, nsample, sort, plan.G, w.info, w.cell_start, w.sorted_id,
                        w.sorted_xyz, idx, dist2);
     return check_launch();
 }
@@ -413,7 +614,7 @@ int grid_ball_query(const float *x, const float *y, const int64_t *seg, const in
 TP3D_EXPORT size_t tp3d_ball_query_workspace_bytes(int num_clouds, int64_t rows, int max_cloud_points)
 {
     if (num_clouds <= 0 || rows < 0 || max_cloud_points <= 0) return 0;
-    const int G = tp3d::grid_edge_for(max_cloud_points);
-    if (G < 2) return 0;
-    return tp3d::carve_grid_workspace(nullptr, num_clouds, rows, G).bytes;
+    const tp3d::GridPlan plan = tp3d::grid_plan(max_cloud_points);
+    if (plan.G < 2) return 0;
+    return tp3d::carve_grid_workspace(nullptr, num_clouds, rows, plan).bytes;
 }

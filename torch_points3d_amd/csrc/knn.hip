@@ -1,0 +1,314 @@
+// Exact k nearest neighbours over the uniform grid (grid.h): the neighbour search behind KNNInterpolate / FPModule_PD
+// (reference core/spatial_ops/interpolate.py:7-69, core/base_conv/partial_dense.py:103-146; k = 1 in the KPConv
+// decoders, applications/conf/kpconv/unet_*.yaml `up_k`) and KNNNeighbourFinder (core/spatial_ops/neighbour_finder.py:
+// 42-47; k = 16 in RandLA-Net).  The reference takes it from torch_cluster 1.5.9 `knn` (absent from the container);
+// semantics here: the k support points of the query's own cloud with the smallest fp32 squared distance
+// (dx*dx + dy*dy) + dz*dz, closest first, ties by lower index; slots beyond the cloud's size hold -1.
+//
+// One wave per query.  Ring R = 1, 2, ... : gather every support point of the (2R+1)^3 cells around the query's cell
+// (x-runs of a (z, y) row are contiguous in the cell-ordered copy), select the k smallest (distance, index) pairs,
+// and accept once the k-th distance is inside the largest ball that is certainly covered by the visited cells
+// (distance to the nearest face of the block that still has cells behind it, shrunk by 0.1 % for the fp32 rounding
+// of the cell coordinate).  Exact by construction: any point outside the block is farther than that ball.
+// k == 1 never touches LDS (running wave arg-min); k > 1 keeps up to 1024 candidates per wave in LDS and falls
+// back to a scan of the whole cloud for queries whose block holds more (far outliers, degenerate densities).
+#include "grid.h"
+
+namespace tp3d {
+
+constexpr int KQ_BLOCK = 256;  // 4 waves, one query per wave
+constexpr int KQ_CAP = 1024;
+
+__device__ __forceinline__ bool pair_less(float da, int ia, float db, int ib) { return da < db || (da == db && ia < ib); }
+
+__device__ __forceinline__ void wave_argmin(float &d, int &i)
+{
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const float od = __shfl_xor(d, off);
+        const int oi = __shfl_xor(i, off);
+        if (pair_less(od, oi, d, i)) {
+            d = od;
+            i = oi;
+        }
+    }
+}
+
+__global__ __launch_bounds__(KQ_BLOCK) void grid_knn_kernel(
+    const float *__restrict__ x, const float *__restrict__ y, const int64_t *__restrict__ seg,
+    const int64_t *__restrict__ batch_y, int64_t total_q, int N, int np, int num_clouds, int k, int G,
+    const GridInfo *__restrict__ info, const int *__restrict__ cell_start, const int *__restrict__ sorted_id,
+    const float *__restrict__ sorted_xyz, int64_t *__restrict__ idx, float *__restrict__ dist2)
+{
+    __shared__ int s_id[KQ_BLOCK / 64][KQ_CAP];
+    __shared__ float s_d[KQ_BLOCK / 64][KQ_CAP];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t q = (int64_t)blockIdx.x * (KQ_BLOCK / 64) + wave;
+    if (q >= total_q) return;  // wave-uniform; the kernel has no workgroup barrier
+    int *cid = s_id[wave];
+    float *cd = s_d[wave];
+    const bool partial = seg != nullptr;
+    const int64_t bq = partial ? batch_y[q] : q / np;
+    int64_t *io = idx + q * k;
+    float *dd = dist2 + q * k;
+    int64_t lo = 0;
+    int L = 0;
+    if (bq >= 0 && bq < num_clouds) {
+        lo = partial ? seg[bq] : bq * N;
+        L = partial ? (int)(seg[bq + 1] - seg[bq]) : N;
+    }
+    if (L == 0) {
+        for (int s = lane; s < k; s += 64) {
+            io[s] = -1;
+            dd[s] = -1.0f;
+        }
+        return;
+    }
+    const int64_t goff = partial ? lo : 0;
+    const float qx = y[q * 3 + 0], qy = y[q * 3 + 1], qz = y[q * 3 + 2];
+    const GridInfo gi = info[bq];
+    const int *cs = cell_start + (size_t)bq * ((size_t)G * G * G + 1);
+    const float cell = 1.0f / gi.inv_cs;
+    // query position in cell units (same fp32 expression as the builders), clamped far outside the grid
+    const float lim = 1.0e6f;
+    const float ux = fminf(fmaxf((qx - gi.minx) * gi.inv_cs, -lim), lim);
+    const float uy = fminf(fmaxf((qy - gi.miny) * gi.inv_cs, -lim), lim);
+    const float uz = fminf(fmaxf((qz - gi.minz) * gi.inv_cs, -lim), lim);
+    const int cx = (int)floorf(ux), cy = (int)floorf(uy), cz = (int)floorf(uz);
+    // smallest ring whose block reaches the grid at all
+    int R = max(1, max(max(max(-cx, cx - (gi.gx - 1)), max(-cy, cy - (gi.gy - 1))), max(-cz, cz - (gi.gz - 1))));
+    const int kk = min(k, L);
+
+    for (;; ++R) {
+        const int x0 = max(cx - R, 0), x1 = min(cx + R, gi.gx - 1);
+        const int y0 = max(cy - R, 0), y1 = min(cy + R, gi.gy - 1);
+        const int z0 = max(cz - R, 0), z1 = min(cz + R, gi.gz - 1);
+        const bool whole = x0 == 0 && y0 == 0 && z0 == 0 && x1 == gi.gx - 1 && y1 == gi.gy - 1 && z1 == gi.gz - 1;
+        // radius of the ball around the query that the block certainly covers (faces with cells behind them only)
+        float cover = 3.0e38f;
+        if (x0 > 0) cover = fminf(cover, ux - (float)(cx - R));
+        if (x1 < gi.gx - 1) cover = fminf(cover, (float)(cx + R + 1) - ux);
+        if (y0 > 0) cover = fminf(cover, uy - (float)(cy - R));
+        if (y1 < gi.gy - 1) cover = fminf(cover, (float)(cy + R + 1) - uy);
+        if (z0 > 0) cover = fminf(cover, uz - (float)(cz - R));
+        if (z1 < gi.gz - 1) cover = fminf(cover, (float)(cz + R + 1) - uz);
+        cover = cover * cell * 0.999f;
+        const float cover2 = cover * cover;
+
+        if (k == 1) {
+            float bd = 3.0e38f;
+            int bi = 0x7fffffff;
+            for (int zz = z0; zz <= z1; ++zz)
+                for (int yy = y0; yy <= y1; ++yy) {
+                    const int rowbase = (zz * gi.gy + yy) * gi.gx;
+                    const int j0 = cs[rowbase + x0], j1 = cs[rowbase + x1 + 1];
+                    for (int j = j0 + lane; j < j1; j += 64) {
+                        const float d = sqdist3(sorted_xyz[(lo + j) * 3 + 0], sorted_xyz[(lo + j) * 3 + 1],
+                                                sorted_xyz[(lo + j) * 3 + 2], qx, qy, qz);
+                        const int id = sorted_id[lo + j];
+                        if (pair_less(d, id, bd, bi)) {
+                            bd = d;
+                            bi = id;
+                        }
+                    }
+                }
+            wave_argmin(bd, bi);
+            const bool found = bi != 0x7fffffff;
+            if (whole || (found && bd <= cover2)) {  // `whole` always ends the search (found unless the input is NaN)
+                if (lane == 0) {
+                    io[0] = found ? goff + bi : -1;
+                    dd[0] = found ? bd : -1.0f;
+                }
+                return;
+            }
+            continue;
+        }
+
+        // ---- k > 1: gather the block's points into LDS
+        int h = 0;
+        bool overflow = false;
+        for (int zz = z0; zz <= z1 && !overflow; ++zz)
+            for (int yy = y0; yy <= y1 && !overflow; ++yy) {
+                const int rowbase = (zz * gi.gy + yy) * gi.gx;
+                const int j0 = cs[rowbase + x0], j1 = cs[rowbase + x1 + 1];
+                if (h + (j1 - j0) > KQ_CAP) {
+                    overflow = true;
+                    break;
+                }
+                for (int j = j0 + lane; j < j1; j += 64) {
+                    cd[h + (j - j0)] = sqdist3(sorted_xyz[(lo + j) * 3 + 0], sorted_xyz[(lo + j) * 3 + 1],
+                                               sorted_xyz[(lo + j) * 3 + 2], qx, qy, qz);
+                    cid[h + (j - j0)] = sorted_id[lo + j];
+                }
+                h += j1 - j0;
+            }
+        if (overflow) break;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        if (h < kk && !whole) continue;
+        // k-th smallest pair by successive selection: pass s finds the smallest pair after the previous one
+        float pd = -1.0f;
+        int pi = -1;
+        const int emit = min(kk, h);
+        bool accepted = true;
+        for (int s = 0; s < emit; ++s) {
+            float bd = 3.0e38f;
+            int bi = 0x7fffffff;
+            for (int t = lane; t < h; t += 64) {
+                const float d = cd[t];
+                const int id = cid[t];
+                if ((d > pd || (d == pd && id > pi)) && pair_less(d, id, bd, bi)) {
+                    bd = d;
+                    bi = id;
+                }
+            }
+            wave_argmin(bd, bi);
+            if (!whole && !(bd <= cover2)) {  // this rank is not certain yet: widen the block (ranks before it are)
+                accepted = false;
+                break;
+            }
+            if (lane == 0) {
+                io[s] = goff + bi;
+                dd[s] = bd;
+            }
+            pd = bd;
+            pi = bi;
+        }
+        if (!accepted) continue;
+        for (int s = emit + lane; s < k; s += 64) {
+            io[s] = -1;
+            dd[s] = -1.0f;
+        }
+        return;
+    }
+
+    // ---- fallback: more block points than LDS slots; successive selection over the whole cloud
+    float pd = -1.0f;
+    int pi = -1;
+    for (int s = 0; s < kk; ++s) {
+        float bd = 3.0e38f;
+        int bi = 0x7fffffff;
+        for (int j = lane; j < L; j += 64) {
+            const float d = sqdist3(x[(lo + j) * 3 + 0], x[(lo + j) * 3 + 1], x[(lo + j) * 3 + 2], qx, qy, qz);
+            if ((d > pd || (d == pd && j > pi)) && pair_less(d, j, bd, bi)) {
+                bd = d;
+                bi = j;
+            }
+        }
+        wave_argmin(bd, bi);
+        if (lane == 0) {
+            io[s] = goff + bi;
+            dd[s] = bd;
+        }
+        pd = bd;
+        pi = bi;
+    }
+    for (int s = kk + lane; s < k; s += 64) {
+        io[s] = -1;
+        dd[s] = -1.0f;
+    }
+}
+
+// knn_interpolate (torch_geometric 1.7.2 nn/unpool/knn_interpolate.py, called at core/spatial_ops/interpolate.py:69) fused
+// with FPModule_PD's skip concatenation (core/base_conv/partial_dense.py:139-140):
+//   w_j = 1 / max(d2_j, 1e-16);  out[i, 0:C] = (sum_j x[idx[i,j]] * w_j) / (sum_j w_j), both sums in slot order;
+//   out[i, C:C+C2] = skip[i];  columns up to ld zero.  wnorm[i,j] = w_j / sum_j w_j is kept for the backward pass.
+__global__ __launch_bounds__(256) void knn_interpolate_kernel(const float *__restrict__ x, const int64_t *__restrict__ idx,
+                                                               const float *__restrict__ dist2,
+                                                               const float *__restrict__ skip, int64_t Nq, int k, int C,
+                                                               int C2, int ld, float *__restrict__ out,
+                                                               float *__restrict__ wnorm)
+{
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= Nq * ld) return;
+    const int64_t i = t / ld;
+    const int c = (int)(t - i * ld);
+    float v = 0.0f;
+    if (c < C) {
+        float num = 0.0f, den = 0.0f;
+        for (int j = 0; j < k; ++j) {
+            const int64_t m = idx[i * k + j];
+            if (m < 0) continue;
+            const float w = 1.0f / fmaxf(dist2[i * k + j], 1.0e-16f);
+            num += x[m * C + c] * w;
+            den += w;
+        }
+        v = num / den;  // den == 0 only when the query's cloud has no support point: 0/0 = NaN, as in the reference
+        if (c == 0 && wnorm)
+            for (int j = 0; j < k; ++j) {
+                const bool real = idx[i * k + j] >= 0;
+                wnorm[i * k + j] = real ? (1.0f / fmaxf(dist2[i * k + j], 1.0e-16f)) / den : 0.0f;
+            }
+    } else if (c < C + C2) {
+        v = skip[i * C2 + (c - C)];
+    }
+    out[t] = v;
+}
+
+int grid_knn(const float *x, const float *y, const int64_t *seg, const int64_t *batch_y, int num_clouds, int64_t rows,
+             int N, int np, int64_t total_q, int Lmax, int k, float cell, int64_t *idx, float *dist2, void *workspace,
+             size_t workspace_bytes, hipStream_t s)
+{
+    const GridPlan plan = grid_plan(Lmax);
+    if (plan.G < 2) return TP3D_E_TOOBIG;
+    GridWorkspace w = carve_grid_workspace(workspace, num_clouds, rows, plan);
+    if (workspace_bytes < w.bytes) return TP3D_E_BADARG;
+    // automatic cell edge: about k/4 points per cell, so the 27-cell block usually holds the k-th neighbour
+    const float target = fmaxf(2.0f, (float)k * 0.25f);
+    if (int rc = grid_build(x, seg, num_clouds, rows, N, Lmax, cell, target, plan, w, s)) return rc;
+    const int64_t blocks = (total_q + KQ_BLOCK / 64 - 1) / (KQ_BLOCK / 64);
+    if (blocks > 0x7fffffff) return TP3D_E_TOOBIG;
+    hipLaunchKernelGGL(grid_knn_kernel, dim3((unsigned)blocks), dim3(KQ_BLOCK), 0, s, x, y, seg, batch_y, total_q, N, np,
+                       num_clouds, k, plan.G, w.info, w.cell_start, w.sorted_id, w.sorted_xyz, idx, dist2);
+    return check_launch();
+}
+
+}  // namespace tp3d
+
+using namespace tp3d;
+
+TP3D_EXPORT size_t tp3d_knn_workspace_bytes(int num_clouds, int64_t rows, int max_cloud_points)
+{
+    if (num_clouds <= 0 || rows < 0 || max_cloud_points <= 0) return 0;
+    const GridPlan plan = grid_plan(max_cloud_points);
+    if (plan.G < 2) return 0;
+    return carve_grid_workspace(nullptr, num_clouds, rows, plan).bytes;
+}
+
+TP3D_EXPORT int tp3d_knn_partial_dense_f32(const float *x, const float *y, const int64_t *batch_y, const int64_t *seg_x,
+                                           int num_clouds, int max_cloud_points, int64_t M, int64_t Nq, int k, float cell,
+                                           int64_t *idx, float *dist2, void *workspace, size_t workspace_bytes,
+                                           void *stream)
+{
+    if (M < 0 || Nq < 0 || k <= 0 || num_clouds <= 0 || max_cloud_points < 0) return TP3D_E_BADARG;
+    if (Nq == 0) return TP3D_OK;
+    if (!y || !batch_y || !seg_x || !idx || !dist2 || !workspace) return TP3D_E_BADARG;
+    if (M > 0 && !x) return TP3D_E_BADARG;
+    if (max_cloud_points == 0) max_cloud_points = 1;  // every cloud empty: the kernel only writes the -1 padding
+    return grid_knn(x, y, seg_x, batch_y, num_clouds, M, 0, 0, Nq, max_cloud_points, k, cell, idx, dist2, workspace,
+                    workspace_bytes, (hipStream_t)stream);
+}
+
+TP3D_EXPORT int tp3d_knn_dense_f32(const float *x, const float *y, int B, int N, int np, int k, float cell, int64_t *idx,
+                                   float *dist2, void *workspace, size_t workspace_bytes, void *stream)
+{
+    if (B < 0 || N <= 0 || np < 0 || k <= 0) return TP3D_E_BADARG;
+    if (B == 0 || np == 0) return TP3D_OK;
+    if (!x || !y || !idx || !dist2 || !workspace) return TP3D_E_BADARG;
+    return grid_knn(x, y, nullptr, nullptr, B, (int64_t)B * N, N, np, (int64_t)B * np, N, k, cell, idx, dist2, workspace,
+                    workspace_bytes, (hipStream_t)stream);
+}
+
+TP3D_EXPORT int tp3d_knn_interpolate_fwd_f32(const float *x, const int64_t *idx, const float *dist2, const float *skip,
+                                             int64_t Nq, int k, int C, int C2, int ld, float *out, float *wnorm,
+                                             void *stream)
+{
+    if (Nq < 0 || k <= 0 || C <= 0 || C2 < 0 || ld < C + C2) return TP3D_E_BADARG;
+    if (Nq == 0) return TP3D_OK;
+    if (!x || !idx || !dist2 || !out || (C2 > 0 && !skip)) return TP3D_E_BADARG;
+    const int64_t blocks = (Nq * ld + 255) / 256;
+    if (blocks > 0x7fffffff) return TP3D_E_TOOBIG;
+    hipLaunchKernelGGL(knn_interpolate_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, idx, dist2,
+                       skip, Nq, k, C, C2, ld, out, wnorm);
+    return check_launch();
+}

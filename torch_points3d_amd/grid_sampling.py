@@ -1,0 +1,188 @@
+"""GridSampling3D on the device: the sampler of every strided KPConv block.
+
+Mirrors torch_points3d/core/data_transform/grid_transform.py:33-141 (`group_data`, `GridSampling3D`): same constructor
+arguments, same `mode` semantics ("mean": positions/features averaged per voxel, integer label keys by majority vote,
+`batch` taken from the voxel's representative point; "last": one point per voxel after a random shuffle), same
+`coords` / `grid_size` attributes on the output.  The reference builds this from torch_cluster.grid_cluster,
+torch_geometric.voxel_grid / consecutive_cluster and torch_scatter (none importable here); this module calls the
+voxel-clustering entry points of libtp3d_hip.so instead (include/tp3d_hip.h, csrc/voxel.hip).
+
+Works on any attribute bag (`PDData`, the reference's torch_geometric `Data`): every tensor attribute whose first
+dimension equals the number of points is grouped, the rest is carried over.
+Parity: unpinned against torch_cluster (absent); pinned against oracle/voxel_ref.py (a numpy restatement of the
+published algorithm) and the reference's own test properties (test/test_grid_sampling.py:29-67).
+"""
+import re
+
+import numpy as np
+import torch
+
+from . import _lib
+
+_INTEGER_LABEL_KEYS = ["y", "instance_labels"]  # grid_transform.py:20
+_ORIGIN_ID_KEY = "origin_id"  # SaveOriginalPosId.KEY (core/data_transform/transforms.py)
+
+
+def _check(pos, batch):
+    if not pos.is_cuda:
+        raise RuntimeError("voxel clustering runs on the GPU only (no CPU fallback in this build)")
+    if pos.dim() != 2 or pos.shape[1] != 3:
+        raise ValueError("pos must be (N, 3)")
+    if batch is not None and (batch.dim() != 1 or batch.shape[0] != pos.shape[0]):
+        raise ValueError("batch must be (N,)")
+
+
+def voxel_cluster(pos, batch, size):
+    """-> (cluster (N,), unique_pos_indices (K,), order (N,), cluster_start (K+1,)); all int64 on pos.device.
+
+    cluster[i]: consecutive id of the voxel of point i (ids ascend with (batch, z, y, x) of the voxel);
+    unique_pos_indices[c]: highest point index inside voxel c; order / cluster_start: members of voxel c are
+    order[cluster_start[c]:cluster_start[c+1]], ascending.
+    """
+    _check(pos, batch)
+    dev = pos.device
+    N = pos.shape[0]
+    empty = torch.empty(0, dtype=torch.int64, device=dev)
+    if N == 0:
+        return empty, empty, empty, torch.zeros(1, dtype=torch.int64, device=dev)
+    pos = pos.detach().contiguous().float()
+    if batch is not None:
+        batch = batch.contiguous().long()
+    with _lib.on_device(dev):
+        s = _lib.stream_ptr(dev)
+        bounds = torch.empty(8, dtype=torch.int32, device=dev)
+        _lib.call("tp3d_voxel_bounds_f32", _lib.ptr(pos), _lib.ptr(batch), N, float(size), _lib.ptr(bounds), s)
+        bounds_host = np.ascontiguousarray(bounds.cpu().numpy())  # wait 1: extent of the voxel key
+        nbytes = _lib.load().tp3d_voxel_workspace_bytes(N)
+        ws = _lib.workspace("voxel", nbytes, dev)
+        cluster = torch.empty(N, dtype=torch.int64, device=dev)
+        order = torch.empty(N, dtype=torch.int64, device=dev)
+        start = torch.empty(N + 1, dtype=torch.int64, device=dev)
+        last = torch.empty(N, dtype=torch.int64, device=dev)
+        count = torch.empty(1, dtype=torch.int64, device=dev)
+        _lib.call("tp3d_voxel_cluster_f32", _lib.ptr(pos), _lib.ptr(batch), N, float(size),
+                  bounds_host.ctypes.data, _lib.ptr(cluster), _lib.ptr(order), _lib.ptr(start), _lib.ptr(last),
+                  _lib.ptr(count), _lib.ptr(ws), nbytes, s)
+        K = int(count.item())  # wait 2: number of occupied voxels
+    return cluster, last[:K], order, start[:K + 1]
+
+
+def cluster_mean(x, order, cluster_start):
+    """scatter_mean of x (N, ...) over the clusters, members summed in ascending point order -> (K, ...) fp32."""
+    K = cluster_start.shape[0] - 1
+    flat = x.detach().reshape(x.shape[0], -1).contiguous().float()
+    C = flat.shape[1]
+    out = torch.empty((K, C), dtype=torch.float32, device=x.device)
+    if K > 0 and C > 0:
+        with _lib.on_device(x.device):
+            _lib.call("tp3d_cluster_mean_f32", _lib.ptr(flat), _lib.ptr(order), _lib.ptr(cluster_start), K, C,
+                      _lib.ptr(out), _lib.stream_ptr(x.device))
+    return out.reshape((K,) + tuple(x.shape[1:]))
+
+
+def cluster_majority(labels, order, cluster_start):
+    """Most frequent label per cluster, ties -> the lowest label (one-hot scatter_add + argmax in the reference)."""
+    K = cluster_start.shape[0] - 1
+    lab = labels.contiguous().long()
+    out = torch.empty(K, dtype=torch.int64, device=labels.device)
+    if K > 0:
+        lo, hi = int(lab.min().item()), int(lab.max().item())
+        with _lib.on_device(labels.device):
+            _lib.call("tp3d_cluster_majority_i64", _lib.ptr(lab), _lib.ptr(order), _lib.ptr(cluster_start), K, lo,
+                      hi - lo + 1, _lib.ptr(out), _lib.stream_ptr(labels.device))
+    return out.to(labels.dtype)
+
+
+def _items(data):
+    keys = data.keys if hasattr(data, "keys") and not callable(data.keys) else list(vars(data).keys())
+    for key in list(keys):
+        item = getattr(data, key, None)
+        if item is not None:
+            yield key, item
+
+
+def _num_nodes(data):
+    n = getattr(data, "num_nodes", None)
+    return int(n) if n is not None else int(data.pos.shape[0])
+
+
+def group_data(data, cluster=None, unique_pos_indices=None, mode="last", skip_keys=(), order=None, cluster_start=None):
+    """In-place grouping of every per-point tensor of `data` (reference grid_transform.py:33-81)."""
+    assert mode in ["mean", "last"]
+    if mode == "mean" and cluster is None:
+        raise ValueError("In mean mode the cluster argument needs to be specified")
+    if mode == "last" and unique_pos_indices is None:
+        raise ValueError("In last mode the unique_pos_indices argument needs to be specified")
+    num_nodes = _num_nodes(data)
+    if mode == "mean" and (order is None or cluster_start is None):
+        # a cluster vector from elsewhere: rebuild the member lists (stable, so members stay in point order)
+        order = torch.sort(cluster, stable=True)[1]
+        counts = torch.bincount(cluster, minlength=int(cluster.max().item()) + 1 if cluster.numel() else 0)
+        cluster_start = torch.cat([counts.new_zeros(1), torch.cumsum(counts, 0)])
+    for key, item in _items(data):
+        if bool(re.search("edge", key)):
+            raise ValueError("Edges not supported. Wrong data type.")
+        if key in skip_keys:
+            continue
+        if torch.is_tensor(item) and item.dim() > 0 and item.size(0) == num_nodes:
+            if mode == "last" or key == "batch" or key == _ORIGIN_ID_KEY:
+                setattr(data, key, item[unique_pos_indices])
+            else:
+                is_item_bool = item.dtype == torch.bool
+                if is_item_bool:
+                    item = item.int()
+                if key in _INTEGER_LABEL_KEYS:
+                    out = cluster_majority(item, order, cluster_start)
+                elif item.is_floating_point():
+                    out = cluster_mean(item, order, cluster_start).to(item.dtype)
+                else:  # scatter_mean of an integer tensor: floor division of the sums
+                    sums = torch.zeros((cluster_start.shape[0] - 1,) + tuple(item.shape[1:]), dtype=item.dtype,
+                                       device=item.device).index_add_(0, cluster, item)
+                    cnt = (cluster_start[1:] - cluster_start[:-1]).to(item.dtype)
+                    out = torch.div(sums, cnt.reshape((-1,) + (1,) * (item.dim() - 1)), rounding_mode="floor")
+                setattr(data, key, out.bool() if is_item_bool else out)
+    if hasattr(data, "num_nodes") and getattr(data, "num_nodes") is not None and "num_nodes" in vars(data):
+        data.num_nodes = int(unique_pos_indices.shape[0])
+    return data
+
+
+def shuffle_data(data):
+    num_points = data.pos.shape[0]
+    shuffle_idx = torch.randperm(num_points).to(data.pos.device)
+    for key, item in _items(data):
+        if torch.is_tensor(item) and item.dim() > 0 and num_points == item.shape[0]:
+            setattr(data, key, item[shuffle_idx])
+    return data
+
+
+class GridSampling3D(object):
+    """Clusters points into voxels of edge `size` (reference grid_transform.py:84-141)."""
+
+    def __init__(self, size, quantize_coords=False, mode="mean", verbose=False):
+        self._grid_size = size
+        self._quantize_coords = quantize_coords
+        self._mode = mode
+
+    def _process(self, data):
+        if self._mode == "last":
+            data = shuffle_data(data)
+        batch = getattr(data, "batch", None)
+        cluster, unique_pos_indices, order, cluster_start = voxel_cluster(data.pos, batch, self._grid_size)
+        if self._quantize_coords:
+            # tensor / tensor is a true fp32 division on the device (tensor / python-scalar multiplies by 1/size)
+            size_t = torch.full((), float(self._grid_size), dtype=torch.float32, device=data.pos.device)
+            coords = torch.round(data.pos[unique_pos_indices].float() / size_t)
+        data = group_data(data, cluster, unique_pos_indices, mode=self._mode, order=order, cluster_start=cluster_start)
+        if self._quantize_coords:
+            data.coords = coords.int()
+        data.grid_size = torch.tensor([self._grid_size])
+        return data
+
+    def __call__(self, data):
+        if isinstance(data, list):
+            return [self._process(d) for d in data]
+        return self._process(data)
+
+    def __repr__(self):
+        return "{}(grid_size={}, quantize_coords={}, mode={})".format(self.__class__.__name__, self._grid_size,
+                                                                      self._quantize_coords, self._mode)

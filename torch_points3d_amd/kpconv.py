@@ -75,6 +75,29 @@ def KPConv_ops(query_points, support_points, neighbors_indices, features, K_poin
                          int(aggregation_mode == "closest"))
 
 
+def default_kernel_points(num_points=15, iterations=400):
+    """A kernel-point disposition in unit scale: one point at the centre, the others spread over the unit sphere by
+    electrostatic repulsion from a Fibonacci lattice (deterministic).
+
+    The reference loads a pre-optimised disposition from a data file (modules/KPConv/kernels/dispositions/*.ply via
+    kernel_utils.load_kernels, kernels.py:51-56) and applies a random rotation; the file is not shipped with this
+    build.  Any well-spread disposition is a valid initialisation, and a reference checkpoint's `K_points` replaces
+    it on load_state_dict."""
+    import numpy as np
+    n = num_points - 1
+    i = np.arange(n) + 0.5
+    phi = np.arccos(1.0 - 2.0 * i / n)
+    theta = np.pi * (1.0 + 5.0 ** 0.5) * i
+    p = np.stack([np.cos(theta) * np.sin(phi), np.sin(theta) * np.sin(phi), np.cos(phi)], axis=1)
+    for _ in range(iterations):
+        d = p[:, None, :] - p[None, :, :]
+        r2 = (d * d).sum(-1) + np.eye(n)
+        f = (d / r2[..., None] ** 1.5).sum(1)
+        p = p + 0.05 * f
+        p /= np.linalg.norm(p, axis=1, keepdims=True)
+    return torch.from_numpy(np.concatenate([np.zeros((1, 3)), p], axis=0).astype(np.float32))
+
+
 class KPConvLayer(nn.Module):
     """Kernel-point convolution layer with the reference's parameters (`K_points` frozen, `weight` (KP, Cin, Cout)
     xavier-normal) and forward signature (modules/KPConv/kernels.py:20-104).  The kernel-point disposition file of the

@@ -6,13 +6,12 @@ state_dict keys), radius rule (2.5 * sigma * prev_grid_size, blocks.py:23,52), B
 LeakyReLU(0.1), bottleneck unaries and the strided shortcut (max over neighbours with a zero shadow row,
 blocks.py:206-210).
 
-Two things the reference pulls from packages that are not part of this build are injected instead:
-  * the strided blocks' `GridSampling3D` (torch_cluster / torch_scatter): pass `sampler=callable`
-    (data -> query data) or feed `precomputed` query data exactly like the reference's MultiScaleTransform path
-    (blocks.py:71-82);
-  * the kernel-point disposition file: pass `kernel_points` (KP, 3) in unit scale; it is scaled by the kernel radius
-    (1.5 * point influence, kernels.py:35,51).  The reference additionally applies a random rotation at construction
-    (kernel_utils.py:251-280); a checkpoint's `K_points` overrides either choice on load.
+The strided blocks sample with the device GridSampling3D (torch_points3d_amd/grid_sampling.py; the reference's
+needs torch_cluster / torch_scatter) unless `sampler=callable` (data -> query data) is given or `precomputed` query
+data is fed exactly like the reference's MultiScaleTransform path (blocks.py:71-82).  The kernel-point disposition
+file of the reference is not shipped: `kernel_points` (KP, 3, unit scale; scaled by the kernel radius = 1.5 * point
+influence, kernels.py:35,51) defaults to kpconv.default_kernel_points(); the reference additionally applies a random
+rotation at construction (kernel_utils.py:251-280); a checkpoint's `K_points` overrides either choice on load.
 Parity: unpinned (the reference block file cannot be imported here: it needs torch_cluster); the convolution inside is
 pinned by tests/golden/kpconv_ops.npz.
 """
@@ -22,7 +21,8 @@ import torch
 import torch.nn as nn
 
 from . import torchpoints as _tp
-from .kpconv import KPConvLayer
+from .grid_sampling import GridSampling3D
+from .kpconv import KPConvLayer, default_kernel_points
 
 
 class PDData(object):
@@ -31,6 +31,14 @@ class PDData(object):
     def __init__(self, **kw):
         for k, v in kw.items():
             setattr(self, k, v)
+
+    def shallow_copy(self):
+        """New bag over the same tensors (for modules that only replace attributes)."""
+        return PDData(**self.__dict__)
+
+    @property
+    def keys(self):
+        return [k for k, v in self.__dict__.items() if v is not None]
 
     def clone(self):
         out = PDData()
@@ -77,7 +85,7 @@ class SimpleBlock(nn.Module):
         super().__init__()
         assert len(down_conv_nn) == 2
         if kernel_points is None:
-            raise ValueError("kernel_points (KP, 3) in unit scale is required (see module docstring)")
+            kernel_points = default_kernel_points(kwargs.get("n_kernel_points", 15))
         num_inputs, num_outputs = down_conv_nn
         influence = prev_grid_size * sigma
         kp = torch.as_tensor(kernel_points, dtype=torch.float32) * (KPConvLayer._INFLUENCE_TO_RADIUS * influence)
@@ -87,7 +95,7 @@ class SimpleBlock(nn.Module):
         self.bn = bn(num_outputs, momentum=bn_momentum) if bn else None
         self.activation = activation if activation is not None else nn.LeakyReLU(negative_slope=0.1)
         self.is_strided = prev_grid_size != grid_size
-        self.sampler = sampler if self.is_strided else None
+        self.sampler = (sampler if sampler is not None else GridSampling3D(grid_size)) if self.is_strided else None
 
     def forward(self, data, precomputed=None, **kwargs):
         if not hasattr(data, "block_idx"):
@@ -97,9 +105,6 @@ class SimpleBlock(nn.Module):
             idx_neighboors, q_pos = query_data.idx_neighboors, query_data.pos
         else:
             if self.is_strided:
-                if self.sampler is None:
-                    raise RuntimeError("strided block without a sampler: pass sampler= or precomputed query data "
-                                       "(GridSampling3D is not part of this build)")
                 query_data = self.sampler(data.clone())
             else:
                 query_data = data.clone()

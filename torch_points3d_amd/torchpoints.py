@@ -11,6 +11,8 @@ Mirrors the names, positional order, return values and error behaviour the refer
 Tensors must live on a ROCm device: there is deliberately no CPU or eager-PyTorch fallback, a CPU
 tensor (or a missing libtp3d_hip.so) raises.
 """
+import weakref
+
 import torch
 
 from . import _lib
@@ -81,21 +83,18 @@ def ball_query(radius, nsample, x, y, mode="dense", batch_x=None, batch_y=None, 
         bx, by = _i64(batch_x), _i64(batch_y)
         if bx.numel() != x.shape[0] or by.numel() != y.shape[0]:
             raise ValueError("batch vectors must have one entry per point")
-        if bx.numel() > 1 and bool((bx[1:] < bx[:-1]).any()):
-            raise ValueError("batch_x must be sorted")
+        _segments(bx)  # also checks that batch_x is sorted
         Nq = y.shape[0]
         idx = torch.empty((Nq, nsample), dtype=torch.int64, device=dev)
         d2 = torch.empty((Nq, nsample), dtype=torch.float32, device=dev)
         seg, ws, ws_bytes, nclouds, nmax = None, None, 0, 0, 0
         if x.shape[0] >= _lib.GRID_MIN_POINTS:
-            # cloud sizes decide between the uniform grid and the segment scan (one host read, like the reference's
-            # own batch bookkeeping); seg = row offsets of the clouds in x
-            counts = torch.bincount(bx)
-            nclouds, nmax = counts.numel(), int(counts.max())
+            # cloud sizes decide between the uniform grid and the segment scan (one host read per batch vector, like
+            # the reference's own batch bookkeeping); seg = row offsets of the clouds in x
+            seg_all, nclouds, nmax = _segments(bx)
             ws, ws_bytes = _lib.ball_query_workspace(nclouds, x.shape[0], nmax, dev)
             if ws is not None:
-                seg = torch.zeros(nclouds + 1, dtype=torch.int64, device=dev)
-                seg[1:] = torch.cumsum(counts, 0)
+                seg = seg_all
         with _lib.on_device(dev):
             _lib.call("tp3d_ball_query_partial_dense_f32", _lib.ptr(x), _lib.ptr(y), _lib.ptr(bx), _lib.ptr(by),
                       x.shape[0], Nq, float(radius), int(nsample), int(bool(sort)), _lib.ptr(idx), _lib.ptr(d2),
@@ -118,6 +117,85 @@ def ball_query(radius, nsample, x, y, mode="dense", batch_x=None, batch_y=None, 
                       int(bool(sort)), _lib.ptr(idx), _lib.ptr(d2), _lib.ptr(ws), ws_bytes, _lib.stream_ptr(dev))
         return idx, d2
     raise Exception("unrecognized mode {}".format(mode))
+
+
+_seg_cache = {}
+
+
+def _segments(bx):
+    """(seg (clouds+1,) row offsets on the device, number of clouds, largest cloud) of a sorted batch vector.
+
+    The same `batch` tensor is searched by every block of a resolution level, so the result (which needs one host
+    read) is remembered per tensor (address, length, version counter)."""
+    key = (bx.data_ptr(), bx.numel(), bx._version, bx.device.index)
+    hit = _seg_cache.get(key)
+    if hit is not None and hit[0]() is bx:  # the very same tensor object, not a new one at a recycled address
+        return hit[1]
+    if bx.numel() == 0:
+        out = (torch.zeros(1, dtype=torch.int64, device=bx.device), 0, 0)
+    else:
+        counts = torch.bincount(bx)
+        seg = torch.zeros(counts.numel() + 1, dtype=torch.int64, device=bx.device)
+        seg[1:] = torch.cumsum(counts, 0)
+        unsorted = (bx[1:] < bx[:-1]).any() if bx.numel() > 1 else torch.zeros((), dtype=torch.bool, device=bx.device)
+        stats = torch.stack([counts.max(), unsorted.long()]).cpu()  # the one host read
+        if int(stats[1]):
+            raise ValueError("batch_x must be sorted")
+        out = (seg, counts.numel(), int(stats[0]))
+    if len(_seg_cache) > 64:
+        _seg_cache.clear()
+    _seg_cache[key] = (weakref.ref(bx), out)
+    return out
+
+
+def knn(k, x, y, batch_x=None, batch_y=None, cell=0.0):
+    """The k nearest support points of every query, inside the query's own cloud.
+
+    partial_dense (x (M,3), y (Nq,3), sorted batch vectors; None = one cloud) -> idx (Nq,k) global rows, dist2 (Nq,k);
+    dense (x (B,N,3), y (B,np,3)) -> idx (B,np,k) cloud-local, dist2 (B,np,k).
+    Closest first, ties by lower index; -1 / -1.0 where the cloud has fewer than k points.  `cell` is an optional
+    hint for the search grid's cell edge (e.g. the grid-sampling size of the support)."""
+    k = int(k)
+    if k <= 0:
+        raise ValueError("k must be positive")
+    if x.dim() == 3:
+        if batch_x is not None or batch_y is not None:
+            raise Exception("batch_x and batch_y should not be provided")
+        dev = _dev(x, y)
+        x, y = _f32(x), _f32(y)
+        B, N, _ = x.shape
+        np_ = y.shape[1]
+        idx = torch.empty((B, np_, k), dtype=torch.int64, device=dev)
+        d2 = torch.empty((B, np_, k), dtype=torch.float32, device=dev)
+        nbytes = _lib.load().tp3d_knn_workspace_bytes(B, B * N, N)
+        ws = _lib.workspace("grid", nbytes, dev)
+        with _lib.on_device(dev):
+            _lib.call("tp3d_knn_dense_f32", _lib.ptr(x), _lib.ptr(y), B, N, np_, k, float(cell), _lib.ptr(idx),
+                      _lib.ptr(d2), _lib.ptr(ws), nbytes, _lib.stream_ptr(dev))
+        return idx, d2
+    if x.dim() != 2 or y.dim() != 2:
+        raise ValueError("knn expects x (M,3), y (Nq,3) or x (B,N,3), y (B,np,3)")
+    dev = _dev(x, y)
+    x, y = _f32(x), _f32(y)
+    bx = torch.zeros(x.shape[0], dtype=torch.int64, device=dev) if batch_x is None else _i64(batch_x)
+    by = torch.zeros(y.shape[0], dtype=torch.int64, device=dev) if batch_y is None else _i64(batch_y)
+    if bx.numel() != x.shape[0] or by.numel() != y.shape[0]:
+        raise ValueError("batch vectors must have one entry per point")
+    Nq = y.shape[0]
+    idx = torch.empty((Nq, k), dtype=torch.int64, device=dev)
+    d2 = torch.empty((Nq, k), dtype=torch.float32, device=dev)
+    if Nq == 0:
+        return idx, d2
+    seg, nclouds, nmax = _segments(bx)
+    if nclouds == 0:
+        return idx.fill_(-1), d2.fill_(-1.0)
+    nbytes = _lib.load().tp3d_knn_workspace_bytes(nclouds, x.shape[0], max(nmax, 1))
+    ws = _lib.workspace("grid", nbytes, dev)
+    with _lib.on_device(dev):
+        _lib.call("tp3d_knn_partial_dense_f32", _lib.ptr(x), _lib.ptr(y), _lib.ptr(by), _lib.ptr(seg), nclouds, nmax,
+                  x.shape[0], Nq, k, float(cell), _lib.ptr(idx), _lib.ptr(d2), _lib.ptr(ws), nbytes,
+                  _lib.stream_ptr(dev))
+    return idx, d2
 
 
 def three_nn(unknown, known):
