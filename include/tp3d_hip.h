@@ -35,7 +35,7 @@ extern "C" {
 #define TP3D_E_UNSORTED (-3) /* reserved: batch vector not sorted (checked by the host wrapper) */
 #define TP3D_E_TOOBIG (-4)   /* size exceeds what the kernel's index arithmetic supports */
 
-#define TP3D_ABI_VERSION 12
+#define TP3D_ABI_VERSION 13
 
 int tp3d_abi_version(void);
 const char *tp3d_strerror(int code);
@@ -219,15 +219,17 @@ int tp3d_idw_weights_f32(const float *dist, int64_t rows, float *weight, void *s
  *                                 cluster_start (N+1; [0..K] valid) slot range of each cluster in `order`;
  *                                 last (N; [0..K) valid) highest point index of each cluster = the reference's
  *                                 unique_pos_indices (consecutive_cluster's scatter_, last write wins);
- *                                 num_clusters (1) int64 on the device = K.  workspace: tp3d_voxel_workspace_bytes(N);
+ *                                 meta (1 + clouds) int64 on the device, clouds = bounds[6] + 1 (1 without batch):
+ *                                 meta[0] = K, meta[1 + b] = clusters of cloud b (the row counts of the sampled
+ *                                 batch vector).  workspace: tp3d_voxel_workspace_bytes(N);
  *   3. tp3d_cluster_mean_f32   -> out (K,C) = scatter_mean(x (N,C)) summed in ascending point order (:78), and
  *      tp3d_cluster_majority_i64 -> out (K) = majority label, ties -> lowest (:72-76); num_classes = max-min+1.
  */
 int tp3d_voxel_bounds_f32(const float *pos, const int64_t *batch, int64_t N, float size, int32_t *bounds, void *stream);
 size_t tp3d_voxel_workspace_bytes(int64_t N);
 int tp3d_voxel_cluster_f32(const float *pos, const int64_t *batch, int64_t N, float size, const int32_t *bounds_host,
-                           int64_t *cluster, int64_t *order, int64_t *cluster_start, int64_t *last,
-                           int64_t *num_clusters, void *workspace, size_t workspace_bytes, void *stream);
+                           int64_t *cluster, int64_t *order, int64_t *cluster_start, int64_t *last, int64_t *meta,
+                           void *workspace, size_t workspace_bytes, void *stream);
 int tp3d_cluster_mean_f32(const float *x, const int64_t *order, const int64_t *cluster_start, int64_t K, int C,
                           float *out, void *stream);
 int tp3d_cluster_majority_i64(const int64_t *labels, const int64_t *order, const int64_t *cluster_start, int64_t K,
@@ -256,6 +258,17 @@ int tp3d_knn_dense_f32(const float *x, const float *y, int B, int N, int np, int
  *   (tp3d_rows_scatter_bwd_f32 with B = 1). */
 int tp3d_knn_interpolate_fwd_f32(const float *x, const int64_t *idx, const float *dist2, const float *skip, int64_t Nq,
                                  int k, int C, int C2, int ld, float *out, float *wnorm, void *stream);
+
+/* Strided shortcut of the KPConv ResnetBBlock (modules/KPConv/blocks.py:206-210):
+ *   out[q, c] = max over n of x[neighbors[q,n], c], a shadow neighbour (-1 or >= M) contributing 0.0
+ * x (M,C), neighbors (Nq,Mn) -> out (Nq,C); argmax (Nq,C) int32 or NULL = winning slot n (first maximum).
+ * Backward: d_x (M,C) overwritten, atomic-free (inverse neighbour table); workspace:
+ * tp3d_kpconv_bwd_workspace_bytes(M, Nq*Mn). */
+int tp3d_nbr_maxpool_fwd_f32(const float *x, const int64_t *neighbors, int64_t Nq, int64_t M, int Mn, int C, float *out,
+                             int32_t *argmax, void *stream);
+int tp3d_nbr_maxpool_bwd_f32(const float *grad_out, const int32_t *argmax, const int64_t *neighbors, int64_t Nq,
+                             int64_t M, int Mn, int C, float *d_x, void *workspace, size_t workspace_bytes,
+                             void *stream);
 
 #ifdef __cplusplus
 }

@@ -229,6 +229,13 @@ def test_gemm_rows_matches_fp64_and_stats(M, N, K):
     p = part[: chunks * 2 * N * 4].view(torch.float32).view(chunks, 2, N)
     torch.testing.assert_close(p[:, 0].double().sum(0), ref.sum(0), rtol=1e-4, atol=1e-3 * float(ref.abs().max()))
     torch.testing.assert_close(p[:, 1].double().sum(0), (ref * ref).sum(0), rtol=1e-4, atol=1e-2)
+    # the statistics rows end exactly at chunks*2*N floats: a guard band behind them must stay untouched
+    from torch_points3d_amd import _lib
+    guard = torch.full((chunks * 2 * N + 8 * 2 * N,), 7.0, device=DEV)
+    C2 = torch.empty_like(C)
+    _lib.call("tp3d_gemm_rows_f32", A.data_ptr(), Bm.t().contiguous().data_ptr(), M, N, K, C2.data_ptr(), guard.data_ptr(),
+              _lib.stream_ptr(A.device))
+    assert torch.equal(C2, C) and bool((guard[chunks * 2 * N:] == 7.0).all())
     # exact integer data: any operand / accumulator layout mix-up shows up as a wrong integer
     Ai = torch.randint(-3, 4, (M, K), generator=g).float().to(DEV)
     Bi = torch.randint(-3, 4, (K, N), generator=g).float().to(DEV)

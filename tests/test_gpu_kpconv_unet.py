@@ -132,3 +132,61 @@ def test_unet_state_dict_layout_and_eval_mode():
         a = model(PDData(pos=pos.to(DEV), batch=batch.to(DEV), x=x.to(DEV))).x
         b = model(PDData(pos=pos.to(DEV), batch=batch.to(DEV), x=x.to(DEV))).x
     assert torch.equal(a, b)  # run-to-run reproducible (no atomics anywhere on the path)
+
+
+def set_fused(model, flag):
+    for m in model.modules():
+        if hasattr(m, "fused"):
+            m.fused = flag
+
+
+@pytest.mark.parametrize("train", [True, False])
+def test_fused_blocks_match_plain_modules(train):
+    """The fused row kernels (Linear/BatchNorm/LeakyReLU, BatchNorm after KPConv, neighbour max-pool shortcut) against
+    the same model run through its plain nn.Modules on the same device."""
+    from torch_points3d_amd.kpconv_blocks import PDData
+    from torch_points3d_amd.kpconv_unet import KPConv
+    torch.manual_seed(3)
+    model = KPConv("unet", input_nc=3, in_feat=16, in_grid_size=0.02, num_layers=4, output_nc=6).to(DEV)
+    model.train(train)
+    pos, batch, x = make_input(15000, 2, 9, 3)
+    outs, grads, stats = [], [], []
+    state = copy.deepcopy(model.state_dict())
+    for flag in (True, False):
+        model.load_state_dict(state)
+        set_fused(model, flag)
+        xin = x.to(DEV).requires_grad_(True)
+        out = model(PDData(pos=pos.to(DEV), batch=batch.to(DEV), x=xin))
+        (out.x * torch.linspace(-1, 1, 6, device=DEV)).sum().backward()
+        outs.append(out.x.detach())
+        grads.append([p.grad.clone() for p in model.parameters() if p.grad is not None] + [xin.grad.clone()])
+        stats.append(model.state_dict()["down_modules.2.blocks.0.unary_1.1.batch_norm.running_var"].clone())
+        model.zero_grad()
+    scale = float(outs[1].abs().max())
+    torch.testing.assert_close(outs[0], outs[1], rtol=1e-4, atol=1e-4 * scale)
+    torch.testing.assert_close(stats[0], stats[1], rtol=1e-5, atol=1e-7)
+    gscale = max(float(g.norm()) for g in grads[1])
+    for a, b in zip(grads[0], grads[1]):
+        err = float((a - b).norm() / (b.norm() + 1e-4 * gscale))
+        assert err < (5e-2 if train else 1e-3), err
+
+
+@pytest.mark.parametrize("Nq,M,Mn,C", [(3000, 5000, 25, 64), (100, 50, 7, 3), (4000, 4000, 30, 130)])
+def test_nbr_maxpool_matches_torch(Nq, M, Mn, C):
+    from torch_points3d_amd.fused import nbr_maxpool
+    g = torch.Generator().manual_seed(Nq)
+    x = torch.randn(M, C, generator=g)
+    x[: M // 4] = -x[: M // 4].abs()  # rows that lose against the zero shadow row
+    nbr = torch.randint(-1, M, (Nq, Mn), generator=g)
+    nbr[: Nq // 10] = -1
+    gout = torch.randn(Nq, C, generator=g)
+    xr = x.clone().requires_grad_(True)
+    padded = torch.cat([xr, torch.zeros_like(xr[:1])], 0)
+    ref = padded[torch.where(nbr < 0, torch.full_like(nbr, M), nbr)].max(dim=1)[0]
+    ref.backward(gout)
+    xd = x.to(DEV).requires_grad_(True)
+    out = nbr_maxpool(xd, nbr.to(DEV))
+    out.backward(gout.to(DEV))
+    assert torch.equal(out.detach().cpu(), ref.detach())
+    # the winner of a tie may differ from torch's; distinct random values make ties (other than shadow-vs-shadow) rare
+    torch.testing.assert_close(xd.grad.cpu(), xr.grad, rtol=1e-5, atol=1e-5)

@@ -40,6 +40,8 @@ SIGNATURES = {
     "tp3d_knn_partial_dense_f32": [_p, _p, _p, _p, _i, _i, _l, _l, _i, _f, _p, _p, _p, ctypes.c_size_t, _p],
     "tp3d_knn_dense_f32": [_p, _p, _i, _i, _i, _i, _f, _p, _p, _p, ctypes.c_size_t, _p],
     "tp3d_knn_interpolate_fwd_f32": [_p, _p, _p, _p, _l, _i, _i, _i, _i, _p, _p, _p],
+    "tp3d_nbr_maxpool_fwd_f32": [_p, _p, _l, _l, _i, _i, _p, _p, _p],
+    "tp3d_nbr_maxpool_bwd_f32": [_p, _p, _p, _l, _l, _i, _i, _p, _p, ctypes.c_size_t, _p],
     "tp3d_voxel_bounds_f32": [_p, _p, _l, _f, _p, _p],
     "tp3d_voxel_cluster_f32": [_p, _p, _l, _f, _p, _p, _p, _p, _p, _p, _p, ctypes.c_size_t, _p],
     "tp3d_cluster_mean_f32": [_p, _p, _p, _l, _i, _p, _p],
@@ -49,7 +51,7 @@ SIGNATURES = {
 MISC = ("tp3d_abi_version", "tp3d_strerror", "tp3d_last_hip_error", "tp3d_scatter_workspace_bytes",
         "tp3d_bn_workspace_floats", "tp3d_gemm_tn_workspace_floats", "tp3d_ball_query_workspace_bytes",
         "tp3d_gemm_rows_stat_floats", "tp3d_kpconv_bwd_workspace_bytes", "tp3d_voxel_workspace_bytes", "tp3d_knn_workspace_bytes")
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 _handle = None
 

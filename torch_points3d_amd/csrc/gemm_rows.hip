@@ -149,7 +149,7 @@ __global__ __launch_bounds__(GR_BLOCK_T) void gemm_rows_kernel(const float *__re
                 }
             }
             __syncthreads();
-            if (tid < GR_BN && n0 + tid < N) {
+            if (tid < GR_BN && n0 + tid < N && m0 < M) {  // padding items (row block past M) own no statistics row
                 partial[((size_t)rb * 2 + 0) * N + n0 + tid] = s_st[0][0][tid] + s_st[0][1][tid];
                 partial[((size_t)rb * 2 + 1) * N + n0 + tid] = s_st[1][0][tid] + s_st[1][1][tid];
             }

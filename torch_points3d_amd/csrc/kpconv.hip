@@ -210,6 +210,74 @@ __global__ void nbr_sort_kernel(const int *__restrict__ start, int64_t M, int *_
     }
 }
 
+// Inverse of a neighbour table: for every support point m the slots (q*Mn + n) that reference it, ascending.
+// workspace: tp3d_kpconv_bwd_workspace_bytes(M, slots)
+static int invert_neighbors(const int64_t *neighbors, int64_t slots, int64_t M, void *workspace, int **start_out,
+                            int **order_out, hipStream_t s)
+{
+    auto up = [](size_t v) { return (v + 15) & ~(size_t)15; };
+    char *p = static_cast<char *>(workspace);
+    int *cnt = reinterpret_cast<int *>(p);
+    int *start = reinterpret_cast<int *>(p + up((size_t)M * 4));
+    int *cursor = reinterpret_cast<int *>(p + up((size_t)M * 4) + up((size_t)(M + 1) * 4));
+    int *order = reinterpret_cast<int *>(p + up((size_t)M * 4) + up((size_t)(M + 1) * 4) + up((size_t)M * 4));
+    if (int rc = zero_async(cnt, (size_t)M * 4, s)) return rc;
+    const unsigned gs = (unsigned)std::min<int64_t>((slots + 255) / 256, 4096);
+    hipLaunchKernelGGL(nbr_hist_kernel, dim3(gs), dim3(256), 0, s, neighbors, slots, M, cnt);
+    hipLaunchKernelGGL(nbr_scan_kernel, dim3(1), dim3(1024), 0, s, cnt, M, start, cursor);
+    hipLaunchKernelGGL(nbr_fill_kernel, dim3(gs), dim3(256), 0, s, neighbors, slots, M, cursor, order);
+    hipLaunchKernelGGL(nbr_sort_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, s, start, M, order);
+    *start_out = start;
+    *order_out = order;
+    return check_launch();
+}
+
+// Strided shortcut of ResnetBBlock (reference modules/KPConv/blocks.py:206-210): max over each query's neighbours of
+// the support features, a shadow neighbour (-1 or >= M) contributing the zero row.  arg = winning slot (first max).
+__global__ __launch_bounds__(256) void nbr_maxpool_kernel(const float *__restrict__ x, const int64_t *__restrict__ nbr,
+                                                           int64_t Nq, int64_t M, int Mn, int C, float *__restrict__ out,
+                                                           int *__restrict__ arg)
+{
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= Nq * C) return;
+    const int64_t q = t / C;
+    const int c = (int)(t - q * C);
+    float best = -3.4028235e38f;
+    int barg = 0;
+    for (int n = 0; n < Mn; ++n) {
+        const int64_t m = nbr[q * Mn + n];
+        const float v = (m >= 0 && m < M) ? x[m * C + c] : 0.0f;
+        if (v > best) {
+            best = v;
+            barg = n;
+        }
+    }
+    out[t] = best;
+    if (arg) arg[t] = barg;
+}
+
+// d_x[m, c] = sum over the slots (q, n) referencing m (ascending) with arg[q, c] == n of g[q, c]; one wave per point
+__global__ __launch_bounds__(KP_BLOCK) void nbr_maxpool_bwd_kernel(const float *__restrict__ g, const int *__restrict__ arg,
+                                                                    const int *__restrict__ start,
+                                                                    const int *__restrict__ order, int64_t M, int Mn,
+                                                                    int C, float *__restrict__ d_x)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t m = (int64_t)blockIdx.x * (KP_BLOCK / 64) + (threadIdx.x >> 6);
+    if (m >= M) return;
+    const int s0 = start[m], s1 = start[m + 1];
+    for (int c = lane; c < C; c += 64) {
+        float acc = 0.0f;
+        for (int j = s0; j < s1; ++j) {
+            const int slot = order[j];
+            const int64_t q = slot / Mn;
+            const int n = slot - (int)q * Mn;
+            if (arg[q * C + c] == n) acc += g[q * C + c];
+        }
+        d_x[m * C + c] = acc;
+    }
+}
+
 __global__ __launch_bounds__(KP_BLOCK) void kpconv_bwd_features_kernel(
     const float *__restrict__ query, const float *__restrict__ support, const float *__restrict__ kpts,
     const float *__restrict__ d_wf, const int *__restrict__ start, const int *__restrict__ order, int64_t M, int Mn,
@@ -276,21 +344,43 @@ TP3D_EXPORT int tp3d_kpconv_bwd_features_f32(const float *query, const float *su
     if (!query || !support || !neighbors || !k_points || !d_weighted || !workspace) return TP3D_E_BADARG;
     if (slots > INT32_MAX || M > INT32_MAX / 2) return TP3D_E_TOOBIG;
     if (workspace_bytes < tp3d_kpconv_bwd_workspace_bytes(M, slots)) return TP3D_E_BADARG;
-    auto up = [](size_t v) { return (v + 15) & ~(size_t)15; };
-    char *p = static_cast<char *>(workspace);
-    int *cnt = reinterpret_cast<int *>(p);
-    int *start = reinterpret_cast<int *>(p + up((size_t)M * 4));
-    int *cursor = reinterpret_cast<int *>(p + up((size_t)M * 4) + up((size_t)(M + 1) * 4));
-    int *order = reinterpret_cast<int *>(p + up((size_t)M * 4) + up((size_t)(M + 1) * 4) + up((size_t)M * 4));
-    if (int rc = zero_async(cnt, (size_t)M * 4, s)) return rc;
-    const unsigned gs = (unsigned)std::min<int64_t>((slots + 255) / 256, 4096);
-    hipLaunchKernelGGL(nbr_hist_kernel, dim3(gs), dim3(256), 0, s, neighbors, slots, M, cnt);
-    hipLaunchKernelGGL(nbr_scan_kernel, dim3(1), dim3(1024), 0, s, cnt, M, start, cursor);
-    hipLaunchKernelGGL(nbr_fill_kernel, dim3(gs), dim3(256), 0, s, neighbors, slots, M, cursor, order);
-    hipLaunchKernelGGL(nbr_sort_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, s, start, M, order);
-    if (int rc = check_launch()) return rc;
+    int *start = nullptr, *order = nullptr;
+    if (int rc = invert_neighbors(neighbors, slots, M, workspace, &start, &order, s)) return rc;
     hipLaunchKernelGGL(kpconv_bwd_features_kernel, dim3((unsigned)((M + KP_BLOCK / 64 - 1) / (KP_BLOCK / 64))),
                        dim3(KP_BLOCK), 0, s, query, support, k_points, d_weighted, start, order, M, Mn, Cin, KP, extent,
                        influence, closest, d_features);
     return check_launch();
+}
+
+TP3D_EXPORT int tp3d_nbr_maxpool_fwd_f32(const float *x, const int64_t *neighbors, int64_t Nq, int64_t M, int Mn, int C,
+                                         float *out, int32_t *argmax, void *stream)
+{
+    if (Nq < 0 || M < 0 || Mn <= 0 || C <= 0) return TP3D_E_BADARG;
+    if (Nq == 0) return TP3D_OK;
+    if (!neighbors || !out || (M > 0 && !x)) return TP3D_E_BADARG;
+    const int64_t blocks = (Nq * C + 255) / 256;
+    if (blocks > 0x7fffffff) return TP3D_E_TOOBIG;
+    hipLaunchKernelGGL(tp3d::nbr_maxpool_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, neighbors, Nq,
+                       M, Mn, C, out, argmax);
+    return tp3d::check_launch();
+}
+
+TP3D_EXPORT int tp3d_nbr_maxpool_bwd_f32(const float *grad_out, const int32_t *argmax, const int64_t *neighbors, int64_t Nq,
+                                         int64_t M, int Mn, int C, float *d_x, void *workspace, size_t workspace_bytes,
+                                         void *stream)
+{
+    if (Nq < 0 || M < 0 || Mn <= 0 || C <= 0) return TP3D_E_BADARG;
+    if (M == 0) return TP3D_OK;
+    if (!d_x) return TP3D_E_BADARG;
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t slots = Nq * Mn;
+    if (slots == 0) return tp3d::zero_async(d_x, (size_t)M * C * sizeof(float), s);
+    if (!grad_out || !argmax || !neighbors || !workspace) return TP3D_E_BADARG;
+    if (slots > INT32_MAX || M > INT32_MAX / 2) return TP3D_E_TOOBIG;
+    if (workspace_bytes < tp3d_kpconv_bwd_workspace_bytes(M, slots)) return TP3D_E_BADARG;
+    int *start = nullptr, *order = nullptr;
+    if (int rc = tp3d::invert_neighbors(neighbors, slots, M, workspace, &start, &order, s)) return rc;
+    hipLaunchKernelGGL(tp3d::nbr_maxpool_bwd_kernel, dim3((unsigned)((M + tp3d::KP_BLOCK / 64 - 1) / (tp3d::KP_BLOCK / 64))),
+                       dim3(tp3d::KP_BLOCK), 0, s, grad_out, argmax, start, order, M, Mn, C, d_x);
+    return tp3d::check_launch();
 }

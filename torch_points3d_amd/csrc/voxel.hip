@@ -114,7 +114,9 @@ __global__ __launch_bounds__(VX_BLOCK) void voxel_scatter_kernel(const unsigned 
                                                                   const int *__restrict__ cid, int64_t N,
                                                                   int64_t *__restrict__ cluster, int64_t *__restrict__ order,
                                                                   int64_t *__restrict__ cluster_start,
-                                                                  int64_t *__restrict__ last, int64_t *__restrict__ count)
+                                                                  int64_t *__restrict__ last,
+                                                                  const int64_t *__restrict__ batch,
+                                                                  unsigned long long *__restrict__ meta)
 {
     const int64_t i = (int64_t)blockIdx.x * VX_BLOCK + threadIdx.x;
     if (i >= N) return;
@@ -123,10 +125,13 @@ __global__ __launch_bounds__(VX_BLOCK) void voxel_scatter_kernel(const unsigned 
     cluster[p] = c;
     order[i] = p;
     if (i == 0 || cid[i - 1] != c) cluster_start[c] = i;
-    if (i == N - 1 || cid[i + 1] != c) last[c] = p;  // highest point index of the voxel (stable sort)
+    if (i == N - 1 || cid[i + 1] != c) {
+        last[c] = p;  // highest point index of the voxel (stable sort)
+        atomicAdd(&meta[1 + (batch ? batch[p] : 0)], 1ull);  // occupied voxels per cloud (integer: order-free)
+    }
     if (i == N - 1) {
         cluster_start[c + 1] = N;
-        *count = (int64_t)c + 1;
+        meta[0] = (unsigned long long)c + 1;
     }
 }
 
@@ -292,11 +297,11 @@ TP3D_EXPORT size_t tp3d_voxel_workspace_bytes(int64_t N)
 
 TP3D_EXPORT int tp3d_voxel_cluster_f32(const float *pos, const int64_t *batch, int64_t N, float size,
                                        const int32_t *bounds_host, int64_t *cluster, int64_t *order,
-                                       int64_t *cluster_start, int64_t *last, int64_t *num_clusters, void *workspace,
+                                       int64_t *cluster_start, int64_t *last, int64_t *meta, void *workspace,
                                        size_t workspace_bytes, void *stream)
 {
     if (N <= 0 || N >= 0x7fffffff || !(size > 0.0f) || !pos || !bounds_host || !cluster || !order || !cluster_start ||
-        !last || !num_clusters || !workspace)
+        !last || !meta || !workspace)
         return TP3D_E_BADARG;
     if (bounds_host[7] != 0) return TP3D_E_TOOBIG;  // a coordinate beyond +-2^24 voxels or a batch id out of range
     const int64_t ex = (int64_t)bounds_host[3] - bounds_host[0] + 1;
@@ -323,8 +328,9 @@ TP3D_EXPORT int tp3d_voxel_cluster_f32(const float *pos, const int64_t *batch, i
     size_t tb = w.tmp_bytes;
     if (int rc = hip_rc(rocprim::inclusive_scan(w.tmp, tb, (const int *)w.flags, w.cid, (size_t)N, rocprim::plus<int>(), s)))
         return rc;
+    if (int rc = zero_async(meta, (size_t)(1 + nb) * sizeof(int64_t), s)) return rc;
     hipLaunchKernelGGL(voxel_scatter_kernel, dim3(blocks), dim3(VX_BLOCK), 0, s, w.vals_out, w.cid, N, cluster, order,
-                       cluster_start, last, num_clusters);
+                       cluster_start, last, batch, reinterpret_cast<unsigned long long *>(meta));
     return check_launch();
 }
 

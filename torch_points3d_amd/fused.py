@@ -173,8 +173,132 @@ class _LinearBNAct(torch.autograd.Function):
         return dA, dW, dgb[1], dgb[0], None, None, None
 
 
+
+class _BNAct(torch.autograd.Function):
+    """out = LeakyReLU(BatchNorm(Y)) on rows (M, C): the BatchNorm + activation that follows a KPConv (SimpleBlock,
+    modules/KPConv/blocks.py:86-89) or any other row-major producer."""
+
+    @staticmethod
+    def forward(ctx, Y, gamma, beta, bn, slope):
+        dev = Y.device
+        Y = Y.contiguous()
+        M, C = Y.shape
+        training = bn.training
+        stats = torch.empty((4, C), dtype=torch.float32, device=dev)  # mean, invstd, scale, shift
+        out = torch.empty((M, C), dtype=torch.float32, device=dev)
+        st = _lib.stream_ptr(dev)
+        with _lib.on_device(dev):
+            ws = _lib.bn_workspace(M, C, dev)
+            _lib.call("tp3d_bn_stats_f32", _lib.ptr(Y), M, C, float(bn.eps), float(bn.momentum), _lib.ptr(gamma),
+                      _lib.ptr(beta), _lib.ptr(bn.running_mean), _lib.ptr(bn.running_var), int(training),
+                      _lib.ptr(stats[0]), _lib.ptr(stats[1]), _lib.ptr(stats[2]), _lib.ptr(stats[3]), _lib.ptr(ws), st)
+            _lib.call("tp3d_bn_act_f32", _lib.ptr(Y), _lib.ptr(stats[2]), _lib.ptr(stats[3]), slope, M, C, _lib.ptr(out), st)
+        if training:
+            bn.num_batches_tracked.add_(1)
+        ctx.save_for_backward(Y, stats)
+        ctx.cfg = (slope, training)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        Y, stats = ctx.saved_tensors
+        slope, training = ctx.cfg
+        dev = grad_out.device
+        grad_out = grad_out.contiguous()
+        M, C = Y.shape
+        dY = torch.empty_like(Y)
+        dgb = torch.empty((2, C), dtype=torch.float32, device=dev)  # dbeta, dgamma
+        ws = _lib.bn_workspace(M, C, dev)
+        with _lib.on_device(dev):
+            _lib.call("tp3d_bn_act_bwd_f32", _lib.ptr(grad_out), None, _lib.ptr(Y), _lib.ptr(stats[2]), _lib.ptr(stats[3]),
+                      _lib.ptr(stats[0]), _lib.ptr(stats[1]), slope, M, 1, C, int(training), _lib.ptr(dgb[0]),
+                      _lib.ptr(dgb[1]), _lib.ptr(dY), _lib.ptr(ws), _lib.stream_ptr(dev))
+        return dY, dgb[1], dgb[0], None, None
+
+
+def bn_act(Y, bn, slope):
+    return _BNAct.apply(Y, bn.weight, bn.bias, bn, slope)
+
+
+class _NbrMaxPool(torch.autograd.Function):
+    """max over each query's neighbours of the support rows, shadow neighbours contributing zeros."""
+
+    @staticmethod
+    def forward(ctx, x, nbr):
+        dev = x.device
+        xf = x.contiguous()
+        Nq, Mn = nbr.shape
+        M, C = xf.shape
+        out = torch.empty((Nq, C), dtype=torch.float32, device=dev)
+        need = ctx.needs_input_grad[0]
+        arg = torch.empty((Nq, C), dtype=torch.int32, device=dev) if need else None
+        with _lib.on_device(dev):
+            _lib.call("tp3d_nbr_maxpool_fwd_f32", _lib.ptr(xf), _lib.ptr(nbr), Nq, M, Mn, C, _lib.ptr(out), _lib.ptr(arg),
+                      _lib.stream_ptr(dev))
+        ctx.save_for_backward(nbr, arg)
+        ctx.cfg = (M, C)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        nbr, arg = ctx.saved_tensors
+        M, C = ctx.cfg
+        dev = g.device
+        g = g.contiguous()
+        Nq, Mn = nbr.shape
+        dx = torch.empty((M, C), dtype=torch.float32, device=dev)
+        nbytes = _lib.load().tp3d_kpconv_bwd_workspace_bytes(M, Nq * Mn)
+        ws = _lib.workspace("kpconv_bwd", nbytes, dev)
+        with _lib.on_device(dev):
+            _lib.call("tp3d_nbr_maxpool_bwd_f32", _lib.ptr(g), _lib.ptr(arg), _lib.ptr(nbr), Nq, M, Mn, C, _lib.ptr(dx),
+                      _lib.ptr(ws), nbytes, _lib.stream_ptr(dev))
+        return dx, None
+
+
+def nbr_maxpool(x, nbr):
+    return _NbrMaxPool.apply(x.float(), nbr)
+
+
 def linear_bn_act(A, conv, bn, slope, pool_ns=0):
     return _LinearBNAct.apply(A, conv.weight, bn.weight, bn.bias, bn, slope, pool_ns)
+
+
+
+def _bn1d_of(m):
+    """nn.BatchNorm1d inside a FastBatchNorm1d-style wrapper (attribute `batch_norm`) or the module itself."""
+    inner = getattr(m, "batch_norm", m)
+    if isinstance(inner, nn.BatchNorm1d) and inner.affine and inner.track_running_stats and inner.momentum is not None:
+        return inner
+    return None
+
+
+def seq_parts(seq):
+    """(linear, bn1d, slope) of nn.Sequential(Linear(bias=False), BatchNorm[, activation]) or None."""
+    mods = list(seq.children()) if isinstance(seq, nn.Sequential) else []
+    if len(mods) not in (2, 3) or not isinstance(mods[0], nn.Linear) or mods[0].bias is not None:
+        return None
+    bn = _bn1d_of(mods[1])
+    slope = _slope_of(mods[2] if len(mods) == 3 else None)
+    if bn is None or slope is None:
+        return None
+    return mods[0], bn, slope
+
+
+def rows_seq(seq, x):
+    """Linear -> BatchNorm1d -> activation on rows (N, C) through the fused kernels when the block has that shape and
+    the rows live on the GPU; otherwise the module itself."""
+    parts = seq_parts(seq) if x.is_cuda else None
+    if parts is None:
+        return seq(x)
+    lin, bn, slope = parts
+    return linear_bn_act(x.float(), lin, bn, slope)
+
+
+def rows_mlp(mlp, x):
+    """A partial-dense MLP: nn.Sequential of [Linear, BatchNorm, activation] blocks."""
+    for block in mlp.children():
+        x = rows_seq(block, x)
+    return x
 
 
 def run_mlp(rows, parts, pool_ns=0):

@@ -32,8 +32,9 @@ def _check(pos, batch):
         raise ValueError("batch must be (N,)")
 
 
-def voxel_cluster(pos, batch, size):
+def voxel_cluster(pos, batch, size, return_counts=False):
     """-> (cluster (N,), unique_pos_indices (K,), order (N,), cluster_start (K+1,)); all int64 on pos.device.
+    With return_counts=True also the number of clusters of every cloud (host int64 tensor).
 
     cluster[i]: consecutive id of the voxel of point i (ids ascend with (batch, z, y, x) of the voxel);
     unique_pos_indices[c]: highest point index inside voxel c; order / cluster_start: members of voxel c are
@@ -44,7 +45,8 @@ def voxel_cluster(pos, batch, size):
     N = pos.shape[0]
     empty = torch.empty(0, dtype=torch.int64, device=dev)
     if N == 0:
-        return empty, empty, empty, torch.zeros(1, dtype=torch.int64, device=dev)
+        out = (empty, empty, empty, torch.zeros(1, dtype=torch.int64, device=dev))
+        return out + (torch.zeros(0, dtype=torch.int64),) if return_counts else out
     pos = pos.detach().contiguous().float()
     if batch is not None:
         batch = batch.contiguous().long()
@@ -59,12 +61,15 @@ def voxel_cluster(pos, batch, size):
         order = torch.empty(N, dtype=torch.int64, device=dev)
         start = torch.empty(N + 1, dtype=torch.int64, device=dev)
         last = torch.empty(N, dtype=torch.int64, device=dev)
-        count = torch.empty(1, dtype=torch.int64, device=dev)
+        nclouds = int(bounds_host[6]) + 1 if batch is not None else 1
+        meta = torch.empty(1 + max(nclouds, 1), dtype=torch.int64, device=dev)
         _lib.call("tp3d_voxel_cluster_f32", _lib.ptr(pos), _lib.ptr(batch), N, float(size),
                   bounds_host.ctypes.data, _lib.ptr(cluster), _lib.ptr(order), _lib.ptr(start), _lib.ptr(last),
-                  _lib.ptr(count), _lib.ptr(ws), nbytes, s)
-        K = int(count.item())  # wait 2: number of occupied voxels
-    return cluster, last[:K], order, start[:K + 1]
+                  _lib.ptr(meta), _lib.ptr(ws), nbytes, s)
+        meta_host = meta.cpu()  # wait 2: number of occupied voxels (+ how many of them each cloud holds)
+        K = int(meta_host[0])
+    out = (cluster, last[:K], order, start[:K + 1])
+    return out + (meta_host[1:],) if return_counts else out
 
 
 def cluster_mean(x, order, cluster_start):
@@ -167,7 +172,8 @@ class GridSampling3D(object):
         if self._mode == "last":
             data = shuffle_data(data)
         batch = getattr(data, "batch", None)
-        cluster, unique_pos_indices, order, cluster_start = voxel_cluster(data.pos, batch, self._grid_size)
+        cluster, unique_pos_indices, order, cluster_start, counts = voxel_cluster(data.pos, batch, self._grid_size,
+                                                                                  return_counts=True)
         if self._quantize_coords:
             # tensor / tensor is a true fp32 division on the device (tensor / python-scalar multiplies by 1/size)
             size_t = torch.full((), float(self._grid_size), dtype=torch.float32, device=data.pos.device)
@@ -176,6 +182,14 @@ class GridSampling3D(object):
         if self._quantize_coords:
             data.coords = coords.int()
         data.grid_size = torch.tensor([self._grid_size])
+        new_batch = getattr(data, "batch", None)
+        if batch is not None and torch.is_tensor(new_batch) and new_batch.dtype == torch.int64 and counts.numel():
+            # the sampled batch vector's segment table is known from the clustering: spare the next radius / kNN
+            # search on this level its own pass over the vector and its host read
+            from . import torchpoints as _tp
+            seg = torch.zeros(counts.numel() + 1, dtype=torch.int64)
+            seg[1:] = torch.cumsum(counts, 0)
+            _tp.prime_segments(new_batch, seg.to(new_batch.device), int(counts.numel()), int(counts.max()))
         return data
 
     def __call__(self, data):

@@ -20,6 +20,7 @@ import copy
 import torch
 import torch.nn as nn
 
+from . import fused as _fused
 from . import torchpoints as _tp
 from .grid_sampling import GridSampling3D
 from .kpconv import KPConvLayer, default_kernel_points
@@ -45,6 +46,12 @@ class PDData(object):
         for k, v in self.__dict__.items():
             setattr(out, k, v.clone() if torch.is_tensor(v) else copy.copy(v))
         return out
+
+
+def _copy(data):
+    """The reference deep-copies (`data.clone()`) before replacing attributes; no block writes a tensor in place, so a
+    new bag over the same tensors is equivalent and saves one device copy per attribute and block."""
+    return data.shallow_copy() if hasattr(data, "shallow_copy") else data.clone()
 
 
 class FastBatchNorm1d(nn.Module):
@@ -81,9 +88,10 @@ class SimpleBlock(nn.Module):
 
     def __init__(self, down_conv_nn=None, grid_size=None, prev_grid_size=None, sigma=1.0, max_num_neighbors=16,
                  activation=None, bn_momentum=0.02, bn=FastBatchNorm1d, add_one=False, kernel_points=None, sampler=None,
-                 **kwargs):
+                 fused=True, **kwargs):
         super().__init__()
         assert len(down_conv_nn) == 2
+        self.fused = fused
         if kernel_points is None:
             kernel_points = default_kernel_points(kwargs.get("n_kernel_points", 15))
         num_inputs, num_outputs = down_conv_nn
@@ -105,16 +113,22 @@ class SimpleBlock(nn.Module):
             idx_neighboors, q_pos = query_data.idx_neighboors, query_data.pos
         else:
             if self.is_strided:
-                query_data = self.sampler(data.clone())
+                query_data = self.sampler(_copy(data))
             else:
-                query_data = data.clone()
+                query_data = _copy(data)
             q_pos = query_data.pos
             idx_neighboors = self.neighbour_finder(data.pos, q_pos, batch_x=data.batch, batch_y=query_data.batch)
             query_data.idx_neighboors = idx_neighboors
         x = self.kp_conv(q_pos, data.pos, idx_neighboors, data.x)
-        if self.bn:
-            x = self.bn(x)
-        query_data.x = self.activation(x)
+        bn1d = _fused._bn1d_of(self.bn) if (self.fused and self.bn is not None and x.is_cuda) else None
+        slope = _fused._slope_of(self.activation)
+        if bn1d is not None and slope is not None:
+            x = _fused.bn_act(x, bn1d, slope)  # BatchNorm statistics + affine + activation: two kernels
+        else:
+            if self.bn:
+                x = self.bn(x)
+            x = self.activation(x)
+        query_data.x = x
         query_data.block_idx = data.block_idx + 1
         return query_data
 
@@ -123,9 +137,11 @@ class ResnetBBlock(nn.Module):
     """unary -> SimpleBlock -> unary, plus shortcut (neighbourhood max-pool when strided), summed."""
 
     def __init__(self, down_conv_nn=None, grid_size=None, prev_grid_size=None, sigma=1, max_num_neighbors=16,
-                 activation=None, has_bottleneck=True, bn_momentum=0.02, bn=FastBatchNorm1d, add_one=False, **kwargs):
+                 activation=None, has_bottleneck=True, bn_momentum=0.02, bn=FastBatchNorm1d, add_one=False, fused=True,
+                 **kwargs):
         super().__init__()
         assert len(down_conv_nn) in (2, 3), "down_conv_nn should be of size 2 or 3"
+        self.fused = fused
         if len(down_conv_nn) == 2:
             num_inputs, num_outputs = down_conv_nn
             d_2 = num_outputs // 4
@@ -137,7 +153,7 @@ class ResnetBBlock(nn.Module):
         kp_size = [d_2, d_2] if has_bottleneck else [num_inputs, num_outputs]
         self.kp_conv = SimpleBlock(down_conv_nn=kp_size, grid_size=grid_size, prev_grid_size=prev_grid_size, sigma=sigma,
                                    max_num_neighbors=max_num_neighbors, activation=activation, bn_momentum=bn_momentum,
-                                   bn=bn, add_one=add_one, **kwargs)
+                                   bn=bn, add_one=add_one, fused=fused, **kwargs)
         if has_bottleneck:
             if bn:
                 self.unary_1 = nn.Sequential(nn.Linear(num_inputs, d_2, bias=False), bn(d_2, momentum=bn_momentum),
@@ -158,19 +174,23 @@ class ResnetBBlock(nn.Module):
         self.activation = activation
 
     def forward(self, data, precomputed=None, **kwargs):
-        output = data.clone()
+        output = _copy(data)
         shortcut_x = data.x
+        seq = _fused.rows_seq if self.fused else (lambda m, x: m(x))
         if self.has_bottleneck:
-            output.x = self.unary_1(output.x)
+            output.x = seq(self.unary_1, output.x)
         output = self.kp_conv(output, precomputed=precomputed)
         if self.has_bottleneck:
-            output.x = self.unary_2(output.x)
+            output.x = seq(self.unary_2, output.x)
         if self.is_strided:
             idx = output.idx_neighboors
-            padded = torch.cat([shortcut_x, torch.zeros_like(shortcut_x[:1, :])], dim=0)  # shadow feature row
-            idx = torch.where(idx < 0, torch.full_like(idx, shortcut_x.shape[0]), idx)
-            shortcut_x = padded[idx].max(dim=1)[0]
-        output.x = output.x + self.shortcut_op(shortcut_x)
+            if self.fused and shortcut_x.is_cuda:
+                shortcut_x = _fused.nbr_maxpool(shortcut_x, idx)
+            else:
+                padded = torch.cat([shortcut_x, torch.zeros_like(shortcut_x[:1, :])], dim=0)  # shadow feature row
+                idx = torch.where(idx < 0, torch.full_like(idx, shortcut_x.shape[0]), idx)
+                shortcut_x = padded[idx].max(dim=1)[0]
+        output.x = output.x + seq(self.shortcut_op, shortcut_x)
         return output
 
     @property

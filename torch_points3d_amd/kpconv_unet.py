@@ -14,6 +14,7 @@ for four layers: level 0 = SimpleBlock(FEAT+1 -> f) + ResnetBBlock(f -> 2f); lev
 import torch
 import torch.nn as nn
 
+from . import fused as _fused
 from .kpconv_blocks import KPDualBlock
 from .partial_dense import MLP, FPModule_PD
 
@@ -45,15 +46,16 @@ def unet_config(num_layers=4, input_nc=3, in_feat=64, in_grid_size=0.02, bn_mome
 class KPConvUnet(nn.Module):
     """down_modules (KPDualBlock per level) -> Identity inner -> up_modules (FPModule_PD), symmetric skips."""
 
-    def __init__(self, config, output_nc=None, kernel_points=None):
+    def __init__(self, config, output_nc=None, kernel_points=None, fused=True):
         super().__init__()
+        self.fused = fused
         self.down_modules = nn.ModuleList()
         self.inner_modules = nn.ModuleList([nn.Identity()])
         self.up_modules = nn.ModuleList()
         for i, opt in enumerate(config["down_conv"]):
-            self.down_modules.append(KPDualBlock(kernel_points=kernel_points, **opt))
+            self.down_modules.append(KPDualBlock(kernel_points=kernel_points, fused=fused, **opt))
         for opt in config["up_conv"]:
-            self.up_modules.append(FPModule_PD(**opt))
+            self.up_modules.append(FPModule_PD(fused=fused, **opt))
         default_output_nc = config["up_conv"][-1]["up_conv_nn"][-1]
         self._output_nc = default_output_nc
         self._has_mlp_head = False
@@ -80,12 +82,12 @@ class KPConvUnet(nn.Module):
         for i in range(len(self.up_modules)):
             data = self.up_modules[i]((data, stack_down.pop()), precomputed=precomputed_up)
         if self.has_mlp_head:
-            data.x = self.mlp(data.x)
+            data.x = _fused.rows_mlp(self.mlp, data.x) if self.fused else self.mlp(data.x)
         return data
 
 
 def KPConv(architecture="unet", input_nc=None, num_layers=4, config=None, in_feat=64, in_grid_size=0.02, output_nc=None,
-           kernel_points=None, **kwargs):
+           kernel_points=None, fused=True, **kwargs):
     """Factory with the reference's signature (applications/kpconv.py:22-49); only the U-Net is assembled here."""
     if not architecture:
         raise ValueError()
@@ -93,4 +95,4 @@ def KPConv(architecture="unet", input_nc=None, num_layers=4, config=None, in_fea
         raise NotImplementedError("only architecture='unet' is built (the encoder is its down_modules half)")
     cfg = config if config is not None else unet_config(num_layers, input_nc, in_feat, in_grid_size,
                                                         kwargs.get("bn_momentum", 0.2), kwargs.get("max_neighbors", 25))
-    return KPConvUnet(cfg, output_nc=output_nc, kernel_points=kernel_points)
+    return KPConvUnet(cfg, output_nc=output_nc, kernel_points=kernel_points, fused=fused)

@@ -14,6 +14,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib
+from . import fused as _fused
 from . import torchpoints as _tp
 from .kpconv_blocks import FastBatchNorm1d
 
@@ -124,6 +125,7 @@ class FPModule_PD(nn.Module):
         self.upsample_op = KNNInterpolate(up_k)
         bn_momentum = kwargs.get("bn_momentum", 0.1)
         self.nn = MLP(up_conv_nn, bn_momentum=bn_momentum, bias=False)
+        self.fused = kwargs.get("fused", True)
 
     def forward(self, data, precomputed=None, **kwargs):
         data, data_skip = data
@@ -149,7 +151,7 @@ class FPModule_PD(nn.Module):
                 x = torch.cat([x, x_skip], dim=1)
         else:
             x = self.upsample_op(data, data_skip, precomputed=pre_data, skip=x_skip)
-        batch_out.x = self.nn(x) if hasattr(self, "nn") else x
+        batch_out.x = (_fused.rows_mlp(self.nn, x) if self.fused else self.nn(x)) if hasattr(self, "nn") else x
         return batch_out
 
 

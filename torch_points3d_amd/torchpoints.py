@@ -148,6 +148,13 @@ def _segments(bx):
     return out
 
 
+def prime_segments(bx, seg, nclouds, nmax):
+    """Record the segment table of a sorted batch vector whose producer already knows it (GridSampling3D)."""
+    if len(_seg_cache) > 64:
+        _seg_cache.clear()
+    _seg_cache[(bx.data_ptr(), bx.numel(), bx._version, bx.device.index)] = (weakref.ref(bx), (seg, nclouds, nmax))
+
+
 def knn(k, x, y, batch_x=None, batch_y=None, cell=0.0):
     """The k nearest support points of every query, inside the query's own cloud.
 
