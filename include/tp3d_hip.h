@@ -220,8 +220,9 @@ int tp3d_idw_weights_f32(const float *dist, int64_t rows, float *weight, void *s
  *                                 last (N; [0..K) valid) highest point index of each cluster = the reference's
  *                                 unique_pos_indices (consecutive_cluster's scatter_, last write wins);
  *                                 meta (1 + clouds) int64 on the device, clouds = bounds[6] + 1 (1 without batch):
- *                                 meta[0] = K, meta[1 + b] = clusters of cloud b (the row counts of the sampled
- *                                 batch vector).  workspace: tp3d_voxel_workspace_bytes(N);
+ *                                 meta[0] = K, meta[1 + b] = clusters of clouds 0..b together (0 for a cloud without
+ *                                 points): the row offsets of the sampled batch vector.  workspace:
+ *                                 tp3d_voxel_workspace_bytes(N);
  *   3. tp3d_cluster_mean_f32   -> out (K,C) = scatter_mean(x (N,C)) summed in ascending point order (:78), and
  *      tp3d_cluster_majority_i64 -> out (K) = majority label, ties -> lowest (:72-76); num_classes = max-min+1.
  */

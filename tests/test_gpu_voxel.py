@@ -115,3 +115,15 @@ def test_bad_arguments():
         gs.voxel_cluster(torch.rand(10, 3, device=DEV) * 1e9, None, 1e-3)  # coordinates beyond 2^24 voxels
     c, u, o, s = gs.voxel_cluster(torch.empty(0, 3, device=DEV), None, 0.1)
     assert c.numel() == 0 and u.numel() == 0 and s.tolist() == [0]
+
+
+def test_cluster_counts_per_cloud():
+    from torch_points3d_amd import grid_sampling as gs
+    pos, batch = cloud(30000, 6, 17)
+    batch[batch == 2] = 3  # a cloud id without points
+    ref_cluster, ref_perm = voxel_ref.consecutive_cluster(voxel_ref.grid_cluster_key(voxel_ref.voxel_coords(pos, 0.07), batch))
+    out = gs.voxel_cluster(torch.from_numpy(pos).to(DEV), torch.from_numpy(batch).to(DEV), 0.07, return_counts=True)
+    counts = out[4]
+    assert counts.tolist() == np.bincount(batch[ref_perm], minlength=6).tolist() and counts[2] == 0
+    c1 = gs.voxel_cluster(torch.from_numpy(pos).to(DEV), None, 0.07, return_counts=True)[4]
+    assert c1.tolist() == [len(np.unique(voxel_ref.grid_cluster_key(voxel_ref.voxel_coords(pos, 0.07), None)))]

@@ -86,18 +86,25 @@ __global__ __launch_bounds__(KP_BLOCK) void kpconv_weighted_kernel(
             __syncthreads();
             // ---- phase B: accumulate the neighbour rows into the KP accumulators (lanes over channels)
             if (c < Cin) {
+#pragma unroll 5
                 for (int n = 0; n < cnt; ++n) {
                     const int id = ids[n];
-                    if (id < 0) continue;  // wave-uniform
-                    const float v = feat[(size_t)id * Cin + c];
+                    // shadow neighbours carry zero weights (phase A): reading row 0 instead keeps the loop branch-free
+                    const float v = feat[(size_t)max(id, 0) * Cin + c];
                     const float4 w0 = *reinterpret_cast<const float4 *>(&w[n][0]);
                     const float4 w1 = *reinterpret_cast<const float4 *>(&w[n][4]);
                     const float4 w2 = *reinterpret_cast<const float4 *>(&w[n][8]);
                     const float4 w3 = *reinterpret_cast<const float4 *>(&w[n][12]);
-                    acc[0] += w0.x * v;  acc[1] += w0.y * v;  acc[2] += w0.z * v;  acc[3] += w0.w * v;
-                    acc[4] += w1.x * v;  acc[5] += w1.y * v;  acc[6] += w1.z * v;  acc[7] += w1.w * v;
-                    acc[8] += w2.x * v;  acc[9] += w2.y * v;  acc[10] += w2.z * v; acc[11] += w2.w * v;
-                    acc[12] += w3.x * v; acc[13] += w3.y * v; acc[14] += w3.z * v; acc[15] += w3.w * v;
+                    // explicit fused multiply-adds: the translation unit is built with contraction off for the
+                    // distance expressions, the feature accumulation has no bit-exactness contract (1e-5 relative)
+                    acc[0] = __builtin_fmaf(w0.x, v, acc[0]);   acc[1] = __builtin_fmaf(w0.y, v, acc[1]);
+                    acc[2] = __builtin_fmaf(w0.z, v, acc[2]);   acc[3] = __builtin_fmaf(w0.w, v, acc[3]);
+                    acc[4] = __builtin_fmaf(w1.x, v, acc[4]);   acc[5] = __builtin_fmaf(w1.y, v, acc[5]);
+                    acc[6] = __builtin_fmaf(w1.z, v, acc[6]);   acc[7] = __builtin_fmaf(w1.w, v, acc[7]);
+                    acc[8] = __builtin_fmaf(w2.x, v, acc[8]);   acc[9] = __builtin_fmaf(w2.y, v, acc[9]);
+                    acc[10] = __builtin_fmaf(w2.z, v, acc[10]); acc[11] = __builtin_fmaf(w2.w, v, acc[11]);
+                    acc[12] = __builtin_fmaf(w3.x, v, acc[12]); acc[13] = __builtin_fmaf(w3.y, v, acc[13]);
+                    acc[14] = __builtin_fmaf(w3.z, v, acc[14]); acc[15] = __builtin_fmaf(w3.w, v, acc[15]);
                 }
             }
             __syncthreads();
@@ -123,6 +130,8 @@ TP3D_EXPORT int tp3d_kpconv_weighted_f32(const float *query, const float *suppor
     if (KP > KP_MAX) return TP3D_E_TOOBIG;
     if (Nq == 0) return TP3D_OK;
     if (!query || !weighted || !k_points || (Mn > 0 && (!neighbors || !support || !features))) return TP3D_E_BADARG;
+    if (M == 0 || Mn == 0)  // no support row to read: every neighbour is a shadow
+        return zero_async(weighted, (size_t)Nq * KP * Cin * sizeof(float), (hipStream_t)stream);
     const int64_t blocks = (Nq + KP_BLOCK / 64 - 1) / (KP_BLOCK / 64);
     if (blocks > 0x7fffffff) return TP3D_E_TOOBIG;
     hipLaunchKernelGGL(kpconv_weighted_kernel, dim3((unsigned)blocks), dim3(KP_BLOCK), 0, (hipStream_t)stream, query,

@@ -125,10 +125,10 @@ __global__ __launch_bounds__(VX_BLOCK) void voxel_scatter_kernel(const unsigned 
     cluster[p] = c;
     order[i] = p;
     if (i == 0 || cid[i - 1] != c) cluster_start[c] = i;
-    if (i == N - 1 || cid[i + 1] != c) {
-        last[c] = p;  // highest point index of the voxel (stable sort)
-        atomicAdd(&meta[1 + (batch ? batch[p] : 0)], 1ull);  // occupied voxels per cloud (integer: order-free)
-    }
+    if (i == N - 1 || cid[i + 1] != c) last[c] = p;  // highest point index of the voxel (stable sort)
+    // clusters are numbered cloud by cloud: the last slot of cloud b records how many clusters clouds 0..b hold
+    const int64_t b = batch ? batch[p] : 0;
+    if (i == N - 1 || (batch && batch[vals[i + 1]] != b)) meta[1 + b] = (unsigned long long)c + 1;
     if (i == N - 1) {
         cluster_start[c + 1] = N;
         meta[0] = (unsigned long long)c + 1;

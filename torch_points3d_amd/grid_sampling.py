@@ -69,7 +69,10 @@ def voxel_cluster(pos, batch, size, return_counts=False):
         meta_host = meta.cpu()  # wait 2: number of occupied voxels (+ how many of them each cloud holds)
         K = int(meta_host[0])
     out = (cluster, last[:K], order, start[:K + 1])
-    return out + (meta_host[1:],) if return_counts else out
+    if not return_counts:
+        return out
+    ends = torch.cummax(meta_host[1:], 0)[0]  # running cluster count after each cloud (empty clouds recorded 0)
+    return out + (torch.diff(ends, prepend=ends.new_zeros(1)),)
 
 
 def cluster_mean(x, order, cluster_start):
