@@ -155,3 +155,35 @@ def test_fp_module_pd_and_neighbour_finder(oracle):
     ref_idx, _ = oracle.knn(4, coarse.pos.cpu(), pos, coarse.batch.cpu(), batch)
     assert edges.shape == (2, N * 4)
     assert torch.equal(edges[1].cpu().reshape(N, 4), ref_idx) and torch.equal(edges[0].cpu(), torch.arange(N).repeat_interleave(4))
+
+
+def test_randla_conv_against_edge_list_formulation(oracle):
+    """RandlaConv (fixed-k neighbour table) against the reference's message-passing formulation written with an
+    explicit edge list and scatter-add in plain torch (modules/RandLANet/modules.py:25-54)."""
+    from torch_points3d_amd.kpconv_blocks import PDData
+    from torch_points3d_amd.randla import RandlaConv
+    torch.manual_seed(0)
+    N, C, k = 4000, 8, 16
+    pos = torch.rand(N, 3)
+    batch = torch.sort(torch.randint(0, 2, (N,)))[0]
+    x = torch.randn(N, C)
+    conv = RandlaConv(ratio=0.25, k=k, point_pos_nn=[10, 8, C], attention_nn=[2 * C, 8, 2 * C],
+                      down_conv_nn=[2 * C, 8, 16]).to(DEV)
+    out = conv(PDData(pos=pos.to(DEV), batch=batch.to(DEV), x=x.to(DEV)))
+    idx = out.idx.cpu()
+    assert idx.shape[0] == N // 4 and out.x.shape == (N // 4, 16)
+    assert torch.equal(out.pos.cpu(), pos[idx]) and torch.equal(out.batch.cpu(), batch[idx])
+    ref_nbr, _ = oracle.knn(k, pos, pos[idx], batch, batch[idx])
+    assert torch.equal(out.neighbors.cpu(), ref_nbr)
+    # edge-list formulation on the CPU with the same weights
+    kern = conv._conv.cpu()
+    row = torch.arange(idx.shape[0]).repeat_interleave(k)  # target (query) of each edge
+    col = ref_nbr.reshape(-1)                                 # source (support) of each edge
+    pos_i, pos_j, x_j = pos[idx][row], pos[col], x[col]
+    vij = pos_i - pos_j
+    rij = kern.point_pos_nn(torch.cat([pos_i, pos_j, vij, vij.norm(dim=1, keepdim=True)], 1))
+    f = torch.cat([x_j, rij], 1)
+    msg = torch.softmax(kern.attention_nn(f), -1) * f
+    aggr = torch.zeros(idx.shape[0], f.shape[1]).index_add_(0, row, msg)
+    ref = kern.global_nn(aggr)
+    torch.testing.assert_close(out.x.detach().cpu(), ref.detach(), rtol=1e-3, atol=1e-4)

@@ -510,8 +510,10 @@ GridPlan grid_plan(int Lmax)
     if (!p.global) {
         p.G = grid_edge_for(Lmax);
     } else {
-        int G = 16;  // about two points per cell of a volume-filling cloud
-        while (G < GRID_GLOBAL_MAX_EDGE && (int64_t)G * G * G * 2 < Lmax) ++G;
+        // scans sample surfaces: the occupied cells are a thin subset of the box, so the table is sized for twice as
+        // many cells as points (126^3 for 10^6 points) rather than for a volume-filling cloud
+        int G = 16;
+        while (G < GRID_GLOBAL_MAX_EDGE && (int64_t)G * G * G < 2 * (int64_t)Lmax) ++G;
         p.G = G;
     }
     return p;

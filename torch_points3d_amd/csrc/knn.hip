@@ -10,14 +10,17 @@
 // and accept once the k-th distance is inside the largest ball that is certainly covered by the visited cells
 // (distance to the nearest face of the block that still has cells behind it, shrunk by 0.1 % for the fp32 rounding
 // of the cell coordinate).  Exact by construction: any point outside the block is farther than that ball.
-// k == 1 never touches LDS (running wave arg-min); k > 1 keeps up to 1024 candidates per wave in LDS and falls
-// back to a scan of the whole cloud for queries whose block holds more (far outliers, degenerate densities).
+// k == 1 never touches LDS (running wave arg-min).  k > 1 streams the block's points through a 1024-slot candidate
+// buffer per wave; when it fills up it is compacted to its k smallest pairs and their largest distance becomes an
+// admission threshold, so over-populated cells (surfaces scanned much denser than the grid assumes) cost a scan of
+// their points but never an overflow.  k > 128 falls back to a selection scan of the whole cloud.
 #include "grid.h"
 
 namespace tp3d {
 
 constexpr int KQ_BLOCK = 256;  // 4 waves, one query per wave
-constexpr int KQ_CAP = 1024;
+constexpr int KQ_CAP = 1024;   // candidate slots per wave
+constexpr int KQ_KMAX = 128;   // largest k served from the grid (beyond: selection scan of the whole cloud)
 
 __device__ __forceinline__ bool pair_less(float da, int ia, float db, int ib) { return da < db || (da == db && ia < ib); }
 
@@ -42,11 +45,15 @@ __global__ __launch_bounds__(KQ_BLOCK) void grid_knn_kernel(
 {
     __shared__ int s_id[KQ_BLOCK / 64][KQ_CAP];
     __shared__ float s_d[KQ_BLOCK / 64][KQ_CAP];
+    __shared__ int s_si[KQ_BLOCK / 64][KQ_KMAX];
+    __shared__ float s_sd[KQ_BLOCK / 64][KQ_KMAX];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t q = (int64_t)blockIdx.x * (KQ_BLOCK / 64) + wave;
     if (q >= total_q) return;  // wave-uniform; the kernel has no workgroup barrier
     int *cid = s_id[wave];
     float *cd = s_d[wave];
+    int *si = s_si[wave];
+    float *sd = s_sd[wave];
     const bool partial = seg != nullptr;
     const int64_t bq = partial ? batch_y[q] : q / np;
     int64_t *io = idx + q * k;
@@ -78,8 +85,9 @@ __global__ __launch_bounds__(KQ_BLOCK) void grid_knn_kernel(
     // smallest ring whose block reaches the grid at all
     int R = max(1, max(max(max(-cx, cx - (gi.gx - 1)), max(-cy, cy - (gi.gy - 1))), max(-cz, cz - (gi.gz - 1))));
     const int kk = min(k, L);
+    float tau = 3.0e38f;  // upper bound of the k-th distance once kk candidates are known
 
-    for (;; ++R) {
+    for (; k <= KQ_KMAX; ++R) {
         const int x0 = max(cx - R, 0), x1 = min(cx + R, gi.gx - 1);
         const int y0 = max(cy - R, 0), y1 = min(cy + R, gi.gy - 1);
         const int z0 = max(cz - R, 0), z1 = min(cz + R, gi.gz - 1);
@@ -124,65 +132,91 @@ __global__ __launch_bounds__(KQ_BLOCK) void grid_knn_kernel(
             continue;
         }
 
-        // ---- k > 1: gather the block's points into LDS
+        // ---- k > 1: stream the block's points through the candidate buffer.  Once the buffer would overflow it is
+        // compacted to its kk smallest pairs, whose largest distance `tau` bounds the final k-th distance from above:
+        // from then on only points with d <= tau are appended, so dense cells cost a scan but never an overflow.
         int h = 0;
-        bool overflow = false;
-        for (int zz = z0; zz <= z1 && !overflow; ++zz)
-            for (int yy = y0; yy <= y1 && !overflow; ++yy) {
+        auto compact = [&]() {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            float pd = -1.0f;
+            int pi = -1;
+            const int emit = min(kk, h);
+            for (int sidx = 0; sidx < emit; ++sidx) {  // pass s: the smallest pair after the previous one
+                float bd = 3.0e38f;
+                int bi = 0x7fffffff;
+                for (int t = lane; t < h; t += 64) {
+                    const float d = cd[t];
+                    const int id = cid[t];
+                    if ((d > pd || (d == pd && id > pi)) && pair_less(d, id, bd, bi)) {
+                        bd = d;
+                        bi = id;
+                    }
+                }
+                wave_argmin(bd, bi);
+                if (lane == 0) {
+                    sd[sidx] = bd;
+                    si[sidx] = bi;
+                }
+                pd = bd;
+                pi = bi;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            for (int t = lane; t < emit; t += 64) {
+                cd[t] = sd[t];
+                cid[t] = si[t];
+            }
+            h = emit;
+            if (emit == kk) tau = pd;  // kk real candidates exist within tau
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+        };
+        for (int zz = z0; zz <= z1; ++zz)
+            for (int yy = y0; yy <= y1; ++yy) {
                 const int rowbase = (zz * gi.gy + yy) * gi.gx;
                 const int j0 = cs[rowbase + x0], j1 = cs[rowbase + x1 + 1];
-                if (h + (j1 - j0) > KQ_CAP) {
-                    overflow = true;
-                    break;
+                for (int j = j0; j < j1; j += 64) {
+                    const int t = j + lane;
+                    const bool valid = t < j1;
+                    const int tt = valid ? t : j0;
+                    const float d = sqdist3(sorted_xyz[(lo + tt) * 3 + 0], sorted_xyz[(lo + tt) * 3 + 1],
+                                            sorted_xyz[(lo + tt) * 3 + 2], qx, qy, qz);
+                    const int id = sorted_id[lo + tt];
+                    bool keep = valid && d <= tau;
+                    unsigned long long mask = __ballot(keep);
+                    if (!mask) continue;
+                    if (h + __builtin_popcountll(mask) > KQ_CAP) {
+                        compact();
+                        keep = keep && d <= tau;
+                        mask = __ballot(keep);
+                        if (!mask) continue;
+                    }
+                    if (keep) {
+                        const int slot = h + lanes_below(mask);
+                        cd[slot] = d;
+                        cid[slot] = id;
+                    }
+                    h += __builtin_popcountll(mask);
                 }
-                for (int j = j0 + lane; j < j1; j += 64) {
-                    cd[h + (j - j0)] = sqdist3(sorted_xyz[(lo + j) * 3 + 0], sorted_xyz[(lo + j) * 3 + 1],
-                                               sorted_xyz[(lo + j) * 3 + 2], qx, qy, qz);
-                    cid[h + (j - j0)] = sorted_id[lo + j];
-                }
-                h += j1 - j0;
             }
-        if (overflow) break;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_wave_barrier();
         if (h < kk && !whole) continue;
-        // k-th smallest pair by successive selection: pass s finds the smallest pair after the previous one
-        float pd = -1.0f;
-        int pi = -1;
-        const int emit = min(kk, h);
-        bool accepted = true;
-        for (int s = 0; s < emit; ++s) {
-            float bd = 3.0e38f;
-            int bi = 0x7fffffff;
-            for (int t = lane; t < h; t += 64) {
-                const float d = cd[t];
-                const int id = cid[t];
-                if ((d > pd || (d == pd && id > pi)) && pair_less(d, id, bd, bi)) {
-                    bd = d;
-                    bi = id;
-                }
-            }
-            wave_argmin(bd, bi);
-            if (!whole && !(bd <= cover2)) {  // this rank is not certain yet: widen the block (ranks before it are)
-                accepted = false;
-                break;
-            }
-            if (lane == 0) {
-                io[s] = goff + bi;
-                dd[s] = bd;
-            }
-            pd = bd;
-            pi = bi;
+        compact();  // the kk (or all h) smallest pairs, sorted, at the front of the buffer
+        const int emit = h;
+        const float worst = emit ? cd[emit - 1] : 0.0f;
+        if (!whole && !(worst <= cover2)) continue;  // the k-th neighbour may still lie outside the block: widen
+        for (int sidx = lane; sidx < emit; sidx += 64) {
+            io[sidx] = goff + cid[sidx];
+            dd[sidx] = cd[sidx];
         }
-        if (!accepted) continue;
-        for (int s = emit + lane; s < k; s += 64) {
-            io[s] = -1;
-            dd[s] = -1.0f;
+        for (int sidx = emit + lane; sidx < k; sidx += 64) {
+            io[sidx] = -1;
+            dd[sidx] = -1.0f;
         }
         return;
     }
 
-    // ---- fallback: more block points than LDS slots; successive selection over the whole cloud
+    // ---- k beyond the grid path's staging size: successive selection over the whole cloud
     float pd = -1.0f;
     int pi = -1;
     for (int s = 0; s < kk; ++s) {

@@ -1,0 +1,99 @@
+"""RandLA-Net down-convolution on the HIP kNN (BASELINE config 5).
+
+Mirrors torch_points3d/modules/RandLANet/modules.py:9-67 (`RandlaKernel`, `RandlaConv`),
+core/base_conv/message_passing.py:35-58 (`BaseConvolutionDown.forward`) and core/spatial_ops/sampling.py:103-112
+(`RandomSampler`): same constructor arguments and attribute names (point_pos_nn / attention_nn / global_nn under
+`_conv`), same message (relative-position encoding [pos_i, pos_j, pos_i - pos_j, |.|] -> MLP, concatenation with the
+neighbour feature, softmax attention over channels, sum over the k neighbours, global MLP).
+
+The reference runs this as a torch_geometric MessagePassing over an edge list built by torch_cluster's `knn`; here the
+neighbour table (Nq, k) comes from libtp3d_hip.so's exact grid kNN and, because every query owns exactly k consecutive
+edges, the "add" aggregation is a sum over a (Nq, k, C) view -- no scatter.  Parity: unpinned (torch_cluster absent;
+the reference's own model test skips randlanet, test/test_models.py:116-125).
+"""
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import torchpoints as _tp
+from .kpconv_blocks import PDData
+from .partial_dense import MLP
+
+
+class RandomSampler(object):
+    """floor(N * ratio) (or num_to_sample) indices drawn uniformly WITH replacement (sampling.py:109-111)."""
+
+    def __init__(self, ratio=None, num_to_sample=None):
+        if num_to_sample is not None:
+            if ratio is not None:
+                raise ValueError("Can only specify ratio or num_to_sample or subsampling_param, not several !")
+            self._num_to_sample = num_to_sample
+        elif ratio is not None:
+            self._ratio = ratio
+        else:
+            raise Exception('At least ["ratio, num_to_sample, subsampling_param"] should be defined')
+
+    def _get_num_to_sample(self, n):
+        return self._num_to_sample if hasattr(self, "_num_to_sample") else math.floor(n * self._ratio)
+
+    def sample(self, pos, batch=None, **kwargs):
+        if len(pos.shape) != 2:
+            raise ValueError(" This class is for sparse data and expects the pos tensor to be of dimension 2")
+        return torch.randint(0, pos.shape[0], (self._get_num_to_sample(pos.shape[0]),), device=pos.device)
+
+    def __call__(self, pos, x=None, batch=None):
+        return self.sample(pos, batch=batch, x=x)
+
+
+class RandlaKernel(nn.Module):
+    """Local spatial encoding + attentive pooling over a fixed-k neighbour table."""
+
+    def __init__(self, point_pos_nn=None, attention_nn=None, global_nn=None, *args, **kwargs):
+        super().__init__()
+        self.point_pos_nn = MLP(point_pos_nn)
+        self.attention_nn = MLP(attention_nn)
+        self.global_nn = MLP(global_nn)
+
+    def forward(self, x, pos, nbr):
+        """x (M,C) or None, pos = (query positions (Nq,3), support positions (M,3)), nbr (Nq,k) rows of the support"""
+        pos_q, pos_s = pos
+        Nq, k = nbr.shape
+        j = nbr.reshape(-1)
+        pos_i = pos_q.repeat_interleave(k, dim=0)
+        pos_j = pos_s[j]
+        x_j = pos_j if x is None else x[j]
+        vij = pos_i - pos_j
+        dij = torch.norm(vij, dim=1).unsqueeze(1)
+        rij = self.point_pos_nn(torch.cat([pos_i, pos_j, vij, dij], dim=1))
+        fij_hat = torch.cat([x_j, rij], dim=1)
+        s_ij = F.softmax(self.attention_nn(fij_hat), -1)
+        msg = s_ij * fij_hat
+        return self.global_nn(msg.reshape(Nq, k, -1).sum(dim=1))
+
+
+class RandlaConv(nn.Module):
+    def __init__(self, ratio=None, k=None, *args, **kwargs):
+        super().__init__()
+        self.sampler = RandomSampler(ratio)
+        self.k = k
+        if kwargs.get("index") == 0 and kwargs.get("nb_feature") is not None:
+            kwargs["point_pos_nn"][-1] = kwargs.get("nb_feature")
+            kwargs["attention_nn"][0] = kwargs["attention_nn"][-1] = kwargs.get("nb_feature") * 2
+            kwargs["down_conv_nn"][0] = kwargs.get("nb_feature") * 2
+        self._conv = RandlaKernel(point_pos_nn=kwargs["point_pos_nn"], attention_nn=kwargs["attention_nn"],
+                                  global_nn=kwargs["down_conv_nn"])
+
+    def forward(self, data, **kwargs):
+        x, pos, batch = data.x, data.pos, data.batch
+        idx = self.sampler(pos, batch=batch)
+        q_pos, q_batch = pos[idx], batch[idx]
+        nbr, _ = _tp.knn(self.k, pos, q_pos, batch, q_batch)  # exact kNN of every sampled point in its own cloud
+        out = data.shallow_copy() if hasattr(data, "shallow_copy") else PDData(**vars(data))
+        out.idx = idx
+        out.neighbors = nbr
+        out.x = self._conv(x, (q_pos, pos), nbr)
+        out.pos = q_pos
+        out.batch = q_batch
+        return out
