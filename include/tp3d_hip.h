@@ -35,7 +35,7 @@ extern "C" {
 #define TP3D_E_UNSORTED (-3) /* reserved: batch vector not sorted (checked by the host wrapper) */
 #define TP3D_E_TOOBIG (-4)   /* size exceeds what the kernel's index arithmetic supports */
 
-#define TP3D_ABI_VERSION 13
+#define TP3D_ABI_VERSION 14
 
 int tp3d_abi_version(void);
 const char *tp3d_strerror(int code);
@@ -197,8 +197,11 @@ int tp3d_kpconv_weighted_f32(const float *query, const float *support, const int
 /* Backward of stage 1 wrt the input features (autograd through convolution_ops.py:92-98):
  *   d_features[m, :] = sum over (q,n) with neighbors[q,n] == m of sum_k h(...) * d_weighted[q, k, :]
  * d_weighted (Nq, KP, Cin) = d_out @ W2^T (host GEMM) -> d_features (M, Cin), overwritten; atomic-free and
- * reproducible (the neighbour table is inverted first).  workspace: tp3d_kpconv_bwd_workspace_bytes(M, Nq*Mn). */
+ * reproducible: per-slot gradient rows (Nq*Mn, Cin) are formed per query and summed per support point in slot order
+ * through the inverted neighbour table.  workspace: tp3d_kpconv_grad_workspace_bytes(M, Nq*Mn, Cin)
+ * (tp3d_kpconv_bwd_workspace_bytes(M, slots) is the inverted table alone). */
 size_t tp3d_kpconv_bwd_workspace_bytes(int64_t M, int64_t slots);
+size_t tp3d_kpconv_grad_workspace_bytes(int64_t M, int64_t slots, int Cin);
 int tp3d_kpconv_bwd_features_f32(const float *query, const float *support, const int64_t *neighbors,
                                  const float *k_points, const float *d_weighted, int64_t Nq, int64_t M, int Mn,
                                  int Cin, int KP, float extent, int influence, int closest, float *d_features,

@@ -91,6 +91,49 @@ def bench_kpconv(reps):
         print("KPConv_ops   N=%d Mn=%d Cin=%d Cout=%d  %8.1f us  (stage-1 algorithmic %.0f MB)" % (N, Mn, Cin, Cout, t * 1e3, by / 1e6))
 
 
+def bench_grid(reps):
+    """Radius search on single clouds at KPConv density (one point per 0.02 voxel, r = 0.05, 25 slots): in-LDS grid
+    build (one workgroup per cloud) against the sort-based build (TP3D_GRID_GLOBAL_MIN lowers the switch-over)."""
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from bench_kpconv import synthetic_cloud
+    for n, clouds in [(8192, 1), (16384, 1), (32768, 1), (65536, 1), (65536, 4), (262144, 16)]:
+        pos, batch = synthetic_cloud(n, clouds, 0.02)
+        pos, batch = pos.to(DEV), batch.to(DEV)
+        for mode, env in (("lds-build", None), ("sort-build", "1024")):
+            if env is None:
+                os.environ.pop("TP3D_GRID_GLOBAL_MIN", None)
+            else:
+                os.environ["TP3D_GRID_GLOBAL_MIN"] = env
+            t = timeit(lambda: tp.ball_query(0.05, 25, pos, pos, mode="partial_dense", batch_x=batch, batch_y=batch), reps)
+            print("ball_query partial N=%d clouds=%d %-10s %8.1f us" % (n, clouds, mode, t * 1e3))
+        os.environ.pop("TP3D_GRID_GLOBAL_MIN", None)
+
+
+def bench_kpconv_bwd(reps):
+    from torch_points3d_amd.kpconv import KPConv_ops
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from bench_kpconv import synthetic_cloud
+    pos, batch = synthetic_cloud(65536, 1, 0.02)
+    pos, batch = pos.to(DEV), batch.to(DEV)
+    nbr, _ = tp.ball_query(0.05, 25, pos, pos, mode="partial_dense", batch_x=batch, batch_y=batch)
+    for Cin, Cout in [(32, 32), (64, 64), (128, 128)]:
+        x = torch.randn(pos.shape[0], Cin, device=DEV, requires_grad=True)
+        kp = (torch.rand(15, 3, device=DEV) - 0.5) * 0.06
+        W = (torch.randn(15, Cin, Cout, device=DEV) * 0.1).requires_grad_(True)
+        gout = torch.randn(pos.shape[0], Cout, device=DEV)
+
+        def fb():
+            out = KPConv_ops(pos, pos, nbr, x, kp, W, 0.02, "linear", "sum")
+            out.backward(gout)
+            x.grad = None
+            W.grad = None
+        t = timeit(fb, reps)
+        with torch.no_grad():
+            tf = timeit(lambda: KPConv_ops(pos, pos, nbr, x, kp, W, 0.02, "linear", "sum"), reps)
+        print("KPConv_ops fwd+bwd N=65536 Mn=25 Cin=%d Cout=%d  fwd %8.1f us  fwd+bwd %8.1f us" % (Cin, Cout, tf * 1e3, t * 1e3))
+
+
 if __name__ == "__main__":
     what = sys.argv[1] if len(sys.argv) > 1 else "all"
     reps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
@@ -105,3 +148,7 @@ if __name__ == "__main__":
         bench_fps(reps)
     if what in ("ball", "all"):
         bench_ball(reps)
+    if what in ("grid", "all"):
+        bench_grid(reps)
+    if what in ("kpconv_bwd", "all"):
+        bench_kpconv_bwd(reps)

@@ -9,6 +9,8 @@
 //
 // Build: one workgroup per cloud, all in LDS: bounding box -> cell histogram (LDS atomics) -> scan -> fill ->
 // cell-ordered ids + a cell-ordered xyz copy for coalesced tests (order inside a cell is irrelevant: hits are ranked).
+#include <cstdlib>
+
 #include "grid.h"
 
 namespace tp3d {
@@ -503,10 +505,21 @@ int grid_edge_for(int Lmax)
     return G;
 }
 
+// Clouds larger than this use the sort-based builder (tunable for experiments: TP3D_GRID_GLOBAL_MIN)
+static int grid_global_min_points()
+{
+    const char *e = getenv("TP3D_GRID_GLOBAL_MIN");
+    if (e && *e) {
+        const int v = atoi(e);
+        if (v > 0) return v < GRID_LDS_MAX_POINTS ? v : GRID_LDS_MAX_POINTS;
+    }
+    return GRID_LDS_MAX_POINTS;
+}
+
 GridPlan grid_plan(int Lmax)
 {
     GridPlan p;
-    p.global = Lmax > GRID_LDS_MAX_POINTS;
+    p.global = Lmax > grid_global_min_points();
     if (!p.global) {
         p.G = grid_edge_for(Lmax);
     } else {

@@ -287,45 +287,113 @@ __global__ __launch_bounds__(KP_BLOCK) void nbr_maxpool_bwd_kernel(const float *
     }
 }
 
-__global__ __launch_bounds__(KP_BLOCK) void kpconv_bwd_features_kernel(
-    const float *__restrict__ query, const float *__restrict__ support, const float *__restrict__ kpts,
-    const float *__restrict__ d_wf, const int *__restrict__ start, const int *__restrict__ order, int64_t M, int Mn,
-    int Cin, int KP, float extent, int influence, int closest, float *__restrict__ d_x)
+// Backward, step 1 (one wave per query): per-slot gradient rows
+//   g[q, n, :] = sum_k h(|(s[nbr[q,n]] - q) - K_k|) * d_wf[q, k, :]
+// d_wf[q] (KP x Cin) is read ONCE into registers (lanes over channels) and combined with the KP x Mn influence weights
+// recomputed in LDS exactly like the forward pass.  (The first version walked, per support point, every slot that
+// references it and re-read the whole d_wf[q] block each time: Mn times the traffic.)
+__global__ __launch_bounds__(KP_BLOCK) void kpconv_bwd_slots_kernel(
+    const float *__restrict__ query, const float *__restrict__ support, const int64_t *__restrict__ nbr,
+    const float *__restrict__ kpts, const float *__restrict__ d_wf, int64_t Nq, int64_t M, int Mn, int Cin, int KP,
+    float extent, int influence, int closest, float *__restrict__ g)
+{
+    __shared__ __attribute__((aligned(16))) float s_w[KP_BLOCK / 64][KP_NCH][KP_MAX];
+    __shared__ float s_d[KP_BLOCK / 64][KP_NCH][KP_MAX];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t qraw = (int64_t)blockIdx.x * (KP_BLOCK / 64) + wave;
+    const bool live = qraw < Nq;  // idle waves keep walking the barriers
+    const int64_t q = live ? qraw : Nq - 1;
+    const float qx = query[q * 3 + 0], qy = query[q * 3 + 1], qz = query[q * 3 + 2];
+    float(*w)[KP_MAX] = s_w[wave];
+    float(*dd)[KP_MAX] = s_d[wave];
+    const float sigma = extent * 0.3f;
+    const float gden = 2.0f * sigma * sigma + 1e-9f;
+    const bool single_pass = Mn <= KP_NCH;
+    for (int c0 = 0; c0 < Cin; c0 += 64) {
+        const int c = c0 + lane;
+        float dk[KP_MAX];
+#pragma unroll
+        for (int k = 0; k < KP_MAX; ++k) dk[k] = (k < KP && c < Cin) ? d_wf[((size_t)q * KP + k) * Cin + c] : 0.0f;
+        for (int n0 = 0; n0 < Mn; n0 += KP_NCH) {
+            const int cnt = min(KP_NCH, Mn - n0);
+            if (!(single_pass && c0 > 0))
+            for (int p = lane; p < cnt * KP_MAX; p += 64) {
+                const int n = p / KP_MAX, k = p % KP_MAX;
+                const int64_t id = nbr[q * Mn + n0 + n];
+                const bool shadow = id < 0 || id >= M;
+                float wv = 0.0f, d2 = 3.0e38f;
+                if (!shadow && k < KP) {
+                    const float cx = support[id * 3 + 0] - qx, cy = support[id * 3 + 1] - qy,
+                                cz = support[id * 3 + 2] - qz;
+                    const float dx = cx - kpts[k * 3 + 0], dy = cy - kpts[k * 3 + 1], dz = cz - kpts[k * 3 + 2];
+                    d2 = (dx * dx + dy * dy) + dz * dz;
+                    if (influence == 0) wv = 1.0f;
+                    else if (influence == 1) wv = fmaxf(1.0f - sqrtf(d2) / extent, 0.0f);
+                    else wv = expf(-d2 / gden);
+                }
+                w[n][k] = wv;
+                dd[n][k] = d2;
+            }
+            __syncthreads();
+            if (closest && !(single_pass && c0 > 0)) {
+                if (lane < cnt) {
+                    int kb = 0;
+                    float best = dd[lane][0];
+                    for (int k = 1; k < KP; ++k)
+                        if (dd[lane][k] < best) {
+                            best = dd[lane][k];
+                            kb = k;
+                        }
+                    for (int k = 0; k < KP; ++k)
+                        if (k != kb) w[lane][k] = 0.0f;
+                }
+            }
+            __syncthreads();
+            if (live && c < Cin) {
+#pragma unroll 5
+                for (int n = 0; n < cnt; ++n) {
+                    const float4 w0 = *reinterpret_cast<const float4 *>(&w[n][0]);
+                    const float4 w1 = *reinterpret_cast<const float4 *>(&w[n][4]);
+                    const float4 w2 = *reinterpret_cast<const float4 *>(&w[n][8]);
+                    const float4 w3 = *reinterpret_cast<const float4 *>(&w[n][12]);
+                    // same k order as the first version's accumulation (ascending k), fused multiply-adds
+                    float acc = w0.x * dk[0];
+                    acc = __builtin_fmaf(w0.y, dk[1], acc);   acc = __builtin_fmaf(w0.z, dk[2], acc);
+                    acc = __builtin_fmaf(w0.w, dk[3], acc);   acc = __builtin_fmaf(w1.x, dk[4], acc);
+                    acc = __builtin_fmaf(w1.y, dk[5], acc);   acc = __builtin_fmaf(w1.z, dk[6], acc);
+                    acc = __builtin_fmaf(w1.w, dk[7], acc);   acc = __builtin_fmaf(w2.x, dk[8], acc);
+                    acc = __builtin_fmaf(w2.y, dk[9], acc);   acc = __builtin_fmaf(w2.z, dk[10], acc);
+                    acc = __builtin_fmaf(w2.w, dk[11], acc);  acc = __builtin_fmaf(w3.x, dk[12], acc);
+                    acc = __builtin_fmaf(w3.y, dk[13], acc);  acc = __builtin_fmaf(w3.z, dk[14], acc);
+                    acc = __builtin_fmaf(w3.w, dk[15], acc);
+                    g[((size_t)q * Mn + n0 + n) * Cin + c] = acc;
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// Backward, step 2 (one wave per support point): d_x[m, :] = sum of the slot rows that reference m, ascending slot
+__global__ __launch_bounds__(KP_BLOCK) void kpconv_bwd_gather_kernel(const float *__restrict__ g,
+                                                                      const int *__restrict__ start,
+                                                                      const int *__restrict__ order, int64_t M, int Cin,
+                                                                      float *__restrict__ d_x)
 {
     const int lane = threadIdx.x & 63;
     const int64_t m = (int64_t)blockIdx.x * (KP_BLOCK / 64) + (threadIdx.x >> 6);
     if (m >= M) return;  // wave-uniform; no workgroup barrier in this kernel
-    const float sx = support[m * 3 + 0], sy = support[m * 3 + 1], sz = support[m * 3 + 2];
-    const int kl = min(lane, KP - 1);
-    const float kx = kpts[kl * 3 + 0], ky = kpts[kl * 3 + 1], kz = kpts[kl * 3 + 2];
-    const float sigma = extent * 0.3f;
-    const float gden = 2.0f * sigma * sigma + 1e-9f;
     const int s0 = start[m], s1 = start[m + 1];
-    for (int c0 = 0; c0 < Cin; c0 += 64) {
-        const int c = min(c0 + lane, Cin - 1);
+    for (int c = lane; c < Cin; c += 64) {
         float acc = 0.0f;
-        for (int j = s0; j < s1; ++j) {
-            const int64_t q = order[j] / Mn;  // wave-uniform
-            // lane k < KP: influence of kernel point k for this (query, support point) pair
-            const float dx = (sx - query[q * 3 + 0]) - kx, dy = (sy - query[q * 3 + 1]) - ky,
-                        dz = (sz - query[q * 3 + 2]) - kz;
-            const float d2 = (dx * dx + dy * dy) + dz * dz;
-            float w;
-            if (influence == 0) w = 1.0f;
-            else if (influence == 1) w = fmaxf(1.0f - sqrtf(d2) / extent, 0.0f);
-            else w = expf(-d2 / gden);
-            if (closest) {
-                // first minimum of d2 over the KP kernel points keeps its weight, the others are masked
-                float best = lane < KP ? d2 : 3.0e38f;
-#pragma unroll
-                for (int off = 8; off >= 1; off >>= 1) best = fminf(best, __shfl_xor(best, off));
-                const unsigned long long eq = __ballot(lane < KP && d2 == best);
-                if (lane != __builtin_ctzll(eq | (1ull << 63))) w = 0.0f;
-            }
-            const float *row = d_wf + (size_t)q * KP * Cin + c;
-            for (int k = 0; k < KP; ++k) acc = acc + rl_bcast(w, k) * row[(size_t)k * Cin];
+        int j = s0;
+        for (; j + 4 <= s1; j += 4) {  // four independent row reads in flight, summed in slot order
+            const float v0 = g[(size_t)order[j] * Cin + c], v1 = g[(size_t)order[j + 1] * Cin + c];
+            const float v2 = g[(size_t)order[j + 2] * Cin + c], v3 = g[(size_t)order[j + 3] * Cin + c];
+            acc = (((acc + v0) + v1) + v2) + v3;
         }
-        if (c0 + lane < Cin) d_x[(size_t)m * Cin + c0 + lane] = acc;
+        for (; j < s1; ++j) acc += g[(size_t)order[j] * Cin + c];
+        d_x[(size_t)m * Cin + c] = acc;
     }
 }
 
@@ -336,6 +404,12 @@ TP3D_EXPORT size_t tp3d_kpconv_bwd_workspace_bytes(int64_t M, int64_t slots)
     if (M < 0 || slots < 0) return 0;
     auto up = [](size_t v) { return (v + 15) & ~(size_t)15; };
     return up((size_t)M * 4) + up((size_t)(M + 1) * 4) + up((size_t)M * 4) + up((size_t)slots * 4);
+}
+
+TP3D_EXPORT size_t tp3d_kpconv_grad_workspace_bytes(int64_t M, int64_t slots, int Cin)
+{
+    if (M < 0 || slots < 0 || Cin <= 0) return 0;
+    return tp3d_kpconv_bwd_workspace_bytes(M, slots) + (((size_t)slots * Cin * 4 + 15) & ~(size_t)15);
 }
 
 TP3D_EXPORT int tp3d_kpconv_bwd_features_f32(const float *query, const float *support, const int64_t *neighbors,
@@ -352,12 +426,15 @@ TP3D_EXPORT int tp3d_kpconv_bwd_features_f32(const float *query, const float *su
     if (slots == 0) return zero_async(d_features, (size_t)M * Cin * sizeof(float), s);
     if (!query || !support || !neighbors || !k_points || !d_weighted || !workspace) return TP3D_E_BADARG;
     if (slots > INT32_MAX || M > INT32_MAX / 2) return TP3D_E_TOOBIG;
-    if (workspace_bytes < tp3d_kpconv_bwd_workspace_bytes(M, slots)) return TP3D_E_BADARG;
+    if (workspace_bytes < tp3d_kpconv_grad_workspace_bytes(M, slots, Cin)) return TP3D_E_BADARG;
     int *start = nullptr, *order = nullptr;
     if (int rc = invert_neighbors(neighbors, slots, M, workspace, &start, &order, s)) return rc;
-    hipLaunchKernelGGL(kpconv_bwd_features_kernel, dim3((unsigned)((M + KP_BLOCK / 64 - 1) / (KP_BLOCK / 64))),
-                       dim3(KP_BLOCK), 0, s, query, support, k_points, d_weighted, start, order, M, Mn, Cin, KP, extent,
-                       influence, closest, d_features);
+    float *g = reinterpret_cast<float *>(static_cast<char *>(workspace) + tp3d_kpconv_bwd_workspace_bytes(M, slots));
+    hipLaunchKernelGGL(kpconv_bwd_slots_kernel, dim3((unsigned)((Nq + KP_BLOCK / 64 - 1) / (KP_BLOCK / 64))), dim3(KP_BLOCK),
+                       0, s, query, support, neighbors, k_points, d_weighted, Nq, M, Mn, Cin, KP, extent, influence, closest,
+                       g);
+    hipLaunchKernelGGL(kpconv_bwd_gather_kernel, dim3((unsigned)((M + KP_BLOCK / 64 - 1) / (KP_BLOCK / 64))),
+                       dim3(KP_BLOCK), 0, s, g, start, order, M, Cin, d_features);
     return check_launch();
 }
 

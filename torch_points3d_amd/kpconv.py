@@ -48,7 +48,7 @@ class _KPConv(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             d_wf = torch.mm(d_out, W.reshape(KP * Cin, -1).t())  # (Nq, KP*Cin)
             dx = torch.empty((M, Cin), dtype=torch.float32, device=dev)
-            nbytes = _lib.load().tp3d_kpconv_bwd_workspace_bytes(M, Nq * Mn)
+            nbytes = _lib.load().tp3d_kpconv_grad_workspace_bytes(M, Nq * Mn, Cin)
             ws = _lib.workspace("kpconv_bwd", nbytes, dev)
             with _lib.on_device(dev):
                 _lib.call("tp3d_kpconv_bwd_features_f32", _lib.ptr(query), _lib.ptr(support), _lib.ptr(nbr), _lib.ptr(kp),
