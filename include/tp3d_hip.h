@@ -73,11 +73,15 @@ size_t tp3d_ball_query_workspace_bytes(int num_clouds, int64_t rows, int max_clo
  *   Optional grid acceleration: seg_x (num_clouds+1) int64 device array of cloud row offsets into x,
  *   max_cloud_points = the largest cloud, workspace = tp3d_ball_query_workspace_bytes(num_clouds, M,
  *   max_cloud_points) bytes; pass NULL / 0 for the brute-force scan of each query's cloud segment.
+ *   reuse_grid != 0: the workspace still holds the grid the previous call on it built for the SAME x, seg_x,
+ *   max_cloud_points and radius (e.g. the last block of a KPConv level and the strided block of the next level
+ *   search the same support with the same radius, modules/KPConv/blocks.py:52): the build is skipped.
  */
 int tp3d_ball_query_partial_dense_f32(const float *x, const float *y, const int64_t *batch_x,
                                       const int64_t *batch_y, int64_t M, int64_t Nq, float radius, int nsample,
                                       int sort, int64_t *idx, float *dist2, const int64_t *seg_x, int num_clouds,
-                                      int max_cloud_points, void *workspace, size_t workspace_bytes, void *stream);
+                                      int max_cloud_points, void *workspace, size_t workspace_bytes, int reuse_grid,
+                                      void *stream);
 
 /*
  * three_nn(unknown, known) -> (dist, idx)       [reference call: core/base_conv/dense.py:136]

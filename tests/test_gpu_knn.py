@@ -187,3 +187,39 @@ def test_randla_conv_against_edge_list_formulation(oracle):
     aggr = torch.zeros(idx.shape[0], f.shape[1]).index_add_(0, row, msg)
     ref = kern.global_nn(aggr)
     torch.testing.assert_close(out.x.detach().cpu(), ref.detach(), rtol=1e-3, atol=1e-4)
+
+
+def test_grid_is_reused_only_for_the_same_support_and_radius(hip, oracle):
+    """Consecutive partial-dense searches over the same support tensor with the same radius skip the grid build
+    (KPConv: last block of a level, strided block of the next); anything else rebuilds.  Results always equal the
+    oracle."""
+    from torch_points3d_amd import _lib
+    x, bx = clouds(30000, 2, 21)
+    xd, bxd = x.to(DEV), bx.to(DEV)
+    g = torch.Generator().manual_seed(4)
+
+    def queries(n):
+        pick = torch.sort(torch.randint(0, x.shape[0], (n,), generator=g))[0]
+        return (x[pick] + 0.01 * torch.randn(n, 3, generator=g)).contiguous(), bx[pick]
+
+    def check(r, xs, xsd):
+        y, by = queries(5000)
+        idx, d2 = hip.ball_query(r, 20, xsd, y.to(DEV), mode="partial_dense", batch_x=bxd, batch_y=by.to(DEV))
+        ref, refd = oracle.ball_query(r, 20, xs, y, mode="partial_dense", batch_x=bx, batch_y=by)
+        assert torch.equal(idx.cpu(), ref) and torch.equal(d2.cpu(), refd)
+
+    timer = _lib.KernelTimer()
+    _lib.set_timer(timer)
+    try:
+        check(0.05, x, xd)          # builds
+        check(0.05, x, xd)          # same support, same radius: reuse
+        check(0.08, x, xd)          # other radius: rebuild
+        hip.knn(3, xd, xd[:100], bxd, bxd[:100])   # another user of the grid workspace
+        check(0.08, x, xd)          # must rebuild
+        xd.mul_(1.5)                # in-place change of the support (version counter moves)
+        check(0.08, x * 1.5, xd)    # must rebuild
+    finally:
+        _lib.set_timer(None)
+    # recorded integer arguments of the entry point: (M, Nq, nsample, sort, clouds, largest, workspace bytes, reuse, stream)
+    reuse = [a[-2] for (name, a), _, _ in timer.records if name == "tp3d_ball_query_partial_dense_f32"]
+    assert reuse == [0, 1, 0, 0, 0]

@@ -19,7 +19,7 @@ SIGNATURES = {
     "tp3d_fps_f32": [_p, _i, _i, _i, _p, _p, _p],
     "tp3d_ball_query_dense_f32": [_p, _p, _i, _i, _i, _f, _i, _i, _p, _p, _p, ctypes.c_size_t, _p],
     "tp3d_ball_query_partial_dense_f32": [_p, _p, _p, _p, _l, _l, _f, _i, _i, _p, _p, _p, _i, _i, _p, ctypes.c_size_t,
-                                          _p],
+                                          _i, _p],
     "tp3d_three_nn_f32": [_p, _p, _i, _i, _i, _p, _p, _p],
     "tp3d_three_interpolate_fwd_f32": [_p, _p, _p, _i, _i, _i, _i, _p, _p],
     "tp3d_three_interpolate_bwd_f32": [_p, _p, _p, _i, _i, _i, _i, _p, _p, ctypes.c_size_t, _p],

@@ -232,7 +232,7 @@ TP3D_EXPORT int tp3d_ball_query_dense_f32(const float *x, const float *y, int B,
     hipStream_t s = (hipStream_t)stream;
     if (workspace && N >= BQ_GRID_MIN_POINTS && grid_plan(N).G >= 2)
         return grid_ball_query(x, y, nullptr, nullptr, B, (int64_t)B * N, N, np, (int64_t)B * np, N, radius, nsample,
-                               sort, idx, dist2, workspace, workspace_bytes, s);
+                               sort, idx, dist2, workspace, workspace_bytes, false, s);
     if (sort) {
         const int64_t total = (int64_t)B * np;
         const int block = 64;
@@ -251,7 +251,8 @@ TP3D_EXPORT int tp3d_ball_query_partial_dense_f32(const float *x, const float *y
                                                   const int64_t *batch_y, int64_t M, int64_t Nq, float radius,
                                                   int nsample, int sort, int64_t *idx, float *dist2,
                                                   const int64_t *seg_x, int num_clouds, int max_cloud_points,
-                                                  void *workspace, size_t workspace_bytes, void *stream)
+                                                  void *workspace, size_t workspace_bytes, int reuse_grid,
+                                                  void *stream)
 {
     using namespace tp3d;
     if (M < 0 || Nq < 0 || nsample <= 0) return TP3D_E_BADARG;
@@ -262,7 +263,7 @@ TP3D_EXPORT int tp3d_ball_query_partial_dense_f32(const float *x, const float *y
     if (workspace && seg_x && num_clouds > 0 && max_cloud_points >= BQ_GRID_MIN_POINTS &&
         grid_plan(max_cloud_points).G >= 2)
         return grid_ball_query(x, y, seg_x, batch_y, num_clouds, M, 0, 0, Nq, max_cloud_points, radius, nsample, sort,
-                               idx, dist2, workspace, workspace_bytes, s);
+                               idx, dist2, workspace, workspace_bytes, reuse_grid != 0, s);
     if (sort) {
         const int block = 64;
         // batch_x must be non-null to select the partial-dense branch even when M == 0

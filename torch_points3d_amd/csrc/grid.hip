@@ -609,13 +609,15 @@ int grid_build(const float *x, const int64_t *seg, int num_clouds, int64_t rows,
 // Enqueue build + query. seg/batch_y null => dense layout.
 int grid_ball_query(const float *x, const float *y, const int64_t *seg, const int64_t *batch_y, int num_clouds,
                     int64_t rows, int N, int np, int64_t total_q, int Lmax, float radius, int nsample, int sort,
-                    int64_t *idx, float *dist2, void *workspace, size_t workspace_bytes, hipStream_t s)
+                    int64_t *idx, float *dist2, void *workspace, size_t workspace_bytes, bool reuse_grid, hipStream_t s)
 {
     const GridPlan plan = grid_plan(Lmax);
     if (plan.G < 2) return TP3D_E_TOOBIG;
     GridWorkspace w = carve_grid_workspace(workspace, num_clouds, rows, plan);
     if (workspace_bytes < w.bytes) return TP3D_E_BADARG;
-    if (int rc = grid_build(x, seg, num_clouds, rows, N, Lmax, radius, 2.0f, plan, w, s)) return rc;
+    // reuse_grid: the workspace still holds the tables of the previous call with the same support, segments and radius
+    if (!reuse_grid)
+        if (int rc = grid_build(x, seg, num_clouds, rows, N, Lmax, radius, 2.0f, plan, w, s)) return rc;
     const int64_t blocks = (total_q + GQ_BLOCK / 64 - 1) / (GQ_BLOCK / 64);
     if (blocks > 0x7fffffff) return TP3D_E_TOOBIG;
     hipLaunchKernelGGL(grid_query_kernel, dim3((unsigned)blocks), dim3(GQ_BLOCK), 0, s, x, y, seg, batch_y, total_q, N,

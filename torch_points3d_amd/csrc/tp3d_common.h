@@ -74,7 +74,7 @@ int gather_sum(const float *rows, const int *start, const int *order, const floa
 // grid.hip: uniform-grid radius search (build + query); seg/batch_y null => dense layout (more in grid.h)
 int grid_ball_query(const float *x, const float *y, const int64_t *seg, const int64_t *batch_y, int num_clouds,
                     int64_t rows, int N, int np, int64_t total_q, int Lmax, float radius, int nsample, int sort,
-                    int64_t *idx, float *dist2, void *workspace, size_t workspace_bytes, hipStream_t s);
+                    int64_t *idx, float *dist2, void *workspace, size_t workspace_bytes, bool reuse_grid, hipStream_t s);
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & (kWave - 1); }
 

@@ -96,9 +96,21 @@ def ball_query(radius, nsample, x, y, mode="dense", batch_x=None, batch_y=None, 
             if ws is not None:
                 seg = seg_all
         with _lib.on_device(dev):
+            reuse = 0
+            if ws is not None:
+                # the grid of the previous search on this stream is still in the workspace when that search had the
+                # very same support tensor, segments and radius (KPConv: last block of a level / strided block of the
+                # next one): skip the build
+                key = (x.data_ptr(), x._version, tuple(x.shape), float(radius), nclouds, nmax, ws.data_ptr(), seg.data_ptr())
+                slot = (dev.index, _lib.stream_ptr(dev))
+                prev = _grid_owner.get(slot)
+                # (the entry keeps the support tensor alive, so an equal address means the same storage, and an
+                #  equal version counter the same content)
+                reuse = int(prev is not None and prev[0] == key)
+                _grid_owner[slot] = (key, x)
             _lib.call("tp3d_ball_query_partial_dense_f32", _lib.ptr(x), _lib.ptr(y), _lib.ptr(bx), _lib.ptr(by),
                       x.shape[0], Nq, float(radius), int(nsample), int(bool(sort)), _lib.ptr(idx), _lib.ptr(d2),
-                      _lib.ptr(seg), nclouds, nmax, _lib.ptr(ws), ws_bytes, _lib.stream_ptr(dev))
+                      _lib.ptr(seg), nclouds, nmax, _lib.ptr(ws), ws_bytes, reuse, _lib.stream_ptr(dev))
         return idx, d2
     if m == "dense":
         if batch_x is not None or batch_y is not None:
@@ -112,6 +124,7 @@ def ball_query(radius, nsample, x, y, mode="dense", batch_x=None, batch_y=None, 
         idx = torch.empty((B, np_, nsample), dtype=torch.int64, device=dev)
         d2 = torch.empty((B, np_, nsample), dtype=torch.float32, device=dev)
         ws, ws_bytes = _lib.ball_query_workspace(B, B * N, N, dev)
+        _grid_owner.pop((dev.index, _lib.stream_ptr(dev)), None)  # the shared grid workspace is overwritten
         with _lib.on_device(dev):
             _lib.call("tp3d_ball_query_dense_f32", _lib.ptr(x), _lib.ptr(y), B, N, np_, float(radius), int(nsample),
                       int(bool(sort)), _lib.ptr(idx), _lib.ptr(d2), _lib.ptr(ws), ws_bytes, _lib.stream_ptr(dev))
@@ -120,6 +133,7 @@ def ball_query(radius, nsample, x, y, mode="dense", batch_x=None, batch_y=None, 
 
 
 _seg_cache = {}
+_grid_owner = {}  # (device, stream) -> identity of the search whose grid the "grid" workspace currently holds
 
 
 def _segments(bx):
@@ -176,6 +190,7 @@ def knn(k, x, y, batch_x=None, batch_y=None, cell=0.0):
         d2 = torch.empty((B, np_, k), dtype=torch.float32, device=dev)
         nbytes = _lib.load().tp3d_knn_workspace_bytes(B, B * N, N)
         ws = _lib.workspace("grid", nbytes, dev)
+        _grid_owner.pop((dev.index, _lib.stream_ptr(dev)), None)
         with _lib.on_device(dev):
             _lib.call("tp3d_knn_dense_f32", _lib.ptr(x), _lib.ptr(y), B, N, np_, k, float(cell), _lib.ptr(idx),
                       _lib.ptr(d2), _lib.ptr(ws), nbytes, _lib.stream_ptr(dev))
@@ -198,6 +213,7 @@ def knn(k, x, y, batch_x=None, batch_y=None, cell=0.0):
         return idx.fill_(-1), d2.fill_(-1.0)
     nbytes = _lib.load().tp3d_knn_workspace_bytes(nclouds, x.shape[0], max(nmax, 1))
     ws = _lib.workspace("grid", nbytes, dev)
+    _grid_owner.pop((dev.index, _lib.stream_ptr(dev)), None)  # the shared grid workspace is overwritten
     with _lib.on_device(dev):
         _lib.call("tp3d_knn_partial_dense_f32", _lib.ptr(x), _lib.ptr(y), _lib.ptr(by), _lib.ptr(seg), nclouds, nmax,
                   x.shape[0], Nq, k, float(cell), _lib.ptr(idx), _lib.ptr(d2), _lib.ptr(ws), nbytes,
