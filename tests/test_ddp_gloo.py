@@ -92,11 +92,14 @@ def _sharded_worker(rank, world, port, out):
     tr = ShardedStep(model, lambda ps: torch.optim.SGD(ps, lr=0.1),
                      lambda: torch.nn.functional.cross_entropy(model(pos[sl], x[sl]), y[sl]), world_size=world,
                      use_graph=False)
+    before = torch.cat([p.detach().reshape(-1) for p in model.parameters()]).clone()
     tr._forward_backward()
     tr._reduce()
-    grads = tr.flat.clone()
-    tr.opt.step()
+    grads = torch.cat([p.grad.reshape(-1) for p in tr.params]).clone()  # views into the (padded) flat buffer
+    assert tr.flat.numel() % 64 == 0 and int(tr.flat.count_nonzero()) == int(grads.count_nonzero())  # padding stays zero
+    tr.opt.step()  # ONE flat parameter inside the optimizer; the model's parameters are views of it
     weights = torch.cat([p.detach().reshape(-1) for p in model.parameters()])
+    assert torch.allclose(weights, before - 0.1 * grads, rtol=0, atol=1e-7)
     gathered = [torch.zeros_like(weights) for _ in range(world)]
     dist.all_gather(gathered, weights)
     if rank == 0:

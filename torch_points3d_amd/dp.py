@@ -17,8 +17,13 @@ import torch.distributed as dist
 
 
 class ShardedStep(object):
-    def __init__(self, model, make_optimizer, loss_fn, world_size=1, use_graph=True, log=None):
-        """loss_fn() -> scalar loss of this rank's shard (closes over static input tensors)."""
+    def __init__(self, model, make_optimizer, loss_fn, world_size=1, use_graph=True, log=None, flatten_params=True):
+        """loss_fn() -> scalar loss of this rank's shard (closes over static input tensors).
+
+        flatten_params: the parameters become views of ONE flat fp32 tensor that is handed to the optimizer as a
+        single parameter (with the flat gradient as its .grad): an element-wise optimizer such as Adam then runs as
+        ~10 kernels over 1.4 M elements instead of ~150 small ones over 56 tensors -- same arithmetic per element.
+        (Per-parameter options such as different weight decays need flatten_params=False.)"""
         self.model = model
         self.loss_fn = loss_fn
         self.world = world_size
@@ -26,13 +31,29 @@ class ShardedStep(object):
         params = [p for p in model.parameters() if p.requires_grad]
         dev = params[0].device
         self.params = params
-        self.flat = torch.zeros(sum(p.numel() for p in params), dtype=torch.float32, device=dev)
-        off = 0
+        # every parameter starts on a 256-byte boundary of the flat buffers (GEMM operands stay 16-byte aligned);
+        # the padding elements are zero in both the parameter and the gradient buffer, so they never move
+        align = 64
+        offsets, total = [], 0
         for p in params:
+            offsets.append(total)
+            total += (p.numel() + align - 1) // align * align
+        self.flat = torch.zeros(total, dtype=torch.float32, device=dev)
+        self._pads = [torch.zeros((o2 - o1) - p.numel(), dtype=torch.float32, device=dev)
+                      for p, o1, o2 in zip(params, offsets, offsets[1:] + [total])]
+        self.flat_param = None
+        if flatten_params:
+            init = torch.zeros(total, dtype=torch.float32, device=dev)
+            for p, off in zip(params, offsets):
+                init[off:off + p.numel()] = p.detach().reshape(-1).float()
+            self.flat_param = torch.nn.Parameter(init)
+            self.flat_param.grad = self.flat
+        for p, off in zip(params, offsets):
             n = p.numel()
-            p.grad = self.flat[off:off + n].view_as(p)  # the optimizer reads these views of the flat buffer
-            off += n
-        self.opt = make_optimizer(params)
+            if flatten_params:
+                p.data = self.flat_param.data[off:off + n].view_as(p)  # the model reads the optimizer's tensor
+            p.grad = self.flat[off:off + n].view_as(p)  # (per-parameter optimizers read these views)
+        self.opt = make_optimizer([self.flat_param] if flatten_params else params)
         self.graph_fb = None
         self.graph_opt = None
         self.graphed = False
@@ -43,7 +64,12 @@ class ShardedStep(object):
         loss = self.loss_fn()
         # fresh gradient tensors (no per-parameter "+=" kernels), packed into the flat buffer by one concatenation
         grads = torch.autograd.grad(loss, self.params)
-        torch.cat([g.reshape(-1) for g in grads], out=self.flat)
+        pieces = []
+        for g, pad in zip(grads, self._pads):
+            pieces.append(g.reshape(-1))
+            if pad.numel():
+                pieces.append(pad)
+        torch.cat(pieces, out=self.flat)
         return loss
 
     def _reduce(self):
