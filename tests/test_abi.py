@@ -74,7 +74,7 @@ def test_argument_errors_match_reference_conventions():
 
 def test_product_never_imports_the_oracle():
     pkg = os.path.join(ROOT, "torch_points3d_amd")
-    for base in (pkg, os.path.join(ROOT, "torch_points_kernels")):
+    for base in (pkg, os.path.join(ROOT, "torch_points_kernels"), os.path.join(ROOT, "tools")):
         for dirpath, _, files in os.walk(base):
             for f in files:
                 if f.endswith((".py", ".hip", ".h")):
