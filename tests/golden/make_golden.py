@@ -225,6 +225,104 @@ def make_kpconv_case():
     print("wrote %s (%.1f KiB)" % (path, os.path.getsize(path) / 1024.0))
 
 
+def make_kpconv_blocks_case():
+    """Partial-dense KPConv path through the REFERENCE's own block classes (modules/KPConv/blocks.py: SimpleBlock,
+    ResnetBBlock, KPDualBlock; core/base_conv/partial_dense.py: FPModule_PD; core/common_modules/base_modules.py: MLP,
+    FastBatchNorm1d) composed as applications/conf/kpconv/unet_4.yaml composes its first two levels and last decoder
+    stage (narrow widths).  Third-party pieces that are not installed are bound to the CPU oracle restatements:
+    torch_points_kernels.ball_query -> oracle/tpk_ref_cpu.c, GridSampling3D -> oracle/voxel_ref.py (the reference's
+    transform module needs torch_cluster), torch_geometric.knn_interpolate -> brute-force kNN + the published
+    inverse-squared-distance formula.  So the fixture pins the block LOGIC (radius rule, bottleneck, BatchNorm
+    momentum, strided shortcut, skip concatenation, kernel-point scaling) as the reference wrote it."""
+    from oracle import voxel_ref
+
+    class CpuGridSampling3D(object):
+        def __init__(self, size, quantize_coords=False, mode="mean", verbose=False):
+            self._grid_size = size
+
+        def __call__(self, data):
+            out = voxel_ref.grid_sampling_mean(data.pos.numpy(), self._grid_size, batch=data.batch.numpy(),
+                                               x=data.x.detach().numpy())
+            data.pos, data.batch = torch.from_numpy(out["pos"]), torch.from_numpy(out["batch"])
+            data.x = torch.from_numpy(out["x"])
+            return data
+
+    def knn_interpolate(x, pos_x, pos_y, batch_x=None, batch_y=None, k=3, num_workers=1):
+        idx, d2 = tpk_ref.knn(k, pos_x, pos_y, batch_x, batch_y)
+        Nq = pos_y.shape[0]
+        y_idx = torch.arange(Nq).repeat_interleave(k)
+        x_idx = idx.reshape(-1)
+        keep = x_idx >= 0
+        w = (1.0 / torch.clamp(d2.reshape(-1, 1), min=1e-16))[keep]
+        y_idx, x_idx = y_idx[keep], x_idx[keep]
+        num = torch.zeros(Nq, x.shape[1]).index_add_(0, y_idx, x[x_idx] * w)
+        return num / torch.zeros(Nq, 1).index_add_(0, y_idx, w)
+
+    class _BILM(torch.nn.Module):
+        pass
+
+    class _Data(_Bag):  # the reference blocks call data.clone()
+        def clone(self):
+            out = _Data()
+            for k, v in self.__dict__.items():
+                setattr(out, k, v.clone() if torch.is_tensor(v) else v)
+            return out
+
+    _stub("torch_points3d.core.data_transform", GridSampling3D=CpuGridSampling3D)
+    _stub("torch_points3d.models.base_model", BaseInternalLossModule=_BILM)
+    try:
+        import matplotlib  # noqa: F401
+    except Exception:
+        _stub("matplotlib").pyplot = _stub("matplotlib.pyplot")
+    sys.modules["torch_geometric.nn"].knn_interpolate = knn_interpolate
+    from torch_points3d.modules.KPConv.blocks import KPDualBlock
+    import torch_points3d.core.base_conv.partial_dense as ref_pd
+    import torch_points3d.core.spatial_ops.interpolate as ref_interp
+    ref_interp.knn_interpolate = knn_interpolate  # it was imported by name before the stub was replaced
+    ref_pd.Batch = _Data
+
+    g = torch.Generator().manual_seed(77)
+    N, grid, f = 1800, 0.04, 8
+    pos = torch.rand(N, 3, generator=g) * 0.7
+    batch = torch.sort(torch.randint(0, 2, (N,), generator=g))[0]
+    x = torch.cat([torch.ones(N, 1), torch.randn(N, 3, generator=g)], 1)
+    torch.manual_seed(5)
+    np.random.seed(5)  # the kernel-point disposition gets a random rotation (kernel_utils.py:251-280)
+    level0 = KPDualBlock(block_names=["SimpleBlock", "ResnetBBlock"], down_conv_nn=[[4, f], [f, 2 * f]],
+                         grid_size=[grid, grid], prev_grid_size=[grid, grid], has_bottleneck=[False, True],
+                         max_num_neighbors=[20, 20], deformable=[False, False], module_name="KPDualBlock", index=0)
+    level1 = KPDualBlock(block_names=["ResnetBBlock", "ResnetBBlock"], down_conv_nn=[[2 * f, 2 * f], [2 * f, 4 * f]],
+                         grid_size=[2 * grid, 2 * grid], prev_grid_size=[grid, 2 * grid], has_bottleneck=[True, True],
+                         max_num_neighbors=[20, 20], deformable=[False, False], module_name="KPDualBlock", index=1)
+    up = ref_pd.FPModule_PD(up_k=1, up_conv_nn=[4 * f + 2 * f, f], skip=True, bn_momentum=0.2, module_name="FPModule_PD",
+                            index=0)
+    net = torch.nn.ModuleDict({"level0": level0, "level1": level1, "up": up})
+    net.train()
+    state = {k: v.clone() for k, v in net.state_dict().items()}
+    xin = x.clone().requires_grad_(True)
+    d0 = level0(_Data(pos=pos, batch=batch, x=xin))
+    d1 = level1(d0)
+    out = up((d1, d0))
+    loss = (out.x * torch.linspace(-1.0, 1.0, f)).sum()
+    loss.backward()
+    arrays = {"pos": pos, "batch": batch, "x": x, "grid": torch.tensor([grid]), "width": torch.tensor([f]),
+              "l0_x": d0.x, "l0_idx": d0.idx_neighboors, "l1_pos": d1.pos, "l1_batch": d1.batch, "l1_x": d1.x,
+              "l1_idx": d1.idx_neighboors, "out_x": out.x, "loss": loss.reshape(1), "grad_x": xin.grad}
+    for k, v in state.items():
+        arrays["sd." + k] = v
+    for k, v in net.state_dict().items():
+        if "running_" in k:
+            arrays["after." + k] = v
+    for k, p in net.named_parameters():
+        if p.grad is not None:
+            arrays["grad." + k] = p.grad
+    path = os.path.join(HERE, "kpconv_blocks.npz")
+    np.savez_compressed(path, **to_np(arrays))
+    print("wrote %s (%.1f KiB): levels %d -> %d points, neighbour slots filled %.0f%% / %.0f%%" % (
+        path, os.path.getsize(path) / 1024.0, N, d1.pos.shape[0], 100 * float((d0.idx_neighboors >= 0).float().mean()),
+        100 * float((d1.idx_neighboors >= 0).float().mean())))
+
+
 def main():
     install_stubs()
     make_kpconv_case()
@@ -266,6 +364,9 @@ def main():
                innermost=[24 + 20 + 3, 32, 48], up_conv_nn=[[48 + 44, 32, 32], [32 + 28, 24, 24], [24 + 3, 16, 16]],
                normalize_xyz=[False, False], save_sampling_id=[False, False])
     make_case("small_msg", msg, 3, 5, pos, feats, seed=11, store_weights=True)
+
+    # (4) KPConv blocks + FPModule_PD through the reference's own classes (last: it replaces further modules by stubs)
+    make_kpconv_blocks_case()
 
 
 if __name__ == "__main__":
