@@ -12,8 +12,10 @@ data is fed exactly like the reference's MultiScaleTransform path (blocks.py:71-
 file of the reference is not shipped: `kernel_points` (KP, 3, unit scale; scaled by the kernel radius = 1.5 * point
 influence, kernels.py:35,51) defaults to kpconv.default_kernel_points(); the reference additionally applies a random
 rotation at construction (kernel_utils.py:251-280); a checkpoint's `K_points` overrides either choice on load.
-Parity: unpinned (the reference block file cannot be imported here: it needs torch_cluster); the convolution inside is
-pinned by tests/golden/kpconv_ops.npz.
+Parity: pinned by tests/golden/kpconv_blocks.npz -- the reference's own KPDualBlock / ResnetBBlock / SimpleBlock (and
+FPModule_PD) run in the build container on top of the CPU oracle (tests/golden/make_golden.py); its state_dict loads
+strictly into these classes and outputs, neighbour tables, running statistics and gradients are compared
+(tests/test_gpu_kpconv_golden.py).  The convolution itself is pinned by tests/golden/kpconv_ops.npz.
 """
 import copy
 import weakref
