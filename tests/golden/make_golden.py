@@ -323,6 +323,97 @@ def make_kpconv_blocks_case():
         100 * float((d1.idx_neighboors >= 0).float().mean())))
 
 
+def make_grid_sampling_case():
+    """GridSampling3D through the REFERENCE's own transform code (core/data_transform/grid_transform.py:33-141:
+    `group_data`, `GridSampling3D._process`), loaded by file path.  Its third-party calls (torch_cluster.grid_cluster,
+    torch_geometric voxel_grid / consecutive_cluster, torch_scatter scatter_mean / scatter_add) are bound to the
+    numpy restatements of oracle/voxel_ref.py, so the fixture pins the transform's own logic: which attributes are
+    grouped how (mean / majority vote over one-hot sums / representative point / bool round trip), `coords`,
+    `grid_size`, untouched attributes."""
+    import importlib.util
+    from oracle import voxel_ref
+
+    class Data(object):  # the slice of torch_geometric.data.Data the transform touches
+        def __init__(self, **kw):
+            for k, v in kw.items():
+                setattr(self, k, v)
+
+        @property
+        def keys(self):
+            return [k for k, v in self.__dict__.items() if v is not None]
+
+        @property
+        def num_nodes(self):
+            return self.pos.shape[0]
+
+        def __iter__(self):
+            for k in list(self.keys):
+                yield k, getattr(self, k)
+
+        def __contains__(self, k):
+            return k in self.keys
+
+        def __getitem__(self, k):
+            return getattr(self, k)
+
+        def __setitem__(self, k, v):
+            setattr(self, k, v)
+
+    def grid_cluster(pos, size, start=None, end=None):
+        return torch.from_numpy(voxel_ref.grid_cluster_key(pos.numpy()))
+
+    def voxel_grid(pos, batch, size, start=None, end=None):
+        return torch.from_numpy(voxel_ref.grid_cluster_key(pos.numpy(), batch.numpy()))
+
+    def consecutive_cluster(src):
+        inv, perm = voxel_ref.consecutive_cluster(src.numpy())
+        return torch.from_numpy(inv), torch.from_numpy(perm)
+
+    def scatter_mean(src, index, dim=0, dim_size=None):
+        K = int(index.max()) + 1
+        if src.is_floating_point():
+            return torch.from_numpy(voxel_ref.scatter_mean(src.numpy(), index.numpy(), K))
+        sums = torch.zeros((K,) + tuple(src.shape[1:]), dtype=src.dtype).index_add_(0, index, src)
+        cnt = torch.bincount(index, minlength=K).clamp(min=1).reshape((-1,) + (1,) * (src.dim() - 1))
+        return torch.div(sums, cnt, rounding_mode="floor")  # torch_scatter: floor division for integer inputs
+
+    def scatter_add(src, index, dim=0, dim_size=None):
+        K = int(index.max()) + 1
+        return torch.zeros((K,) + tuple(src.shape[1:]), dtype=src.dtype).index_add_(0, index, src)
+
+    sys.modules["torch_scatter"].scatter_mean = scatter_mean
+    sys.modules["torch_scatter"].scatter_add = scatter_add
+    sys.modules["torch_geometric.nn.pool.consecutive"].consecutive_cluster = consecutive_cluster
+    sys.modules["torch_geometric.nn"].voxel_grid = voxel_grid
+    sys.modules["torch_geometric.data"].Data = Data
+    _stub("torch_cluster", grid_cluster=grid_cluster)
+    spec = importlib.util.spec_from_file_location(
+        "ref_grid_transform", os.path.join(REF, "torch_points3d/core/data_transform/grid_transform.py"))
+    gt = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gt)
+
+    g = torch.Generator().manual_seed(31)
+    N = 3000
+    pos = torch.rand(N, 3, generator=g) * 0.5
+    batch = torch.sort(torch.randint(0, 3, (N,), generator=g))[0]
+    x = torch.randn(N, 5, generator=g)
+    y = torch.randint(-1, 6, (N,), generator=g)
+    inst = torch.randint(0, 40, (N,), generator=g)
+    flag = torch.rand(N, generator=g) < 0.3
+    origin_id = torch.arange(N)
+    arrays = {"pos": pos, "batch": batch, "x": x, "y": y, "instance_labels": inst, "flag": flag, "size": torch.tensor([0.06])}
+    out = gt.GridSampling3D(0.06, quantize_coords=True, mode="mean")(
+        Data(pos=pos.clone(), batch=batch.clone(), x=x.clone(), y=y.clone(), instance_labels=inst.clone(),
+             flag=flag.clone(), origin_id=origin_id, scalar=torch.tensor([7.0])))
+    for k in ("pos", "batch", "x", "y", "instance_labels", "flag", "origin_id", "coords", "grid_size", "scalar"):
+        arrays["out." + k] = getattr(out, k)
+    nb = gt.GridSampling3D(0.1, mode="mean")(Data(pos=pos.clone(), x=x.clone()))  # no batch attribute
+    arrays["nobatch.pos"], arrays["nobatch.x"] = nb.pos, nb.x
+    path = os.path.join(HERE, "grid_sampling.npz")
+    np.savez_compressed(path, **to_np(arrays))
+    print("wrote %s (%.1f KiB): %d -> %d voxels" % (path, os.path.getsize(path) / 1024.0, N, out.pos.shape[0]))
+
+
 def main():
     install_stubs()
     make_kpconv_case()
@@ -367,6 +458,7 @@ def main():
 
     # (4) KPConv blocks + FPModule_PD through the reference's own classes (last: it replaces further modules by stubs)
     make_kpconv_blocks_case()
+    make_grid_sampling_case()
 
 
 if __name__ == "__main__":

@@ -127,3 +127,27 @@ def test_cluster_counts_per_cloud():
     assert counts.tolist() == np.bincount(batch[ref_perm], minlength=6).tolist() and counts[2] == 0
     c1 = gs.voxel_cluster(torch.from_numpy(pos).to(DEV), None, 0.07, return_counts=True)[4]
     assert c1.tolist() == [len(np.unique(voxel_ref.grid_cluster_key(voxel_ref.voxel_coords(pos, 0.07), None)))]
+
+
+def test_matches_reference_transform_golden():
+    """tests/golden/grid_sampling.npz was produced by the reference's own GridSampling3D / group_data code
+    (core/data_transform/grid_transform.py, loaded by file path in tests/golden/make_golden.py with its third-party
+    calls bound to oracle/voxel_ref.py): every grouped attribute must come out identically."""
+    from conftest import load_golden
+    from torch_points3d_amd.grid_sampling import GridSampling3D
+    from torch_points3d_amd.kpconv_blocks import PDData
+    g = load_golden("grid_sampling")
+    size = float(g["size"][0])
+    dev = lambda k: g[k].to(DEV)  # noqa: E731
+    data = PDData(pos=dev("pos"), batch=dev("batch"), x=dev("x"), y=dev("y"), instance_labels=dev("instance_labels"),
+                  flag=dev("flag"), origin_id=torch.arange(g["pos"].shape[0], device=DEV),
+                  scalar=torch.tensor([7.0], device=DEV))
+    out = GridSampling3D(size, quantize_coords=True, mode="mean")(data)
+    for k in ("pos", "batch", "x", "y", "instance_labels", "flag", "origin_id", "coords", "scalar"):
+        got, ref = getattr(out, k).cpu(), g["out." + k]
+        assert got.shape == ref.shape, k
+        assert torch.equal(got.to(ref.dtype), ref), k
+    assert out.coords.dtype == torch.int32 and out.flag.dtype == torch.bool
+    assert float(out.grid_size[0]) == pytest.approx(float(g["out.grid_size"][0]))
+    nb = GridSampling3D(0.1, mode="mean")(PDData(pos=dev("pos"), x=dev("x")))
+    assert torch.equal(nb.pos.cpu(), g["nobatch.pos"]) and torch.equal(nb.x.cpu(), g["nobatch.x"])

@@ -9,8 +9,10 @@ voxel-clustering entry points of libtp3d_hip.so instead (include/tp3d_hip.h, csr
 
 Works on any attribute bag (`PDData`, the reference's torch_geometric `Data`): every tensor attribute whose first
 dimension equals the number of points is grouped, the rest is carried over.
-Parity: unpinned against torch_cluster (absent); pinned against oracle/voxel_ref.py (a numpy restatement of the
-published algorithm) and the reference's own test properties (test/test_grid_sampling.py:29-67).
+Parity: the transform's own logic (which attribute is grouped how, coords, bool / label handling) is pinned by
+tests/golden/grid_sampling.npz, produced by the reference's grid_transform.py itself; the third-party arithmetic under
+it (torch_cluster / torch_scatter, absent) is unpinned and replaced by oracle/voxel_ref.py, a numpy restatement of the
+published algorithms, checked against the reference's own test properties (test/test_grid_sampling.py:29-67).
 """
 import re
 
