@@ -53,6 +53,7 @@ def main():
     ap.add_argument("--ratio", type=float, default=0.25)
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--check", type=int, default=2000)
+    ap.add_argument("--conv", action="store_true", help="also time one RandlaConv forward (first layer of randlanet.yaml)")
     args = ap.parse_args()
     from torch_points3d_amd import torchpoints as tp
     from torch_points3d_amd.randla import RandomSampler
@@ -104,6 +105,25 @@ def main():
             ok = ok and bool(torch.equal(best, got_d)) and bool(torch.equal(torch.gather(dall, 1, got_i), got_d))
         out["checked"] = int(sel.numel())
         out["exact"] = ok
+    if args.conv:
+        # first down-convolution of conf/models/segmentation/randlanet.yaml (Randlanet_Conv): ratio 0.25, k 16,
+        # FEAT = 3 input features
+        from torch_points3d_amd.kpconv_blocks import PDData
+        from torch_points3d_amd.randla import RandlaConv
+        feat = 3
+        conv = RandlaConv(ratio=args.ratio, k=args.k, point_pos_nn=[10, 8, feat], attention_nn=[2 * feat, 8, 2 * feat],
+                          down_conv_nn=[2 * feat, 8, 16]).to(dev).eval()
+        x = torch.randn(args.n, feat, device=dev)
+        with torch.no_grad():
+            for _ in range(2):
+                conv(PDData(pos=pos, batch=batch, x=x))
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(args.iters):
+                o = conv(PDData(pos=pos, batch=batch, x=x))
+            torch.cuda.synchronize()
+        out["randla_conv_ms"] = round((time.perf_counter() - t0) * 1e3 / args.iters, 3)
+        out["edges"] = int(o.neighbors.numel())
     print(json.dumps(out))
 
 

@@ -10,10 +10,11 @@
 // and accept once the k-th distance is inside the largest ball that is certainly covered by the visited cells
 // (distance to the nearest face of the block that still has cells behind it, shrunk by 0.1 % for the fp32 rounding
 // of the cell coordinate).  Exact by construction: any point outside the block is farther than that ball.
-// k == 1 never touches LDS (running wave arg-min).  k > 1 streams the block's points through a 1024-slot candidate
-// buffer per wave; when it fills up it is compacted to its k smallest pairs and their largest distance becomes an
+// k == 1 never touches LDS (running wave arg-min).  2 <= k <= 64 keeps the 64 best pairs in registers (one per lane)
+// and merges batches of 64 admitted candidates with a wave-wide bitonic network; the current k-th best is the
 // admission threshold, so over-populated cells (surfaces scanned much denser than the grid assumes) cost a scan of
-// their points but never an overflow.  k > 128 falls back to a selection scan of the whole cloud.
+// their points and little else.  64 < k <= 128 streams through a 1024-slot LDS buffer compacted by successive
+// selection; k > 128 falls back to a selection scan of the whole cloud.
 #include "grid.h"
 
 namespace tp3d {
@@ -130,6 +131,91 @@ __global__ __launch_bounds__(KQ_BLOCK) void grid_knn_kernel(
                 return;
             }
             continue;
+        }
+
+        if (k <= 64) {
+            // ---- 2 <= k <= 64: the best 64 pairs live in registers, one per lane, ascending.  Candidates that beat
+            // the current k-th best (`tau`) are staged 64 at a time in LDS, bitonic-sorted across the wave and merged:
+            // min(best[l], staged[63 - l]) holds the 64 smallest of the union as a bitonic sequence, six more
+            // compare-exchange stages sort it.  After the first batch few points pass `tau`, so a query costs the
+            // scan of its cells plus two or three merges.
+            float bd = 3.0e38f;   // lane l: l-th best so far
+            int bi = 0x7fffffff;
+            int staged = 0, total = 0;
+            auto exchange = [&](float &d, int &i, int stride, bool up) {
+                const float od = __shfl_xor(d, stride);
+                const int oi = __shfl_xor(i, stride);
+                const bool lower = (lane & stride) == 0;           // this lane keeps the smaller pair when `up`
+                const bool take = pair_less(od, oi, d, i) == (lower == up);
+                if (take) {
+                    d = od;
+                    i = oi;
+                }
+            };
+            auto flush = [&]() {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                __builtin_amdgcn_wave_barrier();
+                float sdv = lane < staged ? cd[lane] : 3.0e38f;
+                int siv = lane < staged ? cid[lane] : 0x7fffffff;
+#pragma unroll
+                for (int size = 2; size <= 64; size <<= 1)
+#pragma unroll
+                    for (int stride = size >> 1; stride >= 1; stride >>= 1)
+                        exchange(sdv, siv, stride, (lane & size) == 0);  // size == 64: every lane ascending
+                const float rd = __shfl(sdv, 63 - lane);
+                const int ri = __shfl(siv, 63 - lane);
+                if (pair_less(rd, ri, bd, bi)) {
+                    bd = rd;
+                    bi = ri;
+                }
+#pragma unroll
+                for (int stride = 32; stride >= 1; stride >>= 1) exchange(bd, bi, stride, true);
+                total = min(total + staged, 64);
+                staged = 0;
+                if (total >= kk) tau = __shfl(bd, kk - 1);
+                __builtin_amdgcn_wave_barrier();
+            };
+            for (int zz = z0; zz <= z1; ++zz)
+                for (int yy = y0; yy <= y1; ++yy) {
+                    const int rowbase = (zz * gi.gy + yy) * gi.gx;
+                    const int j0 = cs[rowbase + x0], j1 = cs[rowbase + x1 + 1];
+                    for (int j = j0; j < j1; j += 64) {
+                        const int t = j + lane;
+                        const bool valid = t < j1;
+                        const int tt = valid ? t : j0;
+                        const float d = sqdist3(sorted_xyz[(lo + tt) * 3 + 0], sorted_xyz[(lo + tt) * 3 + 1],
+                                                sorted_xyz[(lo + tt) * 3 + 2], qx, qy, qz);
+                        const int id = sorted_id[lo + tt];
+                        bool keep = valid && d <= tau;
+                        unsigned long long mask = __ballot(keep);
+                        if (!mask) continue;
+                        if (staged + __builtin_popcountll(mask) > 64) {
+                            flush();
+                            keep = keep && d <= tau;
+                            mask = __ballot(keep);
+                            if (!mask) continue;
+                        }
+                        if (keep) {
+                            const int slot = staged + lanes_below(mask);
+                            cd[slot] = d;
+                            cid[slot] = id;
+                        }
+                        staged += __builtin_popcountll(mask);
+                    }
+                }
+            if (staged) flush();
+            if (total < kk && !whole) continue;
+            const int emit = min(total, kk);
+            const float worst = emit ? __shfl(bd, emit - 1) : 0.0f;
+            if (!whole && !(worst <= cover2)) continue;  // the k-th neighbour may still lie outside the block: widen
+            if (lane < emit) {
+                io[lane] = goff + bi;
+                dd[lane] = bd;
+            } else if (lane < k) {
+                io[lane] = -1;
+                dd[lane] = -1.0f;
+            }
+            return;
         }
 
         // ---- k > 1: stream the block's points through the candidate buffer.  Once the buffer would overflow it is
