@@ -31,8 +31,8 @@ GridPlan grid_plan(int Lmax);
 struct GridWorkspace {
     GridInfo *info;    // [clouds]
     int *cell_start;   // [clouds][G^3 + 1], offsets relative to the cloud's first row
-    int *sorted_id;    // [rows] cloud-local point id of each cell-ordered slot
-    float *sorted_xyz; // [rows][3] cell-ordered copy of the coordinates
+    float4 *sorted_pt; // [rows] cell-ordered copy of the points: (x, y, z, cloud-local point id as int bits) --
+                       // one 16-byte load per candidate in the query kernels
     // sort-based build only
     int *bbox;                              // [clouds][6] order-preserving int images of min/max
     unsigned long long *keys_in, *keys_out; // [rows]

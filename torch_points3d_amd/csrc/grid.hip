@@ -52,8 +52,7 @@ __global__ __launch_bounds__(GB_BLOCK) void grid_build_kernel(const float *__res
                                                                int N, float radius, float target, int G,
                                                                GridInfo *__restrict__ info,
                                                                int *__restrict__ cell_start /*[B][G^3+1]*/,
-                                                               int *__restrict__ sorted_id /*[rows]*/,
-                                                               float *__restrict__ sorted_xyz /*[rows][3]*/)
+                                                               float4 *__restrict__ sorted_pt /*[rows]*/)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ float s_red[6][GB_BLOCK / 64];
@@ -162,10 +161,7 @@ __global__ __launch_bounds__(GB_BLOCK) void grid_build_kernel(const float *__res
     //  output does not depend on it)
     for (int t = tid; t < L; t += GB_BLOCK) {
         const int j = ord[t];
-        sorted_id[lo + t] = j;
-        sorted_xyz[(lo + t) * 3 + 0] = p[(size_t)j * 3 + 0];
-        sorted_xyz[(lo + t) * 3 + 1] = p[(size_t)j * 3 + 1];
-        sorted_xyz[(lo + t) * 3 + 2] = p[(size_t)j * 3 + 2];
+        sorted_pt[lo + t] = make_float4(p[(size_t)j * 3 + 0], p[(size_t)j * 3 + 1], p[(size_t)j * 3 + 2], __int_as_float(j));
     }
 }
 
@@ -174,8 +170,8 @@ __global__ __launch_bounds__(GB_BLOCK) void grid_build_kernel(const float *__res
 __global__ __launch_bounds__(GQ_BLOCK) void grid_query_kernel(
     const float *__restrict__ x, const float *__restrict__ y, const int64_t *__restrict__ seg,
     const int64_t *__restrict__ batch_y, int64_t total_q, int N, int np, int num_clouds, float r2, int nsample, int sort,
-    int G, const GridInfo *__restrict__ info, const int *__restrict__ cell_start, const int *__restrict__ sorted_id,
-    const float *__restrict__ sorted_xyz, int64_t *__restrict__ idx, float *__restrict__ dist2)
+    int G, const GridInfo *__restrict__ info, const int *__restrict__ cell_start,
+    const float4 *__restrict__ sorted_pt, int64_t *__restrict__ idx, float *__restrict__ dist2)
 {
     __shared__ int s_id[GQ_BLOCK / 64][GQ_CAP];
     __shared__ float s_d[GQ_BLOCK / 64][GQ_CAP];
@@ -214,35 +210,39 @@ __global__ __launch_bounds__(GQ_BLOCK) void grid_query_kernel(
     bool overflow = false;
     const int x0 = max(cx - 1, 0), x1 = min(cx + 1, gi.gx - 1);
     if (x0 <= x1) {
-        for (int dz = -1; dz <= 1 && !overflow; ++dz) {
-            const int zz = cz + dz;
-            if (zz < 0 || zz >= gi.gz) continue;
-            for (int dy = -1; dy <= 1 && !overflow; ++dy) {
-                const int yy = cy + dy;
-                if (yy < 0 || yy >= gi.gy) continue;
+        // the nine (z, y) rows around the query are contiguous x-runs of <= 3 cells: lanes 0..8 fetch their slot
+        // ranges at once (one load latency instead of nine), the loop reads them back with v_readlane
+        int j0v = 0, j1v = 0;
+        if (lane < 9) {
+            const int zz = cz + lane / 3 - 1, yy = cy + lane % 3 - 1;
+            if (zz >= 0 && zz < gi.gz && yy >= 0 && yy < gi.gy) {
                 const int rowbase = (zz * gi.gy + yy) * gi.gx;
-                const int j0 = cs[rowbase + x0], j1 = cs[rowbase + x1 + 1];  // one contiguous run of <= 3 cells
-                for (int j = j0; j < j1; j += 64) {
-                    const int t = j + lane;
-                    const bool valid = t < j1;
-                    const int tt = valid ? t : j0;
-                    const float d = sqdist3(sorted_xyz[(lo + tt) * 3 + 0], sorted_xyz[(lo + tt) * 3 + 1],
-                                            sorted_xyz[(lo + tt) * 3 + 2], qx, qy, qz);
-                    const bool hit = valid && d < r2;
-                    const unsigned long long mask = __ballot(hit);
-                    if (mask) {
-                        const int cntm = __builtin_popcountll(mask);
-                        if (h + cntm > GQ_CAP) {
-                            overflow = true;
-                            break;
-                        }
-                        if (hit) {
-                            const int slot = h + lanes_below(mask);
-                            cid[slot] = sorted_id[lo + tt];
-                            cd[slot] = d;
-                        }
-                        h += cntm;
+                j0v = cs[rowbase + x0];
+                j1v = cs[rowbase + x1 + 1];
+            }
+        }
+        for (int rr = 0; rr < 9 && !overflow; ++rr) {
+            const int j0 = __builtin_amdgcn_readlane(j0v, rr), j1 = __builtin_amdgcn_readlane(j1v, rr);
+            for (int j = j0; j < j1; j += 64) {
+                const int t = j + lane;
+                const bool valid = t < j1;
+                const int tt = valid ? t : j0;
+                const float4 pt = sorted_pt[lo + tt];
+                const float d = sqdist3(pt.x, pt.y, pt.z, qx, qy, qz);
+                const bool hit = valid && d < r2;
+                const unsigned long long mask = __ballot(hit);
+                if (mask) {
+                    const int cntm = __builtin_popcountll(mask);
+                    if (h + cntm > GQ_CAP) {
+                        overflow = true;
+                        break;
                     }
+                    if (hit) {
+                        const int slot = h + lanes_below(mask);
+                        cid[slot] = __float_as_int(pt.w);
+                        cd[slot] = d;
+                    }
+                    h += cntm;
                 }
             }
         }
@@ -457,17 +457,14 @@ __global__ __launch_bounds__(GG_BLOCK) void gridg_fill_kernel(const float *__res
                                                                int N, int G, int64_t rows,
                                                                const unsigned long long *__restrict__ keys,
                                                                const unsigned int *__restrict__ vals,
-                                                               int *__restrict__ sorted_id, float *__restrict__ sorted_xyz)
+                                                               float4 *__restrict__ sorted_pt)
 {
     const int64_t t = (int64_t)blockIdx.x * GG_BLOCK + threadIdx.x;
     if (t >= rows) return;
     const int64_t row = vals[t];
     const int b = (int)(keys[t] / (unsigned long long)(G * G * G));
     const int64_t lo = seg ? seg[b] : (int64_t)b * N;
-    sorted_id[t] = (int)(row - lo);
-    sorted_xyz[t * 3 + 0] = x[row * 3 + 0];
-    sorted_xyz[t * 3 + 1] = x[row * 3 + 1];
-    sorted_xyz[t * 3 + 2] = x[row * 3 + 2];
+    sorted_pt[t] = make_float4(x[row * 3 + 0], x[row * 3 + 1], x[row * 3 + 2], __int_as_float((int)(row - lo)));
 }
 
 // grid = (cell chunks, clouds): cell_start[b][c] = first slot (cloud-relative) whose key is >= cell c
@@ -543,10 +540,8 @@ GridWorkspace carve_grid_workspace(void *ws, int num_clouds, int64_t rows, GridP
     off += up((size_t)num_clouds * sizeof(GridInfo));
     w.cell_start = reinterpret_cast<int *>(p + off);
     off += up((size_t)num_clouds * ((size_t)G * G * G + 1) * 4);
-    w.sorted_id = reinterpret_cast<int *>(p + off);
-    off += up((size_t)rows * 4);
-    w.sorted_xyz = reinterpret_cast<float *>(p + off);
-    off += up((size_t)rows * 12);
+    w.sorted_pt = reinterpret_cast<float4 *>(p + off);
+    off += up((size_t)rows * 16);
     w.bbox = nullptr;
     w.keys_in = w.keys_out = nullptr;
     w.vals_in = w.vals_out = nullptr;
@@ -581,7 +576,7 @@ int grid_build(const float *x, const int64_t *seg, int num_clouds, int64_t rows,
         static bool attr_set[64] = {false};
         allow_large_dynamic_lds(reinterpret_cast<const void *>(&grid_build_kernel), (int)GRID_LDS_BUDGET, attr_set);
         hipLaunchKernelGGL(grid_build_kernel, dim3(num_clouds), dim3(GB_BLOCK), lds, s, x, seg, N, cell, target, G, w.info,
-                           w.cell_start, w.sorted_id, w.sorted_xyz);
+                           w.cell_start, w.sorted_pt);
         return check_launch();
     }
     if (rows >= 0x7fffffff || num_clouds > 65535) return TP3D_E_TOOBIG;
@@ -599,7 +594,7 @@ int grid_build(const float *x, const int64_t *seg, int num_clouds, int64_t rows,
     if (int rc = sort_pairs_u64_u32(w.sort_tmp, w.sort_tmp_bytes, w.keys_in, w.keys_out, w.vals_in, w.vals_out, rows, bits, s))
         return rc;
     hipLaunchKernelGGL(gridg_fill_kernel, dim3((unsigned)((rows + GG_BLOCK - 1) / GG_BLOCK)), dim3(GG_BLOCK), 0, s, x, seg,
-                       N, G, rows, w.keys_out, w.vals_out, w.sorted_id, w.sorted_xyz);
+                       N, G, rows, w.keys_out, w.vals_out, w.sorted_pt);
     const unsigned cchunks = (unsigned)(((size_t)G * G * G + 1 + GG_BLOCK - 1) / GG_BLOCK);
     hipLaunchKernelGGL(gridg_cellstart_kernel, dim3(cchunks, num_clouds), dim3(GG_BLOCK), 0, s, seg, N, G, w.info,
                        w.keys_out, w.cell_start);
@@ -621,8 +616,8 @@ int grid_ball_query(const float *x, const float *y, const int64_t *seg, const in
     const int64_t blocks = (total_q + GQ_BLOCK / 64 - 1) / (GQ_BLOCK / 64);
     if (blocks > 0x7fffffff) return TP3D_E_TOOBIG;
     hipLaunchKernelGGL(grid_query_kernel, dim3((unsigned)blocks), dim3(GQ_BLOCK), 0, s, x, y, seg, batch_y, total_q, N,
-                       np, num_clouds, radius * radius, nsample, sort, plan.G, w.info, w.cell_start, w.sorted_id,
-                       w.sorted_xyz, idx, dist2);
+                       np, num_clouds, radius * radius, nsample, sort, plan.G, w.info, w.cell_start, w.sorted_pt,
+                       idx, dist2);
     return check_launch();
 }
 

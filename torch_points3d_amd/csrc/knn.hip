@@ -38,16 +38,21 @@ __device__ __forceinline__ void wave_argmin(float &d, int &i)
     }
 }
 
+// MODE 0: k == 1;  MODE 1: 2 <= k <= 64;  MODE 2: 64 < k (LDS candidate buffer).  The mode only sizes the LDS arrays
+// (none / 64 staging slots / 1024 + 128 slots per wave), i.e. how many waves fit a CU to hide the load latencies.
+template <int MODE>
 __global__ __launch_bounds__(KQ_BLOCK) void grid_knn_kernel(
     const float *__restrict__ x, const float *__restrict__ y, const int64_t *__restrict__ seg,
     const int64_t *__restrict__ batch_y, int64_t total_q, int N, int np, int num_clouds, int k, int G,
-    const GridInfo *__restrict__ info, const int *__restrict__ cell_start, const int *__restrict__ sorted_id,
-    const float *__restrict__ sorted_xyz, int64_t *__restrict__ idx, float *__restrict__ dist2)
+    const GridInfo *__restrict__ info, const int *__restrict__ cell_start, const float4 *__restrict__ sorted_pt,
+    int64_t *__restrict__ idx, float *__restrict__ dist2)
 {
-    __shared__ int s_id[KQ_BLOCK / 64][KQ_CAP];
-    __shared__ float s_d[KQ_BLOCK / 64][KQ_CAP];
-    __shared__ int s_si[KQ_BLOCK / 64][KQ_KMAX];
-    __shared__ float s_sd[KQ_BLOCK / 64][KQ_KMAX];
+    constexpr int CAP = MODE == 2 ? KQ_CAP : (MODE == 1 ? 64 : 1);
+    constexpr int STG = MODE == 2 ? KQ_KMAX : 1;
+    __shared__ int s_id[KQ_BLOCK / 64][CAP];
+    __shared__ float s_d[KQ_BLOCK / 64][CAP];
+    __shared__ int s_si[KQ_BLOCK / 64][STG];
+    __shared__ float s_sd[KQ_BLOCK / 64][STG];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t q = (int64_t)blockIdx.x * (KQ_BLOCK / 64) + wave;
     if (q >= total_q) return;  // wave-uniform; the kernel has no workgroup barrier
@@ -88,7 +93,7 @@ __global__ __launch_bounds__(KQ_BLOCK) void grid_knn_kernel(
     const int kk = min(k, L);
     float tau = 3.0e38f;  // upper bound of the k-th distance once kk candidates are known
 
-    for (; k <= KQ_KMAX; ++R) {
+    for (; MODE != 2 || k <= KQ_KMAX; ++R) {
         const int x0 = max(cx - R, 0), x1 = min(cx + R, gi.gx - 1);
         const int y0 = max(cy - R, 0), y1 = min(cy + R, gi.gy - 1);
         const int z0 = max(cz - R, 0), z1 = min(cz + R, gi.gz - 1);
@@ -103,24 +108,39 @@ __global__ __launch_bounds__(KQ_BLOCK) void grid_knn_kernel(
         if (z1 < gi.gz - 1) cover = fminf(cover, (float)(cz + R + 1) - uz);
         cover = cover * cell * 0.999f;
         const float cover2 = cover * cover;
+        // The block's (z, y) rows are contiguous x-runs of the cell-ordered copy.  Their slot ranges are fetched 64
+        // rows at a time, one row per lane, and handed out by v_readlane: one load latency per ring instead of one
+        // per row.
+        auto for_each_run = [&](auto &&body) {
+            const int ny = y1 - y0 + 1, nrows = (z1 - z0 + 1) * ny;
+            for (int r0 = 0; r0 < nrows; r0 += 64) {
+                const int r = r0 + lane;
+                int j0v = 0, j1v = 0;
+                if (r < nrows) {
+                    const int rowbase = ((z0 + r / ny) * gi.gy + (y0 + r % ny)) * gi.gx;
+                    j0v = cs[rowbase + x0];
+                    j1v = cs[rowbase + x1 + 1];
+                }
+                const int cnt = min(64, nrows - r0);
+                for (int rr = 0; rr < cnt; ++rr)
+                    body(__builtin_amdgcn_readlane(j0v, rr), __builtin_amdgcn_readlane(j1v, rr));
+            }
+        };
 
-        if (k == 1) {
+        if (MODE == 0) {
             float bd = 3.0e38f;
             int bi = 0x7fffffff;
-            for (int zz = z0; zz <= z1; ++zz)
-                for (int yy = y0; yy <= y1; ++yy) {
-                    const int rowbase = (zz * gi.gy + yy) * gi.gx;
-                    const int j0 = cs[rowbase + x0], j1 = cs[rowbase + x1 + 1];
-                    for (int j = j0 + lane; j < j1; j += 64) {
-                        const float d = sqdist3(sorted_xyz[(lo + j) * 3 + 0], sorted_xyz[(lo + j) * 3 + 1],
-                                                sorted_xyz[(lo + j) * 3 + 2], qx, qy, qz);
-                        const int id = sorted_id[lo + j];
-                        if (pair_less(d, id, bd, bi)) {
-                            bd = d;
-                            bi = id;
-                        }
+            for_each_run([&](int j0, int j1) {
+                for (int j = j0 + lane; j < j1; j += 64) {
+                    const float4 pt = sorted_pt[lo + j];
+                    const float d = sqdist3(pt.x, pt.y, pt.z, qx, qy, qz);
+                    const int id = __float_as_int(pt.w);
+                    if (pair_less(d, id, bd, bi)) {
+                        bd = d;
+                        bi = id;
                     }
                 }
+            });
             wave_argmin(bd, bi);
             const bool found = bi != 0x7fffffff;
             if (whole || (found && bd <= cover2)) {  // `whole` always ends the search (found unless the input is NaN)
@@ -133,7 +153,7 @@ __global__ __launch_bounds__(KQ_BLOCK) void grid_knn_kernel(
             continue;
         }
 
-        if (k <= 64) {
+        if (MODE == 1) {
             // ---- 2 <= k <= 64: the best 64 pairs live in registers, one per lane, ascending.  Candidates that beat
             // the current k-th best (`tau`) are staged 64 at a time in LDS, bitonic-sorted across the wave and merged:
             // min(best[l], staged[63 - l]) holds the 64 smallest of the union as a bitonic sequence, six more
@@ -175,34 +195,31 @@ __global__ __launch_bounds__(KQ_BLOCK) void grid_knn_kernel(
                 if (total >= kk) tau = __shfl(bd, kk - 1);
                 __builtin_amdgcn_wave_barrier();
             };
-            for (int zz = z0; zz <= z1; ++zz)
-                for (int yy = y0; yy <= y1; ++yy) {
-                    const int rowbase = (zz * gi.gy + yy) * gi.gx;
-                    const int j0 = cs[rowbase + x0], j1 = cs[rowbase + x1 + 1];
-                    for (int j = j0; j < j1; j += 64) {
-                        const int t = j + lane;
-                        const bool valid = t < j1;
-                        const int tt = valid ? t : j0;
-                        const float d = sqdist3(sorted_xyz[(lo + tt) * 3 + 0], sorted_xyz[(lo + tt) * 3 + 1],
-                                                sorted_xyz[(lo + tt) * 3 + 2], qx, qy, qz);
-                        const int id = sorted_id[lo + tt];
-                        bool keep = valid && d <= tau;
-                        unsigned long long mask = __ballot(keep);
+            for_each_run([&](int j0, int j1) {
+                for (int j = j0; j < j1; j += 64) {
+                    const int t = j + lane;
+                    const bool valid = t < j1;
+                    const int tt = valid ? t : j0;
+                    const float4 pt = sorted_pt[lo + tt];
+                    const float d = sqdist3(pt.x, pt.y, pt.z, qx, qy, qz);
+                    const int id = __float_as_int(pt.w);
+                    bool keep = valid && d <= tau;
+                    unsigned long long mask = __ballot(keep);
+                    if (!mask) continue;
+                    if (staged + __builtin_popcountll(mask) > 64) {
+                        flush();
+                        keep = keep && d <= tau;
+                        mask = __ballot(keep);
                         if (!mask) continue;
-                        if (staged + __builtin_popcountll(mask) > 64) {
-                            flush();
-                            keep = keep && d <= tau;
-                            mask = __ballot(keep);
-                            if (!mask) continue;
-                        }
-                        if (keep) {
-                            const int slot = staged + lanes_below(mask);
-                            cd[slot] = d;
-                            cid[slot] = id;
-                        }
-                        staged += __builtin_popcountll(mask);
                     }
+                    if (keep) {
+                        const int slot = staged + lanes_below(mask);
+                        cd[slot] = d;
+                        cid[slot] = id;
+                    }
+                    staged += __builtin_popcountll(mask);
                 }
+            });
             if (staged) flush();
             if (total < kk && !whole) continue;
             const int emit = min(total, kk);
@@ -258,34 +275,31 @@ __global__ __launch_bounds__(KQ_BLOCK) void grid_knn_kernel(
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             __builtin_amdgcn_wave_barrier();
         };
-        for (int zz = z0; zz <= z1; ++zz)
-            for (int yy = y0; yy <= y1; ++yy) {
-                const int rowbase = (zz * gi.gy + yy) * gi.gx;
-                const int j0 = cs[rowbase + x0], j1 = cs[rowbase + x1 + 1];
-                for (int j = j0; j < j1; j += 64) {
-                    const int t = j + lane;
-                    const bool valid = t < j1;
-                    const int tt = valid ? t : j0;
-                    const float d = sqdist3(sorted_xyz[(lo + tt) * 3 + 0], sorted_xyz[(lo + tt) * 3 + 1],
-                                            sorted_xyz[(lo + tt) * 3 + 2], qx, qy, qz);
-                    const int id = sorted_id[lo + tt];
-                    bool keep = valid && d <= tau;
-                    unsigned long long mask = __ballot(keep);
+        for_each_run([&](int j0, int j1) {
+            for (int j = j0; j < j1; j += 64) {
+                const int t = j + lane;
+                const bool valid = t < j1;
+                const int tt = valid ? t : j0;
+                const float4 pt = sorted_pt[lo + tt];
+                const float d = sqdist3(pt.x, pt.y, pt.z, qx, qy, qz);
+                const int id = __float_as_int(pt.w);
+                bool keep = valid && d <= tau;
+                unsigned long long mask = __ballot(keep);
+                if (!mask) continue;
+                if (h + __builtin_popcountll(mask) > KQ_CAP) {
+                    compact();
+                    keep = keep && d <= tau;
+                    mask = __ballot(keep);
                     if (!mask) continue;
-                    if (h + __builtin_popcountll(mask) > KQ_CAP) {
-                        compact();
-                        keep = keep && d <= tau;
-                        mask = __ballot(keep);
-                        if (!mask) continue;
-                    }
-                    if (keep) {
-                        const int slot = h + lanes_below(mask);
-                        cd[slot] = d;
-                        cid[slot] = id;
-                    }
-                    h += __builtin_popcountll(mask);
                 }
+                if (keep) {
+                    const int slot = h + lanes_below(mask);
+                    cd[slot] = d;
+                    cid[slot] = id;
+                }
+                h += __builtin_popcountll(mask);
             }
+        });
         if (h < kk && !whole) continue;
         compact();  // the kk (or all h) smallest pairs, sorted, at the front of the buffer
         const int emit = h;
@@ -378,8 +392,13 @@ int grid_knn(const float *x, const float *y, const int64_t *seg, const int64_t *
     if (int rc = grid_build(x, seg, num_clouds, rows, N, Lmax, cell, target, plan, w, s)) return rc;
     const int64_t blocks = (total_q + KQ_BLOCK / 64 - 1) / (KQ_BLOCK / 64);
     if (blocks > 0x7fffffff) return TP3D_E_TOOBIG;
-    hipLaunchKernelGGL(grid_knn_kernel, dim3((unsigned)blocks), dim3(KQ_BLOCK), 0, s, x, y, seg, batch_y, total_q, N, np,
-                       num_clouds, k, plan.G, w.info, w.cell_start, w.sorted_id, w.sorted_xyz, idx, dist2);
+    auto launch = [&](auto kernel) {
+        hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(KQ_BLOCK), 0, s, x, y, seg, batch_y, total_q, N, np,
+                           num_clouds, k, plan.G, w.info, w.cell_start, w.sorted_pt, idx, dist2);
+    };
+    if (k == 1) launch(grid_knn_kernel<0>);
+    else if (k <= 64) launch(grid_knn_kernel<1>);
+    else launch(grid_knn_kernel<2>);
     return check_launch();
 }
 
