@@ -219,7 +219,21 @@ __global__ void nbr_sort_kernel(const int *__restrict__ start, int64_t M, int *_
     }
 }
 
-// Inverse of a neighbour table: for every support point m the slots (q*Mn + n) that reference it, ascending.
+// Inverse of an index table over any number of workgroups: for every bin m the slots that reference it, ascending
+// (integer histogram -> scan -> fill -> per-bin insertion sort of its short run).  Entries outside [0, M) are skipped.
+// cnt, cursor: M ints; start: M + 1 ints; order: `slots` ints.
+int invert_table(const int64_t *idx, int64_t slots, int64_t M, int *cnt, int *start, int *cursor, int *order,
+                 hipStream_t s)
+{
+    if (int rc = zero_async(cnt, (size_t)M * 4, s)) return rc;
+    const unsigned gs = (unsigned)std::min<int64_t>((slots + 255) / 256, 4096);
+    hipLaunchKernelGGL(nbr_hist_kernel, dim3(gs), dim3(256), 0, s, idx, slots, M, cnt);
+    hipLaunchKernelGGL(nbr_scan_kernel, dim3(1), dim3(1024), 0, s, cnt, M, start, cursor);
+    hipLaunchKernelGGL(nbr_fill_kernel, dim3(gs), dim3(256), 0, s, idx, slots, M, cursor, order);
+    hipLaunchKernelGGL(nbr_sort_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, s, start, M, order);
+    return check_launch();
+}
+
 // workspace: tp3d_kpconv_bwd_workspace_bytes(M, slots)
 static int invert_neighbors(const int64_t *neighbors, int64_t slots, int64_t M, void *workspace, int **start_out,
                             int **order_out, hipStream_t s)
@@ -230,15 +244,9 @@ static int invert_neighbors(const int64_t *neighbors, int64_t slots, int64_t M, 
     int *start = reinterpret_cast<int *>(p + up((size_t)M * 4));
     int *cursor = reinterpret_cast<int *>(p + up((size_t)M * 4) + up((size_t)(M + 1) * 4));
     int *order = reinterpret_cast<int *>(p + up((size_t)M * 4) + up((size_t)(M + 1) * 4) + up((size_t)M * 4));
-    if (int rc = zero_async(cnt, (size_t)M * 4, s)) return rc;
-    const unsigned gs = (unsigned)std::min<int64_t>((slots + 255) / 256, 4096);
-    hipLaunchKernelGGL(nbr_hist_kernel, dim3(gs), dim3(256), 0, s, neighbors, slots, M, cnt);
-    hipLaunchKernelGGL(nbr_scan_kernel, dim3(1), dim3(1024), 0, s, cnt, M, start, cursor);
-    hipLaunchKernelGGL(nbr_fill_kernel, dim3(gs), dim3(256), 0, s, neighbors, slots, M, cursor, order);
-    hipLaunchKernelGGL(nbr_sort_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, s, start, M, order);
     *start_out = start;
     *order_out = order;
-    return check_launch();
+    return invert_table(neighbors, slots, M, cnt, start, cursor, order, s);
 }
 
 // Strided shortcut of ResnetBBlock (reference modules/KPConv/blocks.py:206-210): max over each query's neighbours of

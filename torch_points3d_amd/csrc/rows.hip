@@ -542,6 +542,19 @@ TP3D_EXPORT int tp3d_group_concat_fwd_f32(const float *pos, const float *new_pos
     return check_launch();
 }
 
+namespace tp3d {
+// order[j] (slot id) -> row id (slot / div); wsorted[j] = weight[slot]; only the first start[nbins] entries are real
+__global__ void slots_to_rows_kernel(int *__restrict__ order, const float *__restrict__ weight, int div, int L,
+                                     const int *__restrict__ start, int nbins, float *__restrict__ wsorted)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= L || j >= start[nbins]) return;
+    const int slot = order[j];
+    if (wsorted) wsorted[j] = weight[slot];
+    order[j] = slot / div;
+}
+}  // namespace tp3d
+
 TP3D_EXPORT int tp3d_rows_scatter_bwd_f32(const float *grad_rows, const int64_t *idx, const float *weight, int B,
                                           int L, int div, int nbins, int ld, int col0, int C, float *grad_x_cl,
                                           void *workspace, size_t workspace_bytes, void *stream)
@@ -555,7 +568,16 @@ TP3D_EXPORT int tp3d_rows_scatter_bwd_f32(const float *grad_rows, const int64_t 
     if (!grad_rows || !idx || !workspace || B > 65535) return TP3D_E_BADARG;
     ScatterWorkspace w = carve_scatter_workspace(workspace, B, L, nbins, weight != nullptr);
     if (workspace_bytes < w.bytes) return TP3D_E_BADARG;
-    if (int rc = csr_transpose(idx, B, L, nbins, div, weight, w.start, w.order, w.wsorted, w.scratch, s)) return rc;
+    if (B == 1 && L >= 16384 && L >= 2 * nbins) {
+        // one large cloud (partial-dense decoders): the per-cloud transpose would be a single workgroup; invert the
+        // table over the whole device instead (scratch holds the histogram and the cursors), then turn slot ids into
+        // row ids and line the weights up with them
+        if (int rc = invert_table(idx, L, nbins, w.scratch, w.start, w.scratch + nbins, w.order, s)) return rc;
+        hipLaunchKernelGGL(slots_to_rows_kernel, dim3((L + 255) / 256), dim3(256), 0, s, w.order, weight, div, L, w.start,
+                           nbins, w.wsorted);
+    } else if (int rc = csr_transpose(idx, B, L, nbins, div, weight, w.start, w.order, w.wsorted, w.scratch, s)) {
+        return rc;
+    }
     dim3 grid((nbins + RW_BLOCK / 64 - 1) / (RW_BLOCK / 64), B);
     hipLaunchKernelGGL(rows_gather_sum_kernel, grid, dim3(RW_BLOCK), 0, s, grad_rows, w.start, w.order, w.wsorted,
                        nbins, L, L / div, ld, col0, C, grad_x_cl);

@@ -71,6 +71,10 @@ int csr_transpose(const int64_t *idx, int B, int L, int nbins, int div, const fl
 int gather_sum(const float *rows, const int *start, const int *order, const float *wsorted, int B, int C, int nbins,
                int Lrow, int Lslots, float *out, hipStream_t s);
 
+// kpconv.hip: multi-workgroup inverse of an index table (cnt, cursor: M ints; start: M + 1; order: slots)
+int invert_table(const int64_t *idx, int64_t slots, int64_t M, int *cnt, int *start, int *cursor, int *order,
+                 hipStream_t s);
+
 // grid.hip: uniform-grid radius search (build + query); seg/batch_y null => dense layout (more in grid.h)
 int grid_ball_query(const float *x, const float *y, const int64_t *seg, const int64_t *batch_y, int num_clouds,
                     int64_t rows, int N, int np, int64_t total_q, int Lmax, float radius, int nsample, int sort,
