@@ -241,3 +241,43 @@ def test_gemm_rows_matches_fp64_and_stats(M, N, K):
     Bi = torch.randint(-3, 4, (K, N), generator=g).float().to(DEV)
     Ci, _ = fused.gemm_rows(Ai, Bi.t().contiguous())
     assert torch.equal(Ci, torch.mm(Ai.double(), Bi.double()).float())
+
+
+@pytest.mark.parametrize("train", [True, False])
+def test_rows_mlp_with_linear_bias_matches_modules(train):
+    """The reference's partial-dense MLP keeps the Linear bias in front of BatchNorm (base_modules.py:29-43): the fused
+    row kernels run the GEMM without it and account for it in the running mean (training) or the affine shift (eval)."""
+    import copy
+    from torch_points3d_amd import fused
+    from torch_points3d_amd.partial_dense import MLP
+    torch.manual_seed(0)
+    mlp = MLP([12, 128, 20], bn_momentum=0.1, bias=True).to(DEV)
+    with torch.no_grad():
+        for m in mlp.modules():
+            if isinstance(m, torch.nn.BatchNorm1d):
+                m.running_mean.normal_()
+                m.running_var.uniform_(0.5, 2.0)
+            if isinstance(m, torch.nn.Linear):
+                m.bias.normal_()
+    ref = copy.deepcopy(mlp)
+    mlp.train(train)
+    ref.train(train)
+    x = torch.randn(5000, 12, device=DEV)
+    xa, xb = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+    g = torch.randn(5000, 20, device=DEV)
+    out = fused.rows_mlp(mlp, xa)
+    want = ref(xb)
+    out.backward(g)
+    want.backward(g)
+    torch.testing.assert_close(out, want, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(xa.grad, xb.grad, rtol=1e-3, atol=1e-4 * float(xb.grad.abs().max()))
+    for (k, a), (_, b) in zip(mlp.state_dict().items(), ref.state_dict().items()):
+        torch.testing.assert_close(a.float(), b.float(), rtol=1e-4, atol=1e-5, msg=lambda m, k=k: k + ": " + m)
+    for (k, a), (_, b) in zip(mlp.named_parameters(), ref.named_parameters()):
+        if train and k.endswith("0.bias"):
+            # a bias in front of batch-statistics BatchNorm has an exactly zero gradient; autograd through the plain
+            # modules leaves the rounding residue of a sum that cancels
+            assert float(a.grad.abs().max()) == 0.0 and float(b.grad.abs().max()) < 1e-3, k
+            continue
+        scale = float(b.grad.abs().max()) + 1e-6
+        torch.testing.assert_close(a.grad, b.grad, rtol=1e-3, atol=1e-4 * scale + 1e-5, msg=lambda m, k=k: k + ": " + m)

@@ -97,12 +97,13 @@ def gemm_rows(A, Bt, want_stats=False):
 
 
 
-def _bn_stats(Y, M, C, gamma, beta, bn, training, dev, st):
+def _bn_stats(Y, M, C, gamma, beta, bn, training, dev, st, bias=None):
     """(4, C) = mean, invstd, scale, shift of BatchNorm over the rows of Y.  In eval mode they depend only on the
     module's parameters and running statistics, so they are computed once and reused until any of those changes."""
     key = None
     if not training:
-        key = tuple((t.data_ptr(), t._version) for t in (gamma, beta, bn.running_mean, bn.running_var))
+        key = tuple((t.data_ptr(), t._version) for t in (gamma, beta, bn.running_mean, bn.running_var)
+                    + ((bias,) if bias is not None else ()))
         hit = getattr(bn, "_tp3d_eval_stats", None)
         if hit is not None and hit[0] == key:
             return hit[1]
@@ -112,6 +113,9 @@ def _bn_stats(Y, M, C, gamma, beta, bn, training, dev, st):
               _lib.ptr(bn.running_mean), _lib.ptr(bn.running_var), int(training), _lib.ptr(stats[0]), _lib.ptr(stats[1]),
               _lib.ptr(stats[2]), _lib.ptr(stats[3]), _lib.ptr(ws), st)
     if key is not None:
+        if bias is not None:
+            stats[3].addcmul_(stats[2], bias.detach())  # shift += scale * bias: act(scale * (Y + b) + shift)
+            stats[0].sub_(bias.detach())                # yhat = (Y + b - running_mean) * invstd in the backward pass
         bn._tp3d_eval_stats = (key, stats)
     return stats
 
@@ -120,7 +124,10 @@ class _LinearBNAct(torch.autograd.Function):
     """out = LeakyReLU(BatchNorm(A @ W^T)) on rows; with pool_ns > 0 also the max over groups of pool_ns rows."""
 
     @staticmethod
-    def forward(ctx, A, weight, gamma, beta, bn, slope, pool_ns):
+    def forward(ctx, A, weight, gamma, beta, bn, slope, pool_ns, bias=None):
+        # bias: the Linear's bias (reference MLP default, core/common_modules/base_modules.py:29-43).  The GEMM runs
+        # without it: under batch statistics it cancels in the normalised output (it only shifts the running mean);
+        # with running statistics it folds into the affine shift.
         dev = A.device
         A = A.contiguous()
         M, Kp = A.shape  # Kp >= Cin: producers pad rows with zero columns to a multiple of 4 floats
@@ -149,7 +156,7 @@ class _LinearBNAct(torch.autograd.Function):
                           _lib.ptr(bn.running_var), _lib.ptr(stats[0]), _lib.ptr(stats[1]), _lib.ptr(stats[2]),
                           _lib.ptr(stats[3]), st)
             else:
-                stats = _bn_stats(Y, M, Cout, gamma, beta, bn, training, dev, st)
+                stats = _bn_stats(Y, M, Cout, gamma, beta, bn, training, dev, st, bias)
             if pool_ns:
                 G = M // pool_ns
                 out = torch.empty((G, Cout), dtype=torch.float32, device=dev)
@@ -163,14 +170,16 @@ class _LinearBNAct(torch.autograd.Function):
                           _lib.ptr(out), st)
         if training:
             bn.num_batches_tracked.add_(1)
+            if bias is not None:
+                bn.running_mean.add_(bias.detach(), alpha=float(bn.momentum))  # the kernels saw the mean without it
         ctx.save_for_backward(A, W2, Y, stats, arg)
-        ctx.cfg = (slope, pool_ns, training, tuple(weight.shape), Cin)
+        ctx.cfg = (slope, pool_ns, training, tuple(weight.shape), Cin, bias is not None)
         return out
 
     @staticmethod
     def backward(ctx, grad_out):
         A, W2, Y, stats, arg = ctx.saved_tensors
-        slope, pool_ns, training, wshape, Cin = ctx.cfg
+        slope, pool_ns, training, wshape, Cin, has_bias = ctx.cfg
         dev = grad_out.device
         grad_out = grad_out.contiguous()
         M, Cout = Y.shape
@@ -186,7 +195,11 @@ class _LinearBNAct(torch.autograd.Function):
         # input gradient: nothing to fuse into its epilogue, and the library GEMM is 10-25 % faster than the rows
         # kernel on these shapes (same measurement), so it stays a plain library GEMM
         dA = torch.mm(dY, W2) if ctx.needs_input_grad[0] else None
-        return dA, dW, dgb[1], dgb[0], None, None, None
+        dbias = None
+        if has_bias and ctx.needs_input_grad[7]:
+            # batch statistics remove the bias from the output (gradient exactly zero); running statistics do not
+            dbias = torch.zeros(Y.shape[1], dtype=torch.float32, device=dev) if training else dY.sum(0)
+        return dA, dW, dgb[1], dgb[0], None, None, None, dbias
 
 
 
@@ -272,7 +285,7 @@ def nbr_maxpool(x, nbr):
 
 
 def linear_bn_act(A, conv, bn, slope, pool_ns=0):
-    return _LinearBNAct.apply(A, conv.weight, bn.weight, bn.bias, bn, slope, pool_ns)
+    return _LinearBNAct.apply(A, conv.weight, bn.weight, bn.bias, bn, slope, pool_ns, getattr(conv, "bias", None))
 
 
 
@@ -285,9 +298,9 @@ def _bn1d_of(m):
 
 
 def seq_parts(seq):
-    """(linear, bn1d, slope) of nn.Sequential(Linear(bias=False), BatchNorm[, activation]) or None."""
+    """(linear, bn1d, slope) of nn.Sequential(Linear, BatchNorm[, activation]) or None."""
     mods = list(seq.children()) if isinstance(seq, nn.Sequential) else []
-    if len(mods) not in (2, 3) or not isinstance(mods[0], nn.Linear) or mods[0].bias is not None:
+    if len(mods) not in (2, 3) or not isinstance(mods[0], nn.Linear):
         return None
     bn = _bn1d_of(mods[1])
     slope = _slope_of(mods[2] if len(mods) == 3 else None)

@@ -17,6 +17,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import fused as _fused
 from . import torchpoints as _tp
 from .kpconv_blocks import PDData
 from .partial_dense import MLP
@@ -66,11 +67,11 @@ class RandlaKernel(nn.Module):
         x_j = pos_j if x is None else x[j]
         vij = pos_i - pos_j
         dij = torch.norm(vij, dim=1).unsqueeze(1)
-        rij = self.point_pos_nn(torch.cat([pos_i, pos_j, vij, dij], dim=1))
+        rij = _fused.rows_mlp(self.point_pos_nn, torch.cat([pos_i, pos_j, vij, dij], dim=1))
         fij_hat = torch.cat([x_j, rij], dim=1)
-        s_ij = F.softmax(self.attention_nn(fij_hat), -1)
+        s_ij = F.softmax(_fused.rows_mlp(self.attention_nn, fij_hat), -1)
         msg = s_ij * fij_hat
-        return self.global_nn(msg.reshape(Nq, k, -1).sum(dim=1))
+        return _fused.rows_mlp(self.global_nn, msg.reshape(Nq, k, -1).sum(dim=1))
 
 
 class RandlaConv(nn.Module):
