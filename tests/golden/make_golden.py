@@ -414,6 +414,40 @@ def make_grid_sampling_case():
     print("wrote %s (%.1f KiB): %d -> %d voxels" % (path, os.path.getsize(path) / 1024.0, N, out.pos.shape[0]))
 
 
+def make_unet4_config_case():
+    """applications/conf/kpconv/unet_4.yaml resolved the way the reference resolves it
+    (utils/model_building_utils/model_definition_resolver.py:22-51: every string leaf is eval()'d with FEAT and the
+    file's define_constants; applications/modelfactory.py overrides in_grid_size / in_feat from the factory arguments):
+    the architecture table torch_points3d_amd.kpconv_unet.unet_config must reproduce."""
+    import json
+    import yaml
+    with open(os.path.join(REF, "torch_points3d/applications/conf/kpconv/unet_4.yaml")) as f:
+        cfg = yaml.safe_load(f)
+
+    def resolve(obj, constants):
+        if isinstance(obj, dict):
+            return {k: resolve(v, constants) for k, v in obj.items()}
+        if isinstance(obj, list):
+            return [resolve(v, constants) for v in obj]
+        if isinstance(obj, str):
+            try:
+                return eval(obj, dict(constants))
+            except (NameError, ValueError, SyntaxError):
+                return obj
+        return obj
+
+    out = {}
+    for feat, in_feat, grid in ((3, 64, 0.02), (1, 32, 0.05)):
+        constants = dict(cfg["define_constants"])
+        constants.update({"FEAT": feat, "in_feat": in_feat, "in_grid_size": grid})
+        out["feat%d_infeat%d_grid%g" % (feat, in_feat, grid)] = {
+            "down_conv": resolve(cfg["down_conv"], constants), "up_conv": resolve(cfg["up_conv"], constants)}
+    path = os.path.join(HERE, "kpconv_unet4_config.json")
+    with open(path, "w") as f:
+        json.dump(out, f, indent=1, sort_keys=True)
+    print("wrote %s" % path)
+
+
 def main():
     install_stubs()
     make_kpconv_case()
@@ -459,6 +493,7 @@ def main():
     # (4) KPConv blocks + FPModule_PD through the reference's own classes (last: it replaces further modules by stubs)
     make_kpconv_blocks_case()
     make_grid_sampling_case()
+    make_unet4_config_case()
 
 
 if __name__ == "__main__":
