@@ -244,7 +244,8 @@ def main():
     pos, x, y = make_inputs(B_PER_GPU, N_POINTS, 1234 + rank, device)
     use_graph = not args.no_graph
     trainer = ShardedStep(model, lambda params: torch.optim.Adam(params, lr=1e-3, capturable=use_graph),
-                          lambda: F.cross_entropy(model(pos, x), y), world_size=world, use_graph=use_graph, log=log)
+                          lambda: F.cross_entropy(model(pos, x), y), world_size=world, use_graph=use_graph, log=log,
+                          reduce_always=multi)
     log("model built; warm-up")
     graphed = trainer.warmup_and_capture(args.warmup)
     torch.cuda.synchronize()

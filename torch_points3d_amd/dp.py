@@ -17,7 +17,8 @@ import torch.distributed as dist
 
 
 class ShardedStep(object):
-    def __init__(self, model, make_optimizer, loss_fn, world_size=1, use_graph=True, log=None, flatten_params=True):
+    def __init__(self, model, make_optimizer, loss_fn, world_size=1, use_graph=True, log=None, flatten_params=True,
+                 reduce_always=False):
         """loss_fn() -> scalar loss of this rank's shard (closes over static input tensors).
 
         flatten_params: the parameters become views of ONE flat fp32 tensor that is handed to the optimizer as a
@@ -27,6 +28,7 @@ class ShardedStep(object):
         self.model = model
         self.loss_fn = loss_fn
         self.world = world_size
+        self.reduce_always = reduce_always  # issue the collective even on one rank (rehearsal of the N > 1 path)
         self.log = log or (lambda msg: None)
         params = [p for p in model.parameters() if p.requires_grad]
         dev = params[0].device
@@ -73,7 +75,7 @@ class ShardedStep(object):
         return loss
 
     def _reduce(self):
-        if self.world > 1:
+        if self.world > 1 or self.reduce_always:
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
             self.flat.div_(self.world)
 
@@ -97,11 +99,12 @@ class ShardedStep(object):
                     self._eager_step()
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
+            # thread-local capture mode: RCCL's watchdog thread may poll events while this thread captures
             g1 = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g1):
+            with torch.cuda.graph(g1, capture_error_mode="thread_local"):
                 self._forward_backward()
             g2 = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g2):
+            with torch.cuda.graph(g2, capture_error_mode="thread_local"):
                 self.opt.step()
             torch.cuda.synchronize()
             self.graph_fb, self.graph_opt, self.graphed = g1, g2, True
