@@ -223,3 +223,40 @@ def test_grid_is_reused_only_for_the_same_support_and_radius(hip, oracle):
     # recorded integer arguments of the entry point: (M, Nq, nsample, sort, clouds, largest, workspace bytes, reuse, stream)
     reuse = [a[-2] for (name, a), _, _ in timer.records if name == "tp3d_ball_query_partial_dense_f32"]
     assert reuse == [0, 1, 0, 0, 0]
+
+
+def test_knn_and_neighbour_ops_on_empty_inputs(hip):
+    from torch_points3d_amd.fused import nbr_maxpool
+    from torch_points3d_amd.partial_dense import knn_interpolate
+    x = torch.rand(50, 3, device=DEV)
+    empty = torch.empty(0, 3, device=DEV)
+    bx = torch.zeros(50, dtype=torch.long, device=DEV)
+    be = torch.zeros(0, dtype=torch.long, device=DEV)
+    idx, d2 = hip.knn(4, x, empty, bx, be)                  # no queries
+    assert idx.shape == (0, 4) and d2.shape == (0, 4)
+    idx, d2 = hip.knn(4, empty, x, be, bx)                  # no support at all
+    assert idx.shape == (50, 4) and bool((idx == -1).all()) and bool((d2 == -1).all())
+    idx, d2 = hip.knn(3, x, x, bx, bx + 1)                  # the queries' cloud holds no support point
+    assert bool((idx == -1).all())
+    idx, d2 = hip.knn(1, x, x, bx, bx)
+    assert torch.equal(idx[:, 0].cpu(), torch.arange(50)) and float(d2.abs().max()) == 0.0
+    out = nbr_maxpool(torch.rand(50, 8, device=DEV), torch.empty(0, 5, dtype=torch.long, device=DEV))
+    assert out.shape == (0, 8)
+    # interpolation without a skip tensor and with a single support point
+    feats = torch.randn(1, 6, device=DEV)
+    y = knn_interpolate(feats, x[:1], x, bx[:1], bx, k=3)
+    torch.testing.assert_close(y, feats.expand(50, 6), rtol=1e-6, atol=1e-6)
+
+
+def test_fp_module_pd_global_innermost_on_device():
+    from torch_points3d_amd.kpconv_blocks import PDData
+    from torch_points3d_amd.partial_dense import FPModule_PD
+    torch.manual_seed(0)
+    N = 300
+    batch = torch.sort(torch.randint(0, 3, (N,)))[0].to(DEV)
+    skip = PDData(pos=torch.rand(N, 3, device=DEV), x=torch.randn(N, 4, device=DEV), batch=batch)
+    pooled = PDData(pos=torch.zeros(3, 3, device=DEV), x=torch.randn(3, 6, device=DEV), batch=torch.arange(3, device=DEV))
+    fp = FPModule_PD(1, [10, 5], bn_momentum=0.1).to(DEV).eval()
+    out = fp((pooled, skip))
+    want = fp.nn(torch.cat([pooled.x[batch], skip.x], dim=1))
+    torch.testing.assert_close(out.x, want, rtol=1e-5, atol=1e-5)
