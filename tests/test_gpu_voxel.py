@@ -151,3 +151,31 @@ def test_matches_reference_transform_golden():
     assert float(out.grid_size[0]) == pytest.approx(float(g["out.grid_size"][0]))
     nb = GridSampling3D(0.1, mode="mean")(PDData(pos=dev("pos"), x=dev("x")))
     assert torch.equal(nb.pos.cpu(), g["nobatch.pos"]) and torch.equal(nb.x.cpu(), g["nobatch.x"])
+
+
+def test_coordinate_bounds_hint_is_verified():
+    """An enclosing extent handed in by the caller replaces the device reduction's host read; a wrong one is detected
+    at the final read and the clustering is redone with the measured extent."""
+    from torch_points3d_amd import grid_sampling as gs
+    from torch_points3d_amd.grid_sampling import GridSampling3D
+    from torch_points3d_amd.kpconv_blocks import PDData
+    pos, batch = cloud(20000, 3, 5)
+    tp_, tb = torch.from_numpy(pos).to(DEV), torch.from_numpy(batch).to(DEV)
+    exact = gs.voxel_cluster(tp_, tb, 0.05, return_counts=True)
+    loose = gs.voxel_cluster(tp_, tb, 0.05, return_counts=True, coord_bounds=[-7, -3, -9, 40, 33, 29, 2])
+    wrong = gs.voxel_cluster(tp_, tb, 0.05, return_counts=True, coord_bounds=[0, 0, 0, 5, 5, 5, 0])
+    for other in (loose, wrong):
+        for a, b in zip(exact, other):
+            assert torch.equal(a.cpu(), b.cpu())
+    # two chained samplers: the second one runs on the bounds the first one attached
+    first = GridSampling3D(0.05)(PDData(pos=tp_, batch=tb, x=tp_.clone()))
+    assert first.pos_bounds is not None
+    second = GridSampling3D(0.1)(first.clone())
+    ref = voxel_ref.grid_sampling_mean(first.pos.cpu().numpy(), 0.1, batch=first.batch.cpu().numpy(), x=first.x.cpu().numpy())
+    assert np.array_equal(second.pos.cpu().numpy(), ref["pos"]) and np.array_equal(second.batch.cpu().numpy(), ref["batch"])
+    # positions moved after sampling (stale bounds): still correct
+    moved = first.clone()
+    moved.pos = moved.pos + 3.0
+    third = GridSampling3D(0.1)(moved)
+    ref = voxel_ref.grid_sampling_mean((first.pos + 3.0).cpu().numpy(), 0.1, batch=first.batch.cpu().numpy())
+    assert np.array_equal(third.pos.cpu().numpy(), ref["pos"])

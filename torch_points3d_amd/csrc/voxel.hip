@@ -115,7 +115,7 @@ __global__ __launch_bounds__(VX_BLOCK) void voxel_scatter_kernel(const unsigned 
                                                                   int64_t *__restrict__ cluster, int64_t *__restrict__ order,
                                                                   int64_t *__restrict__ cluster_start,
                                                                   int64_t *__restrict__ last,
-                                                                  const int64_t *__restrict__ batch,
+                                                                  const int64_t *__restrict__ batch, int64_t nb,
                                                                   unsigned long long *__restrict__ meta)
 {
     const int64_t i = (int64_t)blockIdx.x * VX_BLOCK + threadIdx.x;
@@ -128,7 +128,8 @@ __global__ __launch_bounds__(VX_BLOCK) void voxel_scatter_kernel(const unsigned 
     if (i == N - 1 || cid[i + 1] != c) last[c] = p;  // highest point index of the voxel (stable sort)
     // clusters are numbered cloud by cloud: the last slot of cloud b records how many clusters clouds 0..b hold
     const int64_t b = batch ? batch[p] : 0;
-    if (i == N - 1 || (batch && batch[vals[i + 1]] != b)) meta[1 + b] = (unsigned long long)c + 1;
+    // (b < nb: the caller's extent may be a hint that the host verifies afterwards; never write past meta)
+    if ((i == N - 1 || (batch && batch[vals[i + 1]] != b)) && b >= 0 && b < nb) meta[1 + b] = (unsigned long long)c + 1;
     if (i == N - 1) {
         cluster_start[c + 1] = N;
         meta[0] = (unsigned long long)c + 1;
@@ -330,7 +331,7 @@ TP3D_EXPORT int tp3d_voxel_cluster_f32(const float *pos, const int64_t *batch, i
         return rc;
     if (int rc = zero_async(meta, (size_t)(1 + nb) * sizeof(int64_t), s)) return rc;
     hipLaunchKernelGGL(voxel_scatter_kernel, dim3(blocks), dim3(VX_BLOCK), 0, s, w.vals_out, w.cid, N, cluster, order,
-                       cluster_start, last, batch, reinterpret_cast<unsigned long long *>(meta));
+                       cluster_start, last, batch, nb, reinterpret_cast<unsigned long long *>(meta));
     return check_launch();
 }
 

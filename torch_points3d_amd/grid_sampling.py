@@ -34,9 +34,12 @@ def _check(pos, batch):
         raise ValueError("batch must be (N,)")
 
 
-def voxel_cluster(pos, batch, size, return_counts=False):
+def voxel_cluster(pos, batch, size, return_counts=False, coord_bounds=None):
     """-> (cluster (N,), unique_pos_indices (K,), order (N,), cluster_start (K+1,)); all int64 on pos.device.
     With return_counts=True also the number of clusters of every cloud (host int64 tensor).
+    coord_bounds: optional host sequence (min x, y, z, max x, y, z of round(pos / size), highest batch id) known to
+    contain every point (e.g. derived from the bounding box of the cloud this one was sampled from); it replaces the
+    device reduction and its host read.  The key only needs an enclosing extent, so a loose bound changes nothing.
 
     cluster[i]: consecutive id of the voxel of point i (ids ascend with (batch, z, y, x) of the voxel);
     unique_pos_indices[c]: highest point index inside voxel c; order / cluster_start: members of voxel c are
@@ -56,7 +59,12 @@ def voxel_cluster(pos, batch, size, return_counts=False):
         s = _lib.stream_ptr(dev)
         bounds = torch.empty(8, dtype=torch.int32, device=dev)
         _lib.call("tp3d_voxel_bounds_f32", _lib.ptr(pos), _lib.ptr(batch), N, float(size), _lib.ptr(bounds), s)
-        bounds_host = np.ascontiguousarray(bounds.cpu().numpy())  # wait 1: extent of the voxel key
+        if coord_bounds is None:
+            bounds_host = np.ascontiguousarray(bounds.cpu().numpy())  # wait 1: extent of the voxel key
+        else:
+            # the caller's enclosing extent sizes the key; the true extent is still reduced on the device and is
+            # checked against it after the one host read at the end (no wait here)
+            bounds_host = np.ascontiguousarray(np.asarray(list(coord_bounds) + [0], dtype=np.int32))
         nbytes = _lib.load().tp3d_voxel_workspace_bytes(N)
         ws = _lib.workspace("voxel", nbytes, dev)
         cluster = torch.empty(N, dtype=torch.int64, device=dev)
@@ -68,9 +76,19 @@ def voxel_cluster(pos, batch, size, return_counts=False):
         _lib.call("tp3d_voxel_cluster_f32", _lib.ptr(pos), _lib.ptr(batch), N, float(size),
                   bounds_host.ctypes.data, _lib.ptr(cluster), _lib.ptr(order), _lib.ptr(start), _lib.ptr(last),
                   _lib.ptr(meta), _lib.ptr(ws), nbytes, s)
-        meta_host = meta.cpu()  # wait 2: number of occupied voxels (+ how many of them each cloud holds)
+        if coord_bounds is None:
+            meta_host = meta.cpu()  # wait 2: number of occupied voxels (+ how many of them each cloud holds)
+        else:
+            both = torch.cat([meta, bounds.to(torch.int64)]).cpu()  # the only wait on this path
+            meta_host, true_b = both[:meta.numel()], both[meta.numel():].numpy()
+            inside = (true_b[7] == 0 and all(true_b[a] >= bounds_host[a] for a in range(3))
+                      and all(true_b[3 + a] <= bounds_host[3 + a] for a in range(3))
+                      and (batch is None or true_b[6] <= bounds_host[6]))
+            if not inside:  # a stale or wrong hint: redo with the measured extent
+                return voxel_cluster(pos, batch, size, return_counts=return_counts)
         K = int(meta_host[0])
     out = (cluster, last[:K], order, start[:K + 1])
+    voxel_cluster.last_bounds = bounds_host  # (GridSampling3D hands the extent on to the next, coarser level)
     if not return_counts:
         return out
     ends = torch.cummax(meta_host[1:], 0)[0]  # running cluster count after each cloud (empty clouds recorded 0)
@@ -177,8 +195,26 @@ class GridSampling3D(object):
         if self._mode == "last":
             data = shuffle_data(data)
         batch = getattr(data, "batch", None)
-        cluster, unique_pos_indices, order, cluster_start, counts = voxel_cluster(data.pos, batch, self._grid_size,
-                                                                                  return_counts=True)
+        # a cloud produced by a previous GridSampling3D carries the bounding box of its ancestors' voxel coordinates
+        # (`pos_bounds`, host floats): voxel means stay inside it, so the key extent needs no device reduction here
+        hint = None
+        pb = getattr(data, "pos_bounds", None)
+        if pb is not None and data.pos.shape[0] > 0:
+            size = float(self._grid_size)
+            nb = 0
+            if batch is not None:
+                from . import torchpoints as _tp
+                nb = _tp._segments(_tp._i64(batch))[1] - 1  # cached for a batch vector the searches have seen
+            hint = [int(np.floor(pb[0][a] / size)) - 1 for a in range(3)] + \
+                   [int(np.ceil(pb[1][a] / size)) + 1 for a in range(3)] + [max(nb, 0)]
+        cluster, unique_pos_indices, order, cluster_start, counts = voxel_cluster(
+            data.pos, batch, self._grid_size, return_counts=True, coord_bounds=hint)
+        if data.pos.shape[0] > 0:
+            if pb is None:
+                b = voxel_cluster.last_bounds
+                size = float(self._grid_size)
+                pb = ([(int(b[a]) - 0.5) * size for a in range(3)], [(int(b[3 + a]) + 0.5) * size for a in range(3)])
+            data.pos_bounds = pb
         if self._quantize_coords:
             # tensor / tensor is a true fp32 division on the device (tensor / python-scalar multiplies by 1/size)
             size_t = torch.full((), float(self._grid_size), dtype=torch.float32, device=data.pos.device)
