@@ -190,3 +190,39 @@ def test_nbr_maxpool_matches_torch(Nq, M, Mn, C):
     assert torch.equal(out.detach().cpu(), ref.detach())
     # the winner of a tie may differ from torch's; distinct random values make ties (other than shadow-vs-shadow) rare
     torch.testing.assert_close(xd.grad.cpu(), xr.grad, rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("train", [False, True])
+def test_multiscale_precompute_gives_the_same_forward(train):
+    """MultiScaleTransform (device mirror of core/data_transform/transforms.py:579-654) + the blocks' precomputed path
+    against the on-the-fly path: same tables, same features, the tables stay reusable."""
+    from torch_points3d_amd.kpconv_blocks import PDData
+    from torch_points3d_amd.kpconv_unet import KPConv
+    from torch_points3d_amd.multiscale import MultiScaleTransform
+    torch.manual_seed(5)
+    model = KPConv("unet", input_nc=3, in_feat=16, in_grid_size=0.02, num_layers=4, output_nc=7).to(DEV).train(train)
+    pos, batch, x = make_input(14000, 2, 21, 3)
+    pos, batch, x = pos.to(DEV), batch.to(DEV), x.to(DEV)
+    state = copy.deepcopy(model.state_dict())
+    ops = model.get_spatial_ops()
+    assert len(ops["sampler"]) == len(ops["neighbour_finder"]) == 10 and len(ops["upsample_op"]) == 4
+    assert sum(s is not None for s in ops["sampler"]) == 4
+    tables = MultiScaleTransform(ops)(PDData(pos=pos, batch=batch))
+    assert len(tables.multiscale) == 10 and len(tables.upsample) == 4
+
+    live = []
+    hooks = [m.register_forward_hook(lambda mod, inp, out: live.append((out.pos, out.idx_neighboors)))
+             for m in model.modules() if type(m).__name__ == "SimpleBlock"]
+    ref = model(PDData(pos=pos, batch=batch, x=x)).x.detach().clone()
+    for h in hooks:
+        h.remove()
+    for (p, idx), entry in zip(live, tables.multiscale):
+        assert torch.equal(p, entry.pos) and torch.equal(idx, entry.idx_neighboors)
+
+    for _ in range(2):  # twice: the tables must not be consumed or altered by a forward pass
+        model.load_state_dict(state)
+        data = PDData(pos=pos, batch=batch, x=x)
+        data.multiscale, data.upsample = tables.multiscale, tables.upsample
+        out = model(data).x
+        torch.testing.assert_close(out.detach(), ref, rtol=1e-5, atol=1e-5 * float(ref.abs().max()))
+    assert not hasattr(tables.multiscale[0], "x") or tables.multiscale[0].x is None

@@ -37,6 +37,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--in-feat", type=int, default=64)
     ap.add_argument("--train", action="store_true", help="time forward + backward in training mode")
+    ap.add_argument("--precomputed", action="store_true",
+                    help="sampling / neighbour search / interpolation tables computed once by MultiScaleTransform "
+                         "(the reference's data-loader precompute, on the device); the timed forward only convolves")
+    ap.add_argument("--graph", action="store_true", help="with --precomputed: replay the forward from one HIP graph")
     args = ap.parse_args()
     from torch_points3d_amd import _lib
     from torch_points3d_amd.kpconv_blocks import PDData
@@ -48,9 +52,23 @@ def main():
     x = torch.cat([torch.ones(pos.shape[0], 1), torch.randn(pos.shape[0], 3)], 1)
     pos, batch, x = pos.to(dev), batch.to(dev), x.to(dev)
     model.train(args.train)
+    tables = None
+    pre_ms = None
+    if args.precomputed:
+        from torch_points3d_amd.multiscale import MultiScaleTransform
+        transform = MultiScaleTransform(model.get_spatial_ops())
+        tables = transform(PDData(pos=pos, batch=batch))  # first call: workspaces, lazy initialisation
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            tables = transform(PDData(pos=pos, batch=batch))
+        torch.cuda.synchronize()
+        pre_ms = (time.perf_counter() - t0) * 1e3 / 5
 
     def step():
         data = PDData(pos=pos, batch=batch, x=x)
+        if tables is not None:
+            data.multiscale, data.upsample = tables.multiscale, tables.upsample
         if args.train:
             out = model(data)
             out.x.square().mean().backward()
@@ -64,9 +82,29 @@ def main():
     for _ in range(args.warmup):
         out = step()
     torch.cuda.synchronize()
+    run = step
+    if args.graph:
+        if not args.precomputed or args.train:
+            raise SystemExit("--graph needs --precomputed (static shapes, no host reads) and no --train")
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(2):
+                step()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            graph_out = step()
+        torch.cuda.synchronize()
+        eager_out = step()
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(graph_out.x, eager_out.x), "graph replay differs from the eager forward"
+        run = g.replay
     t0 = time.perf_counter()
     for _ in range(args.iters):
-        out = step()
+        out = run()
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) * 1e3 / args.iters
     timer = _lib.KernelTimer()
@@ -79,7 +117,10 @@ def main():
         c, t = per_entry.get(name, (0, 0.0))
         per_entry[name] = (c + cnt, t + tot)
     top = sorted(per_entry.items(), key=lambda kv: -kv[1][1])
-    print(json.dumps({"workload": "kpconv_unet4_%s" % ("train" if args.train else "forward"), "points": pos.shape[0],
+    mode = ("train" if args.train else "forward") + ("_precomputed" if args.precomputed else "") + \
+           ("_graph" if args.graph else "")
+    print(json.dumps({"workload": "kpconv_unet4_%s" % mode, "precompute_ms": None if pre_ms is None else round(pre_ms, 3),
+                      "points": pos.shape[0],
                       "clouds": args.clouds, "in_feat": args.in_feat, "ms": round(ms, 3),
                       "points_per_s": round(pos.shape[0] / ms * 1e3),
                       "library_ms": round(sum(v[1] for v in per_entry.values()), 3),

@@ -124,11 +124,14 @@ class SimpleBlock(nn.Module):
         if not hasattr(data, "block_idx"):
             data.block_idx = 0
         if precomputed:
-            query_data = precomputed[data.block_idx]
+            query_data = _copy(precomputed[data.block_idx])  # (the caller's table is left untouched)
             idx_neighboors, q_pos = query_data.idx_neighboors, query_data.pos
         else:
             if self.is_strided:
-                query_data = self.sampler(_copy(data))
+                sample_in = _copy(data)
+                if isinstance(self.sampler, GridSampling3D):
+                    sample_in.x = None  # the block overwrites query_data.x below: averaging the features is wasted work
+                query_data = self.sampler(sample_in)
             else:
                 query_data = _copy(data)
             q_pos = query_data.pos

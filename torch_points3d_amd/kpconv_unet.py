@@ -72,8 +72,26 @@ class KPConvUnet(nn.Module):
     def output_nc(self):
         return self._output_nc
 
+    def get_spatial_ops(self):
+        """{"sampler", "neighbour_finder", "upsample_op"}: one entry per block / decoder stage, in forward order
+        (reference models/base_architectures/unet.py:315-334; the input of `MultiScaleTransform`)."""
+        ops = {"sampler": [], "neighbour_finder": [], "upsample_op": []}
+        for down in self.down_modules:
+            for block in down.blocks:
+                ops["sampler"].append(block.sampler)
+                ops["neighbour_finder"].append(block.neighbour_finder)
+        for up in self.up_modules:
+            ops["upsample_op"].append(up.upsample_op)
+        return ops
+
     def forward(self, data, precomputed_down=None, precomputed_up=None):
-        """data: pos (N,3), x (N, input_nc + 1), batch (N) sorted -> data with x (N, output_nc) at the input resolution"""
+        """data: pos (N,3), x (N, input_nc + 1), batch (N) sorted -> data with x (N, output_nc) at the input resolution.
+        Data that went through `MultiScaleTransform` (attributes `multiscale` / `upsample`) runs on those tables
+        (reference applications/kpconv.py:99-111)."""
+        if precomputed_down is None and getattr(data, "multiscale", None) is not None:
+            precomputed_down, precomputed_up = data.multiscale, getattr(data, "upsample", None)
+            data = data.shallow_copy() if hasattr(data, "shallow_copy") else data
+            data.multiscale = data.upsample = None
         stack_down = []
         for i in range(len(self.down_modules) - 1):
             data = self.down_modules[i](data, precomputed=precomputed_down)

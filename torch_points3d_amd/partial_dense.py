@@ -87,7 +87,9 @@ class KNNInterpolate(object):
         weights = (1.0 / torch.clamp(d2.reshape(-1, 1), min=1e-16))[keep]
         y_idx, x_idx = y_idx[keep], x_idx[keep]
         normalisation = torch.zeros((Nq, 1), device=pos_y.device).index_add_(0, y_idx, weights)
-        return PDData(num_nodes=Nq, x_idx=x_idx, y_idx=y_idx, weights=weights, normalisation=normalisation)
+        # knn_idx / knn_d2: the same table in the fixed-k layout the fused interpolation kernel reads
+        return PDData(num_nodes=Nq, x_idx=x_idx, y_idx=y_idx, weights=weights, normalisation=normalisation,
+                      knn_idx=idx, knn_d2=d2)
 
     def __call__(self, query, support, precomputed=None, skip=None):
         """query: low-resolution data (pos, x[, batch]); support: the positions to interpolate to."""
@@ -96,6 +98,9 @@ class KNNInterpolate(object):
             if num_points != precomputed.num_nodes:
                 raise ValueError("Precomputed indices do not match with the data given to the transform")
             x = query.x
+            if getattr(precomputed, "knn_idx", None) is not None and x.is_cuda:
+                C = x.shape[1] + (0 if skip is None else skip.shape[1])
+                return _KnnInterpolate.apply(x, skip, precomputed.knn_idx, precomputed.knn_d2, C)
             y = torch.zeros((num_points, x.shape[1]), dtype=x.dtype, device=x.device).index_add_(
                 0, precomputed.y_idx, x[precomputed.x_idx] * precomputed.weights)
             y = y / precomputed.normalisation
