@@ -79,13 +79,31 @@ def main():
                 out = model(data)
         return out
 
-    for _ in range(args.warmup):
-        out = step()
+    if not (args.graph and args.train):
+        # (the graph-replayed training step warms up inside ShardedStep: a .backward() here would leave gradient
+        #  accumulators bound to the default stream, which the capture on a side stream must not touch)
+        for _ in range(args.warmup):
+            out = step()
     torch.cuda.synchronize()
     run = step
-    if args.graph:
-        if not args.precomputed or args.train:
-            raise SystemExit("--graph needs --precomputed (static shapes, no host reads) and no --train")
+    if args.graph and args.train:
+        # training step (forward, loss, backward, Adam) replayed from two HIP graphs, as bench.py does for PointNet++
+        if not args.precomputed:
+            raise SystemExit("--graph needs --precomputed (static shapes, no host reads)")
+        from torch_points3d_amd.dp import ShardedStep
+
+        def loss_fn():
+            data = PDData(pos=pos, batch=batch, x=x)
+            data.multiscale, data.upsample = tables.multiscale, tables.upsample
+            return model(data).x.square().mean()
+        trainer = ShardedStep(model, lambda ps: torch.optim.Adam(ps, lr=1e-3, capturable=True), loss_fn, use_graph=True,
+                              log=lambda m: print("[bench_kpconv] " + m, file=sys.stderr))
+        if not trainer.warmup_and_capture(3):
+            raise SystemExit("graph capture failed")
+        run = trainer.step
+    elif args.graph:
+        if not args.precomputed:
+            raise SystemExit("--graph needs --precomputed (static shapes, no host reads)")
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
@@ -109,7 +127,7 @@ def main():
     ms = (time.perf_counter() - t0) * 1e3 / args.iters
     timer = _lib.KernelTimer()
     _lib.set_timer(timer)
-    step()
+    (trainer.eager_step if (args.graph and args.train) else step)()
     torch.cuda.synchronize()
     _lib.set_timer(None)
     per_entry = {}

@@ -24,7 +24,11 @@ class ShardedStep(object):
         flatten_params: the parameters become views of ONE flat fp32 tensor that is handed to the optimizer as a
         single parameter (with the flat gradient as its .grad): an element-wise optimizer such as Adam then runs as
         ~10 kernels over 1.4 M elements instead of ~150 small ones over 56 tensors -- same arithmetic per element.
-        (Per-parameter options such as different weight decays need flatten_params=False.)"""
+        (Per-parameter options such as different weight decays need flatten_params=False.)
+
+        Build the stepper BEFORE the model has seen a `.backward()`: gradient accumulators created on the default
+        stream make the autograd engine synchronise with it, which is illegal inside the side-stream capture (the
+        capture then crashes at instantiation -- seen with tools/bench_kpconv.py when it warmed up that way)."""
         self.model = model
         self.loss_fn = loss_fn
         self.world = world_size
