@@ -35,7 +35,7 @@ extern "C" {
 #define TP3D_E_UNSORTED (-3) /* reserved: batch vector not sorted (checked by the host wrapper) */
 #define TP3D_E_TOOBIG (-4)   /* size exceeds what the kernel's index arithmetic supports */
 
-#define TP3D_ABI_VERSION 14
+#define TP3D_ABI_VERSION 15
 
 int tp3d_abi_version(void);
 const char *tp3d_strerror(int code);
@@ -202,14 +202,19 @@ int tp3d_kpconv_weighted_f32(const float *query, const float *support, const int
  *   d_features[m, :] = sum over (q,n) with neighbors[q,n] == m of sum_k h(...) * d_weighted[q, k, :]
  * d_weighted (Nq, KP, Cin) = d_out @ W2^T (host GEMM) -> d_features (M, Cin), overwritten; atomic-free and
  * reproducible: per-slot gradient rows (Nq*Mn, Cin) are formed per query and summed per support point in slot order
- * through the inverted neighbour table.  workspace: tp3d_kpconv_grad_workspace_bytes(M, Nq*Mn, Cin)
- * (tp3d_kpconv_bwd_workspace_bytes(M, slots) is the inverted table alone). */
+ * through the inverted neighbour table.
+ *   inverse: tp3d_kpconv_bwd_workspace_bytes(M, Nq*Mn) bytes holding the inverted table; it is (re)built by the call
+ *            unless inverse_ready != 0, i.e. the caller kept the buffer of an earlier call on the SAME neighbours / M
+ *            (tp3d_nbr_maxpool_bwd_f32 shares it: a strided block inverts its table once for both; with precomputed
+ *            neighbour tables it is built once for the whole training run);
+ *   workspace: tp3d_kpconv_grad_workspace_bytes(M, Nq*Mn, Cin) bytes for the per-slot rows. */
 size_t tp3d_kpconv_bwd_workspace_bytes(int64_t M, int64_t slots);
 size_t tp3d_kpconv_grad_workspace_bytes(int64_t M, int64_t slots, int Cin);
 int tp3d_kpconv_bwd_features_f32(const float *query, const float *support, const int64_t *neighbors,
                                  const float *k_points, const float *d_weighted, int64_t Nq, int64_t M, int Mn,
                                  int Cin, int KP, float extent, int influence, int closest, float *d_features,
-                                 void *workspace, size_t workspace_bytes, void *stream);
+                                 void *inverse, size_t inverse_bytes, int inverse_ready, void *workspace,
+                                 size_t workspace_bytes, void *stream);
 
 /* inverse-distance weights of DenseFPModule (core/base_conv/dense.py:137-139): dist (rows,3) -> weight (rows,3) */
 int tp3d_idw_weights_f32(const float *dist, int64_t rows, float *weight, void *stream);
@@ -270,13 +275,13 @@ int tp3d_knn_interpolate_fwd_f32(const float *x, const int64_t *idx, const float
 /* Strided shortcut of the KPConv ResnetBBlock (modules/KPConv/blocks.py:206-210):
  *   out[q, c] = max over n of x[neighbors[q,n], c], a shadow neighbour (-1 or >= M) contributing 0.0
  * x (M,C), neighbors (Nq,Mn) -> out (Nq,C); argmax (Nq,C) int32 or NULL = winning slot n (first maximum).
- * Backward: d_x (M,C) overwritten, atomic-free (inverse neighbour table); workspace:
- * tp3d_kpconv_bwd_workspace_bytes(M, Nq*Mn). */
+ * Backward: d_x (M,C) overwritten, atomic-free (inverse neighbour table); inverse / inverse_ready as for
+ * tp3d_kpconv_bwd_features_f32. */
 int tp3d_nbr_maxpool_fwd_f32(const float *x, const int64_t *neighbors, int64_t Nq, int64_t M, int Mn, int C, float *out,
                              int32_t *argmax, void *stream);
 int tp3d_nbr_maxpool_bwd_f32(const float *grad_out, const int32_t *argmax, const int64_t *neighbors, int64_t Nq,
-                             int64_t M, int Mn, int C, float *d_x, void *workspace, size_t workspace_bytes,
-                             void *stream);
+                             int64_t M, int Mn, int C, float *d_x, void *inverse, size_t inverse_bytes,
+                             int inverse_ready, void *stream);
 
 #ifdef __cplusplus
 }

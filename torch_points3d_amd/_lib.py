@@ -36,12 +36,13 @@ SIGNATURES = {
     "tp3d_gemm_tn_f32": [_p, _p, _l, _i, _i, _p, _p, _p],
     "tp3d_gemm_rows_f32": [_p, _p, _l, _i, _i, _p, _p, _p],
     "tp3d_bn_finalize_f32": [_p, _i, _l, _i, _f, _f, _p, _p, _p, _p, _p, _p, _p, _p, _p],
-    "tp3d_kpconv_bwd_features_f32": [_p, _p, _p, _p, _p, _l, _l, _i, _i, _i, _f, _i, _i, _p, _p, ctypes.c_size_t, _p],
+    "tp3d_kpconv_bwd_features_f32": [_p, _p, _p, _p, _p, _l, _l, _i, _i, _i, _f, _i, _i, _p, _p, ctypes.c_size_t, _i, _p,
+                                     ctypes.c_size_t, _p],
     "tp3d_knn_partial_dense_f32": [_p, _p, _p, _p, _i, _i, _l, _l, _i, _f, _p, _p, _p, ctypes.c_size_t, _p],
     "tp3d_knn_dense_f32": [_p, _p, _i, _i, _i, _i, _f, _p, _p, _p, ctypes.c_size_t, _p],
     "tp3d_knn_interpolate_fwd_f32": [_p, _p, _p, _p, _l, _i, _i, _i, _i, _p, _p, _p],
     "tp3d_nbr_maxpool_fwd_f32": [_p, _p, _l, _l, _i, _i, _p, _p, _p],
-    "tp3d_nbr_maxpool_bwd_f32": [_p, _p, _p, _l, _l, _i, _i, _p, _p, ctypes.c_size_t, _p],
+    "tp3d_nbr_maxpool_bwd_f32": [_p, _p, _p, _l, _l, _i, _i, _p, _p, ctypes.c_size_t, _i, _p],
     "tp3d_voxel_bounds_f32": [_p, _p, _l, _f, _p, _p],
     "tp3d_voxel_cluster_f32": [_p, _p, _l, _f, _p, _p, _p, _p, _p, _p, _p, ctypes.c_size_t, _p],
     "tp3d_cluster_mean_f32": [_p, _p, _p, _l, _i, _p, _p],
@@ -51,7 +52,7 @@ SIGNATURES = {
 MISC = ("tp3d_abi_version", "tp3d_strerror", "tp3d_last_hip_error", "tp3d_scatter_workspace_bytes",
         "tp3d_bn_workspace_floats", "tp3d_gemm_tn_workspace_floats", "tp3d_ball_query_workspace_bytes",
         "tp3d_gemm_rows_stat_floats", "tp3d_kpconv_bwd_workspace_bytes", "tp3d_voxel_workspace_bytes", "tp3d_knn_workspace_bytes", "tp3d_kpconv_grad_workspace_bytes")
-ABI_VERSION = 14
+ABI_VERSION = 15
 
 _handle = None
 
@@ -217,6 +218,47 @@ def ball_query_workspace(num_clouds, rows, max_cloud_points, device):
     if nbytes == 0:
         return None, 0
     return workspace("grid", nbytes, device), nbytes
+
+
+_inverse_cache = {}
+
+
+def neighbour_inverse(nbr, M, device):
+    """(buffer, nbytes, ready, token) for the inverted form of the neighbour table `nbr` (Nq, Mn) over M support points.
+
+    The buffer is kept per table (address, version counter, shape): the two backward kernels of a strided block share
+    it, and with precomputed neighbour tables it is built once for the whole run (a captured training step then only
+    reads it).  The entry keeps `nbr` alive, so an equal address means the same storage and an equal version counter
+    the same content.  ready == 0: the caller's kernel builds the table; it then calls inverse_built(token).
+    A table built on another stream is waited for through its event; inside a stream capture the caller is expected
+    to have synchronised after warm-up (torch.cuda.graph does)."""
+    key = (nbr.data_ptr(), nbr._version, tuple(nbr.shape), int(M), device.index)
+    hit = _inverse_cache.get(key)
+    cur = _raw_stream(device)
+    capturing = torch.cuda.is_current_stream_capturing()
+    if hit is not None and hit[3] is not None:
+        if hit[4] != cur and not capturing:
+            torch.cuda.current_stream(device).wait_event(hit[3])
+        return hit[1], hit[2], 1, None
+    nbytes = load().tp3d_kpconv_bwd_workspace_bytes(int(M), nbr.numel())
+    if capturing:  # never publish a table whose build is only a node of a graph being recorded
+        return workspace("nbr_inverse", nbytes, device), nbytes, 0, None
+    buf = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+    if len(_inverse_cache) >= 48:
+        _inverse_cache.clear()
+    _inverse_cache[key] = [nbr, buf, nbytes, None, cur]
+    return buf, nbytes, 0, key
+
+
+def inverse_built(token, device):
+    """Publish the table the caller's kernel has just enqueued (records the event other streams wait on)."""
+    if token is None:
+        return
+    entry = _inverse_cache.get(token)
+    if entry is not None:
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(device))
+        entry[3] = ev
 
 
 def bn_workspace(M, C, device):

@@ -236,7 +236,7 @@ int invert_table(const int64_t *idx, int64_t slots, int64_t M, int *cnt, int *st
 
 // workspace: tp3d_kpconv_bwd_workspace_bytes(M, slots)
 static int invert_neighbors(const int64_t *neighbors, int64_t slots, int64_t M, void *workspace, int **start_out,
-                            int **order_out, hipStream_t s)
+                            int **order_out, hipStream_t s, bool ready = false)
 {
     auto up = [](size_t v) { return (v + 15) & ~(size_t)15; };
     char *p = static_cast<char *>(workspace);
@@ -246,6 +246,7 @@ static int invert_neighbors(const int64_t *neighbors, int64_t slots, int64_t M, 
     int *order = reinterpret_cast<int *>(p + up((size_t)M * 4) + up((size_t)(M + 1) * 4) + up((size_t)M * 4));
     *start_out = start;
     *order_out = order;
+    if (ready) return TP3D_OK;  // the caller kept the table of an earlier call on the same neighbours
     return invert_table(neighbors, slots, M, cnt, start, cursor, order, s);
 }
 
@@ -417,13 +418,14 @@ TP3D_EXPORT size_t tp3d_kpconv_bwd_workspace_bytes(int64_t M, int64_t slots)
 TP3D_EXPORT size_t tp3d_kpconv_grad_workspace_bytes(int64_t M, int64_t slots, int Cin)
 {
     if (M < 0 || slots < 0 || Cin <= 0) return 0;
-    return tp3d_kpconv_bwd_workspace_bytes(M, slots) + (((size_t)slots * Cin * 4 + 15) & ~(size_t)15);
+    return ((size_t)slots * Cin * 4 + 15) & ~(size_t)15;  // the per-slot gradient rows
 }
 
 TP3D_EXPORT int tp3d_kpconv_bwd_features_f32(const float *query, const float *support, const int64_t *neighbors,
                                              const float *k_points, const float *d_weighted, int64_t Nq, int64_t M,
                                              int Mn, int Cin, int KP, float extent, int influence, int closest,
-                                             float *d_features, void *workspace, size_t workspace_bytes, void *stream)
+                                             float *d_features, void *inverse, size_t inverse_bytes, int inverse_ready,
+                                             void *workspace, size_t workspace_bytes, void *stream)
 {
     if (Nq < 0 || M < 0 || Mn < 0 || Cin <= 0 || KP <= 0 || influence < 0 || influence > 2) return TP3D_E_BADARG;
     if (KP > KP_MAX) return TP3D_E_TOOBIG;
@@ -432,12 +434,13 @@ TP3D_EXPORT int tp3d_kpconv_bwd_features_f32(const float *query, const float *su
     hipStream_t s = (hipStream_t)stream;
     const int64_t slots = Nq * Mn;
     if (slots == 0) return zero_async(d_features, (size_t)M * Cin * sizeof(float), s);
-    if (!query || !support || !neighbors || !k_points || !d_weighted || !workspace) return TP3D_E_BADARG;
+    if (!query || !support || !neighbors || !k_points || !d_weighted || !workspace || !inverse) return TP3D_E_BADARG;
     if (slots > INT32_MAX || M > INT32_MAX / 2) return TP3D_E_TOOBIG;
+    if (inverse_bytes < tp3d_kpconv_bwd_workspace_bytes(M, slots)) return TP3D_E_BADARG;
     if (workspace_bytes < tp3d_kpconv_grad_workspace_bytes(M, slots, Cin)) return TP3D_E_BADARG;
     int *start = nullptr, *order = nullptr;
-    if (int rc = invert_neighbors(neighbors, slots, M, workspace, &start, &order, s)) return rc;
-    float *g = reinterpret_cast<float *>(static_cast<char *>(workspace) + tp3d_kpconv_bwd_workspace_bytes(M, slots));
+    if (int rc = invert_neighbors(neighbors, slots, M, inverse, &start, &order, s, inverse_ready != 0)) return rc;
+    float *g = static_cast<float *>(workspace);
     hipLaunchKernelGGL(kpconv_bwd_slots_kernel, dim3((unsigned)((Nq + KP_BLOCK / 64 - 1) / (KP_BLOCK / 64))), dim3(KP_BLOCK),
                        0, s, query, support, neighbors, k_points, d_weighted, Nq, M, Mn, Cin, KP, extent, influence, closest,
                        g);
@@ -460,8 +463,8 @@ TP3D_EXPORT int tp3d_nbr_maxpool_fwd_f32(const float *x, const int64_t *neighbor
 }
 
 TP3D_EXPORT int tp3d_nbr_maxpool_bwd_f32(const float *grad_out, const int32_t *argmax, const int64_t *neighbors, int64_t Nq,
-                                         int64_t M, int Mn, int C, float *d_x, void *workspace, size_t workspace_bytes,
-                                         void *stream)
+                                         int64_t M, int Mn, int C, float *d_x, void *inverse, size_t inverse_bytes,
+                                         int inverse_ready, void *stream)
 {
     if (Nq < 0 || M < 0 || Mn <= 0 || C <= 0) return TP3D_E_BADARG;
     if (M == 0) return TP3D_OK;
@@ -469,11 +472,11 @@ TP3D_EXPORT int tp3d_nbr_maxpool_bwd_f32(const float *grad_out, const int32_t *a
     hipStream_t s = (hipStream_t)stream;
     const int64_t slots = Nq * Mn;
     if (slots == 0) return tp3d::zero_async(d_x, (size_t)M * C * sizeof(float), s);
-    if (!grad_out || !argmax || !neighbors || !workspace) return TP3D_E_BADARG;
+    if (!grad_out || !argmax || !neighbors || !inverse) return TP3D_E_BADARG;
     if (slots > INT32_MAX || M > INT32_MAX / 2) return TP3D_E_TOOBIG;
-    if (workspace_bytes < tp3d_kpconv_bwd_workspace_bytes(M, slots)) return TP3D_E_BADARG;
+    if (inverse_bytes < tp3d_kpconv_bwd_workspace_bytes(M, slots)) return TP3D_E_BADARG;
     int *start = nullptr, *order = nullptr;
-    if (int rc = tp3d::invert_neighbors(neighbors, slots, M, workspace, &start, &order, s)) return rc;
+    if (int rc = tp3d::invert_neighbors(neighbors, slots, M, inverse, &start, &order, s, inverse_ready != 0)) return rc;
     hipLaunchKernelGGL(tp3d::nbr_maxpool_bwd_kernel, dim3((unsigned)((M + tp3d::KP_BLOCK / 64 - 1) / (tp3d::KP_BLOCK / 64))),
                        dim3(tp3d::KP_BLOCK), 0, s, grad_out, argmax, start, order, M, Mn, C, d_x);
     return tp3d::check_launch();

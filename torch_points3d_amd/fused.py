@@ -272,11 +272,11 @@ class _NbrMaxPool(torch.autograd.Function):
         g = g.contiguous()
         Nq, Mn = nbr.shape
         dx = torch.empty((M, C), dtype=torch.float32, device=dev)
-        nbytes = _lib.load().tp3d_kpconv_bwd_workspace_bytes(M, Nq * Mn)
-        ws = _lib.workspace("kpconv_bwd", nbytes, dev)
         with _lib.on_device(dev):
+            inv, inv_bytes, ready, token = _lib.neighbour_inverse(nbr, M, dev)
             _lib.call("tp3d_nbr_maxpool_bwd_f32", _lib.ptr(g), _lib.ptr(arg), _lib.ptr(nbr), Nq, M, Mn, C, _lib.ptr(dx),
-                      _lib.ptr(ws), nbytes, _lib.stream_ptr(dev))
+                      _lib.ptr(inv), inv_bytes, ready, _lib.stream_ptr(dev))
+            _lib.inverse_built(token, dev)
         return dx, None
 
 

@@ -51,9 +51,11 @@ class _KPConv(torch.autograd.Function):
             nbytes = _lib.load().tp3d_kpconv_grad_workspace_bytes(M, Nq * Mn, Cin)
             ws = _lib.workspace("kpconv_bwd", nbytes, dev)
             with _lib.on_device(dev):
+                inv, inv_bytes, ready, token = _lib.neighbour_inverse(nbr, M, dev)
                 _lib.call("tp3d_kpconv_bwd_features_f32", _lib.ptr(query), _lib.ptr(support), _lib.ptr(nbr), _lib.ptr(kp),
-                          _lib.ptr(d_wf), Nq, M, Mn, Cin, KP, extent, influence, closest, _lib.ptr(dx), _lib.ptr(ws),
-                          nbytes, _lib.stream_ptr(dev))
+                          _lib.ptr(d_wf), Nq, M, Mn, Cin, KP, extent, influence, closest, _lib.ptr(dx), _lib.ptr(inv),
+                          inv_bytes, ready, _lib.ptr(ws), nbytes, _lib.stream_ptr(dev))
+                _lib.inverse_built(token, dev)
         return dx, dW, None, None, None, None, None, None, None
 
 
