@@ -18,28 +18,102 @@ __device__ __forceinline__ float rl_bcast(float x, int lane)
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), lane));
 }
 
+// Every wave owns its slice of the LDS arrays, so the phases of a query only need the wave's own LDS writes to have
+// landed: a wave-level barrier, not a workgroup one (which would make four unrelated queries wait for each other).
+__device__ __forceinline__ void wave_lds_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
 constexpr int KP_BLOCK = 256;  // 4 waves, one query per wave
 constexpr int KP_MAX = 16;     // kernel points (15 in every reference config)
 constexpr int KP_NCH = 48;     // neighbours per LDS pass (covers every max_num_neighbors of the reference configs)
 
+// Phase A of both per-query kernels: influence weight of every (neighbour, kernel point) pair of a chunk of <= KP_NCH
+// neighbours, into the wave's LDS slice.  Two steps so that a query costs two dependent global round trips instead of
+// two per group of four neighbours: (a) lane n fetches neighbour n's id and its centred position into LDS; (b) every
+// lane owns kernel point (lane & 15) and walks the neighbours four at a time, reading only LDS.  (The kernel was bound
+// by exactly that chain: ~6 waves per SIMD each waiting ~14 serial L2 round trips.)
+template <bool CLOSEST>
+__device__ __forceinline__ void kp_influence_weights(const float *__restrict__ support, const int64_t *__restrict__ nbr_row,
+                                                     int cnt, int64_t M, float qx, float qy, float qz,
+                                                     const float *__restrict__ kpts, int KP, int influence,
+                                                     float inv_extent, float gden, float (*w)[KP_MAX],
+                                                     float (*dd)[KP_MAX], float4 *rel, int *ids, int lane)
+{
+    if (lane < cnt) {
+        const int64_t id = nbr_row[lane];
+        const bool shadow = id < 0 || id >= M;
+        float4 r = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (!shadow) {
+            r.x = support[id * 3 + 0] - qx;
+            r.y = support[id * 3 + 1] - qy;
+            r.z = support[id * 3 + 2] - qz;
+        }
+        ids[lane] = shadow ? -1 : (int)id;
+        rel[lane] = r;
+    }
+    wave_lds_sync();
+    const int k = lane & (KP_MAX - 1);
+    const bool kreal = k < KP;
+    const float kx = kreal ? kpts[k * 3 + 0] : 0.0f, ky = kreal ? kpts[k * 3 + 1] : 0.0f, kz = kreal ? kpts[k * 3 + 2] : 0.0f;
+    for (int n = lane / KP_MAX; n < cnt; n += 64 / KP_MAX) {
+        const float4 r = rel[n];
+        float wv = 0.0f, d2 = 3.0e38f;
+        if (ids[n] >= 0 && kreal) {
+            const float dx = r.x - kx, dy = r.y - ky, dz = r.z - kz;
+            d2 = (dx * dx + dy * dy) + dz * dz;
+            if (influence == 0) wv = 1.0f;
+            // linear: 1-ulp v_sqrt_f32 and a reciprocal multiply (features carry a 1e-5 tolerance; the correctly
+            // rounded sqrt + divide sequences cost ~25 instructions per pair)
+            else if (influence == 1) wv = fmaxf(1.0f - __builtin_amdgcn_sqrtf(d2) * inv_extent, 0.0f);
+            else wv = expf(-d2 / gden);
+        }
+        w[n][k] = wv;
+        if (CLOSEST) dd[n][k] = d2;
+    }
+    wave_lds_sync();
+    if (CLOSEST) {  // only the closest kernel point keeps its influence (first minimum)
+        if (lane < cnt) {
+            int kb = 0;
+            float best = dd[lane][0];
+            for (int kk = 1; kk < KP; ++kk)
+                if (dd[lane][kk] < best) {
+                    best = dd[lane][kk];
+                    kb = kk;
+                }
+            for (int kk = 0; kk < KP; ++kk)
+                if (kk != kb) w[lane][kk] = 0.0f;
+        }
+        wave_lds_sync();
+    }
+}
+
+template <bool CLOSEST>
 __global__ __launch_bounds__(KP_BLOCK) void kpconv_weighted_kernel(
     const float *__restrict__ query, const float *__restrict__ support, const int64_t *__restrict__ nbr,
     const float *__restrict__ feat, const float *__restrict__ kpts, int64_t Nq, int64_t M, int Mn, int Cin, int KP,
-    float extent, int influence, int closest, float *__restrict__ wf)
+    float extent, int influence, float *__restrict__ wf)
 {
     __shared__ __attribute__((aligned(16))) float s_w[KP_BLOCK / 64][KP_NCH][KP_MAX];
-    __shared__ float s_d[KP_BLOCK / 64][KP_NCH][KP_MAX];
+    __shared__ __attribute__((aligned(16))) float4 s_rel[KP_BLOCK / 64][KP_NCH];
+    __shared__ float s_d[CLOSEST ? KP_BLOCK / 64 : 1][CLOSEST ? KP_NCH : 1][KP_MAX];  // distances: closest mode only
     __shared__ int s_id[KP_BLOCK / 64][KP_NCH];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t qraw = (int64_t)blockIdx.x * (KP_BLOCK / 64) + wave;
-    const bool live = qraw < Nq;  // idle waves keep walking the barriers
-    const int64_t q = live ? qraw : Nq - 1;
+    if (qraw >= Nq) return;  // wave-uniform; the kernel has no workgroup barrier
+    const bool live = true;
+    const int64_t q = qraw;
     const float qx = query[q * 3 + 0], qy = query[q * 3 + 1], qz = query[q * 3 + 2];
     float(*w)[KP_MAX] = s_w[wave];
-    float(*dd)[KP_MAX] = s_d[wave];
+    float(*dd)[KP_MAX] = s_d[CLOSEST ? wave : 0];
+    float4 *rel = s_rel[wave];
     int *ids = s_id[wave];
     const float sigma = extent * 0.3f;
     const float gden = 2.0f * sigma * sigma + 1e-9f;
+    const float inv_extent = 1.0f / extent;
 
     const bool single_pass = Mn <= KP_NCH;  // then the weights of phase A serve every channel chunk
     for (int c0 = 0; c0 < Cin; c0 += 64) {
@@ -51,39 +125,8 @@ __global__ __launch_bounds__(KP_BLOCK) void kpconv_weighted_kernel(
             const int cnt = min(KP_NCH, Mn - n0);
             // ---- phase A: influence weight of every (neighbour, kernel point) pair of this chunk
             if (!(single_pass && c0 > 0))
-            for (int p = lane; p < cnt * KP_MAX; p += 64) {
-                const int n = p / KP_MAX, k = p % KP_MAX;
-                const int64_t id = nbr[q * Mn + n0 + n];
-                const bool shadow = id < 0 || id >= M;
-                if (k == 0) ids[n] = shadow ? -1 : (int)id;
-                float wv = 0.0f, d2 = 3.0e38f;
-                if (!shadow && k < KP) {
-                    const float cx = support[id * 3 + 0] - qx, cy = support[id * 3 + 1] - qy,
-                                cz = support[id * 3 + 2] - qz;
-                    const float dx = cx - kpts[k * 3 + 0], dy = cy - kpts[k * 3 + 1], dz = cz - kpts[k * 3 + 2];
-                    d2 = (dx * dx + dy * dy) + dz * dz;
-                    if (influence == 0) wv = 1.0f;
-                    else if (influence == 1) wv = fmaxf(1.0f - sqrtf(d2) / extent, 0.0f);
-                    else wv = expf(-d2 / gden);
-                }
-                w[n][k] = wv;
-                dd[n][k] = d2;
-            }
-            __syncthreads();
-            if (closest && !(single_pass && c0 > 0)) {  // only the closest kernel point keeps its influence
-                if (lane < cnt) {
-                    int kb = 0;
-                    float best = dd[lane][0];
-                    for (int k = 1; k < KP; ++k)
-                        if (dd[lane][k] < best) {
-                            best = dd[lane][k];
-                            kb = k;
-                        }
-                    for (int k = 0; k < KP; ++k)
-                        if (k != kb) w[lane][k] = 0.0f;
-                }
-            }
-            __syncthreads();
+                kp_influence_weights<CLOSEST>(support, nbr + q * Mn + n0, cnt, M, qx, qy, qz, kpts, KP, influence, inv_extent,
+                                              gden, w, dd, rel, ids, lane);
             // ---- phase B: accumulate the neighbour rows into the KP accumulators (lanes over channels)
             if (c < Cin) {
 #pragma unroll 5
@@ -107,7 +150,7 @@ __global__ __launch_bounds__(KP_BLOCK) void kpconv_weighted_kernel(
                     acc[14] = __builtin_fmaf(w3.z, v, acc[14]); acc[15] = __builtin_fmaf(w3.w, v, acc[15]);
                 }
             }
-            __syncthreads();
+            wave_lds_sync();
         }
         if (live && c < Cin) {
 #pragma unroll
@@ -134,9 +177,12 @@ TP3D_EXPORT int tp3d_kpconv_weighted_f32(const float *query, const float *suppor
         return zero_async(weighted, (size_t)Nq * KP * Cin * sizeof(float), (hipStream_t)stream);
     const int64_t blocks = (Nq + KP_BLOCK / 64 - 1) / (KP_BLOCK / 64);
     if (blocks > 0x7fffffff) return TP3D_E_TOOBIG;
-    hipLaunchKernelGGL(kpconv_weighted_kernel, dim3((unsigned)blocks), dim3(KP_BLOCK), 0, (hipStream_t)stream, query,
-                       support, neighbors, features, k_points, Nq, M, Mn, Cin, KP, extent, influence, closest,
-                       weighted);
+    if (closest)
+        hipLaunchKernelGGL(kpconv_weighted_kernel<true>, dim3((unsigned)blocks), dim3(KP_BLOCK), 0, (hipStream_t)stream,
+                           query, support, neighbors, features, k_points, Nq, M, Mn, Cin, KP, extent, influence, weighted);
+    else
+        hipLaunchKernelGGL(kpconv_weighted_kernel<false>, dim3((unsigned)blocks), dim3(KP_BLOCK), 0, (hipStream_t)stream,
+                           query, support, neighbors, features, k_points, Nq, M, Mn, Cin, KP, extent, influence, weighted);
     return check_launch();
 }
 
@@ -301,22 +347,29 @@ __global__ __launch_bounds__(KP_BLOCK) void nbr_maxpool_bwd_kernel(const float *
 // d_wf[q] (KP x Cin) is read ONCE into registers (lanes over channels) and combined with the KP x Mn influence weights
 // recomputed in LDS exactly like the forward pass.  (The first version walked, per support point, every slot that
 // references it and re-read the whole d_wf[q] block each time: Mn times the traffic.)
+template <bool CLOSEST>
 __global__ __launch_bounds__(KP_BLOCK) void kpconv_bwd_slots_kernel(
     const float *__restrict__ query, const float *__restrict__ support, const int64_t *__restrict__ nbr,
     const float *__restrict__ kpts, const float *__restrict__ d_wf, int64_t Nq, int64_t M, int Mn, int Cin, int KP,
-    float extent, int influence, int closest, float *__restrict__ g)
+    float extent, int influence, float *__restrict__ g)
 {
     __shared__ __attribute__((aligned(16))) float s_w[KP_BLOCK / 64][KP_NCH][KP_MAX];
-    __shared__ float s_d[KP_BLOCK / 64][KP_NCH][KP_MAX];
+    __shared__ __attribute__((aligned(16))) float4 s_rel[KP_BLOCK / 64][KP_NCH];
+    __shared__ float s_d[CLOSEST ? KP_BLOCK / 64 : 1][CLOSEST ? KP_NCH : 1][KP_MAX];
+    __shared__ int s_id[KP_BLOCK / 64][KP_NCH];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t qraw = (int64_t)blockIdx.x * (KP_BLOCK / 64) + wave;
-    const bool live = qraw < Nq;  // idle waves keep walking the barriers
-    const int64_t q = live ? qraw : Nq - 1;
+    if (qraw >= Nq) return;  // wave-uniform; the kernel has no workgroup barrier
+    const bool live = true;
+    const int64_t q = qraw;
     const float qx = query[q * 3 + 0], qy = query[q * 3 + 1], qz = query[q * 3 + 2];
     float(*w)[KP_MAX] = s_w[wave];
-    float(*dd)[KP_MAX] = s_d[wave];
+    float(*dd)[KP_MAX] = s_d[CLOSEST ? wave : 0];
+    float4 *rel = s_rel[wave];
+    int *ids = s_id[wave];
     const float sigma = extent * 0.3f;
     const float gden = 2.0f * sigma * sigma + 1e-9f;
+    const float inv_extent = 1.0f / extent;
     const bool single_pass = Mn <= KP_NCH;
     for (int c0 = 0; c0 < Cin; c0 += 64) {
         const int c = c0 + lane;
@@ -326,38 +379,8 @@ __global__ __launch_bounds__(KP_BLOCK) void kpconv_bwd_slots_kernel(
         for (int n0 = 0; n0 < Mn; n0 += KP_NCH) {
             const int cnt = min(KP_NCH, Mn - n0);
             if (!(single_pass && c0 > 0))
-            for (int p = lane; p < cnt * KP_MAX; p += 64) {
-                const int n = p / KP_MAX, k = p % KP_MAX;
-                const int64_t id = nbr[q * Mn + n0 + n];
-                const bool shadow = id < 0 || id >= M;
-                float wv = 0.0f, d2 = 3.0e38f;
-                if (!shadow && k < KP) {
-                    const float cx = support[id * 3 + 0] - qx, cy = support[id * 3 + 1] - qy,
-                                cz = support[id * 3 + 2] - qz;
-                    const float dx = cx - kpts[k * 3 + 0], dy = cy - kpts[k * 3 + 1], dz = cz - kpts[k * 3 + 2];
-                    d2 = (dx * dx + dy * dy) + dz * dz;
-                    if (influence == 0) wv = 1.0f;
-                    else if (influence == 1) wv = fmaxf(1.0f - sqrtf(d2) / extent, 0.0f);
-                    else wv = expf(-d2 / gden);
-                }
-                w[n][k] = wv;
-                dd[n][k] = d2;
-            }
-            __syncthreads();
-            if (closest && !(single_pass && c0 > 0)) {
-                if (lane < cnt) {
-                    int kb = 0;
-                    float best = dd[lane][0];
-                    for (int k = 1; k < KP; ++k)
-                        if (dd[lane][k] < best) {
-                            best = dd[lane][k];
-                            kb = k;
-                        }
-                    for (int k = 0; k < KP; ++k)
-                        if (k != kb) w[lane][k] = 0.0f;
-                }
-            }
-            __syncthreads();
+                kp_influence_weights<CLOSEST>(support, nbr + q * Mn + n0, cnt, M, qx, qy, qz, kpts, KP, influence, inv_extent,
+                                              gden, w, dd, rel, ids, lane);
             if (live && c < Cin) {
 #pragma unroll 5
                 for (int n = 0; n < cnt; ++n) {
@@ -378,7 +401,7 @@ __global__ __launch_bounds__(KP_BLOCK) void kpconv_bwd_slots_kernel(
                     g[((size_t)q * Mn + n0 + n) * Cin + c] = acc;
                 }
             }
-            __syncthreads();
+            wave_lds_sync();
         }
     }
 }
@@ -441,9 +464,13 @@ TP3D_EXPORT int tp3d_kpconv_bwd_features_f32(const float *query, const float *su
     int *start = nullptr, *order = nullptr;
     if (int rc = invert_neighbors(neighbors, slots, M, inverse, &start, &order, s, inverse_ready != 0)) return rc;
     float *g = static_cast<float *>(workspace);
-    hipLaunchKernelGGL(kpconv_bwd_slots_kernel, dim3((unsigned)((Nq + KP_BLOCK / 64 - 1) / (KP_BLOCK / 64))), dim3(KP_BLOCK),
-                       0, s, query, support, neighbors, k_points, d_weighted, Nq, M, Mn, Cin, KP, extent, influence, closest,
-                       g);
+    const dim3 qgrid((unsigned)((Nq + KP_BLOCK / 64 - 1) / (KP_BLOCK / 64)));
+    if (closest)
+        hipLaunchKernelGGL(kpconv_bwd_slots_kernel<true>, qgrid, dim3(KP_BLOCK), 0, s, query, support, neighbors, k_points,
+                           d_weighted, Nq, M, Mn, Cin, KP, extent, influence, g);
+    else
+        hipLaunchKernelGGL(kpconv_bwd_slots_kernel<false>, qgrid, dim3(KP_BLOCK), 0, s, query, support, neighbors, k_points,
+                           d_weighted, Nq, M, Mn, Cin, KP, extent, influence, g);
     hipLaunchKernelGGL(kpconv_bwd_gather_kernel, dim3((unsigned)((M + KP_BLOCK / 64 - 1) / (KP_BLOCK / 64))),
                        dim3(KP_BLOCK), 0, s, g, start, order, M, Cin, d_features);
     return check_launch();
