@@ -129,7 +129,7 @@ __global__ __launch_bounds__(KP_BLOCK) void kpconv_weighted_kernel(
                                               gden, w, dd, rel, ids, lane);
             // ---- phase B: accumulate the neighbour rows into the KP accumulators (lanes over channels)
             if (c < Cin) {
-#pragma unroll 5
+#pragma unroll 13
                 for (int n = 0; n < cnt; ++n) {
                     const int id = ids[n];
                     // shadow neighbours carry zero weights (phase A): reading row 0 instead keeps the loop branch-free
@@ -416,16 +416,25 @@ __global__ __launch_bounds__(KP_BLOCK) void kpconv_bwd_gather_kernel(const float
     const int64_t m = (int64_t)blockIdx.x * (KP_BLOCK / 64) + (threadIdx.x >> 6);
     if (m >= M) return;  // wave-uniform; no workgroup barrier in this kernel
     const int s0 = start[m], s1 = start[m + 1];
-    for (int c = lane; c < Cin; c += 64) {
+    for (int c0 = 0; c0 < Cin; c0 += 64) {
+        const int c = min(c0 + lane, Cin - 1);
         float acc = 0.0f;
-        int j = s0;
-        for (; j + 4 <= s1; j += 4) {  // four independent row reads in flight, summed in slot order
-            const float v0 = g[(size_t)order[j] * Cin + c], v1 = g[(size_t)order[j + 1] * Cin + c];
-            const float v2 = g[(size_t)order[j + 2] * Cin + c], v3 = g[(size_t)order[j + 3] * Cin + c];
-            acc = (((acc + v0) + v1) + v2) + v3;
+        // the run's slot ids are fetched 64 at a time with one coalesced load and handed out by v_readlane, so the row
+        // reads (four in flight) no longer wait for a dependent index load each; summed in slot order
+        for (int j0 = s0; j0 < s1; j0 += 64) {
+            const int cnt = min(64, s1 - j0);
+            const int mine = lane < cnt ? order[j0 + lane] : 0;
+            int t = 0;
+            for (; t + 4 <= cnt; t += 4) {
+                const int r0 = __builtin_amdgcn_readlane(mine, t), r1 = __builtin_amdgcn_readlane(mine, t + 1);
+                const int r2 = __builtin_amdgcn_readlane(mine, t + 2), r3 = __builtin_amdgcn_readlane(mine, t + 3);
+                const float v0 = g[(size_t)r0 * Cin + c], v1 = g[(size_t)r1 * Cin + c];
+                const float v2 = g[(size_t)r2 * Cin + c], v3 = g[(size_t)r3 * Cin + c];
+                acc = (((acc + v0) + v1) + v2) + v3;
+            }
+            for (; t < cnt; ++t) acc += g[(size_t)__builtin_amdgcn_readlane(mine, t) * Cin + c];
         }
-        for (; j < s1; ++j) acc += g[(size_t)order[j] * Cin + c];
-        d_x[(size_t)m * Cin + c] = acc;
+        if (c0 + lane < Cin) d_x[(size_t)m * Cin + c0 + lane] = acc;
     }
 }
 
