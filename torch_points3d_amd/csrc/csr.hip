@@ -15,6 +15,8 @@
 namespace tp3d {
 
 constexpr int CSR_BLOCK = 1024;
+constexpr int CSR_SMALL_BIN = 24;   // bins up to this many slots are insertion-sorted by one thread
+constexpr int CSR_RANK_SLOTS = 16;  // slots per lane when a wave ranks a large bin (bins up to 1024 slots)
 constexpr int CSR_LDS_BYTES = 144 * 1024;
 
 // exclusive scan of cnt[0..n) in place (one workgroup); afterwards cnt[k] = #slots in bins < k
@@ -52,6 +54,48 @@ __device__ void block_exclusive_scan(CntPtr cnt, int n, int *s_wave /* CSR_BLOCK
     __syncthreads();
 }
 
+
+// Bitonic sort of one bin (n <= 64 * NU slot ids) by one wave: element i lives in lane i & 63, register i >> 6.
+template <int NU, typename OrdT>
+__device__ __forceinline__ void wave_sort_bin(OrdT *__restrict__ bin, int n, int lane)
+{
+    int e[NU];
+#pragma unroll
+    for (int u = 0; u < NU; ++u) e[u] = (lane + 64 * u < n) ? (int)bin[lane + 64 * u] : 0x7fffffff;
+#pragma unroll
+    for (int size = 2; size <= 64 * NU; size <<= 1) {
+#pragma unroll
+        for (int stride = size >> 1; stride >= 1; stride >>= 1) {
+            if (stride >= 64) {  // partner in the same lane, another register
+#pragma unroll
+                for (int u = 0; u < NU; ++u) {
+                    const int pu = u ^ (stride >> 6);
+                    if (pu > u) {
+                        const bool up = (((u << 6) | lane) & size) == 0;
+                        const int a = e[u], b = e[pu];
+                        const bool swap = up ? a > b : a < b;
+                        e[u] = swap ? b : a;
+                        e[pu] = swap ? a : b;
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int u = 0; u < NU; ++u) {
+                    const int other = __shfl_xor(e[u], stride);
+                    const bool up = (((u << 6) | lane) & size) == 0;
+                    const bool lower = (lane & stride) == 0;
+                    e[u] = (lower == up) ? min(e[u], other) : max(e[u], other);
+                }
+            }
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();  // (the loads above all happened before the first exchange)
+#pragma unroll
+    for (int u = 0; u < NU; ++u)
+        if (lane + 64 * u < n) bin[lane + 64 * u] = (OrdT)e[u];
+}
+
 // OrdT: uint16_t when L <= 65536 (LDS variant), int otherwise.
 template <typename OrdT, bool IN_LDS>
 __global__ __launch_bounds__(CSR_BLOCK) void csr_transpose_kernel(const int64_t *__restrict__ idx, int L, int nbins,
@@ -80,21 +124,56 @@ __global__ __launch_bounds__(CSR_BLOCK) void csr_transpose_kernel(const int64_t 
 
     for (int k = tid; k < nbins; k += CSR_BLOCK) cnt[k] = 0;
     __syncthreads();
-    for (int s = tid; s < L; s += CSR_BLOCK) {
-        int k = min(max((int)ib[s], 0), nbins - 1);
-        atomicAdd(&cnt[k], 1);
+    // Both slot passes were chains of (global index load -> LDS atomic), one 1024-slot window per iteration: ~2 us of
+    // L2 latency each, 2 x L/1024 times, with one workgroup per cloud.  The indices of PER windows are now fetched
+    // together into registers (and kept for the second pass when the cloud has at most PER windows), so the windows
+    // themselves only touch LDS.  The fill pass still walks the windows in order with a barrier between them: a bin
+    // must receive its slots in (nearly) ascending order or the insertion sort below degenerates (the padded tail of
+    // a dense ball query repeats one index up to nsample times).
+    constexpr int PER = 32;
+    int vals[PER];
+    const bool keep = L <= PER * CSR_BLOCK;
+    for (int base = 0; base < L; base += PER * CSR_BLOCK) {
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const int s = base + u * CSR_BLOCK + tid;
+            vals[u] = s < L ? min(max((int)ib[s], 0), nbins - 1) : -1;
+        }
+#pragma unroll
+        for (int u = 0; u < PER; ++u)
+            if (vals[u] >= 0) atomicAdd(&cnt[vals[u]], 1);
     }
     __syncthreads();
     block_exclusive_scan(cnt, nbins, s_wave);
-    for (int s = tid; s < L; s += CSR_BLOCK) {
-        int k = min(max((int)ib[s], 0), nbins - 1);
-        int pos = atomicAdd(&cnt[k], 1);  // cnt[k] ends as the END of bin k
-        ord[pos] = (OrdT)s;
+    for (int base = 0; base < L; base += PER * CSR_BLOCK) {
+        if (!keep) {
+#pragma unroll
+            for (int u = 0; u < PER; ++u) {
+                const int s = base + u * CSR_BLOCK + tid;
+                vals[u] = s < L ? min(max((int)ib[s], 0), nbins - 1) : -1;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            if (base + u * CSR_BLOCK < L) {  // workgroup-uniform: the barrier is reached by every thread
+                if (vals[u] >= 0) {
+                    const int pos = atomicAdd(&cnt[vals[u]], 1);  // cnt[k] ends as the END of bin k
+                    ord[pos] = (OrdT)(base + u * CSR_BLOCK + tid);
+                }
+                __syncthreads();
+            }
+        }
     }
     __syncthreads();
-    // canonical order inside every bin: ascending slot id
+    // canonical order inside every bin: ascending slot id.  Small bins: one thread each, insertion sort (arrival order
+    // is nearly sorted).  Large bins -- a point referenced by many slots: the padded tail of a dense ball query repeats
+    // its first hit up to nsample times per query, an interpolation table references each coarse point ~100 times --
+    // would serialise hundreds of dependent LDS steps in one thread (measured: 78 of 95 us for SA2's table), so a whole
+    // wave sorts such a bin instead: its slots sit in registers (up to 16 per lane) and go through a bitonic network
+    // (in-lane exchanges for strides >= 64, wave shuffles below).
     for (int k = tid; k < nbins; k += CSR_BLOCK) {
         const int lo = k ? cnt[k - 1] : 0, hi = cnt[k];
+        if (hi - lo > CSR_SMALL_BIN && hi - lo <= 64 * CSR_RANK_SLOTS) continue;  // ranked by a wave below
         for (int a = lo + 1; a < hi; ++a) {
             OrdT v = ord[a];
             int p = a;
@@ -103,6 +182,28 @@ __global__ __launch_bounds__(CSR_BLOCK) void csr_transpose_kernel(const int64_t 
                 --p;
             }
             ord[p] = v;
+        }
+    }
+    {
+        const int lane = tid & 63, wave = tid >> 6;
+        for (int k0 = wave * 64; k0 < nbins; k0 += (CSR_BLOCK / 64) * 64) {
+            const int k = k0 + lane;
+            int lo = 0, hi = 0;
+            if (k < nbins) {
+                lo = k ? cnt[k - 1] : 0;
+                hi = cnt[k];
+            }
+            unsigned long long big = __ballot(hi - lo > CSR_SMALL_BIN && hi - lo <= 64 * CSR_RANK_SLOTS);
+            while (big) {
+                const int l = __builtin_ctzll(big);
+                big &= big - 1;
+                const int blo = __builtin_amdgcn_readlane(lo, l), n = __builtin_amdgcn_readlane(hi, l) - blo;
+                if (n <= 64) wave_sort_bin<1>(ord + blo, n, lane);
+                else if (n <= 128) wave_sort_bin<2>(ord + blo, n, lane);
+                else if (n <= 256) wave_sort_bin<4>(ord + blo, n, lane);
+                else if (n <= 512) wave_sort_bin<8>(ord + blo, n, lane);
+                else wave_sort_bin<16>(ord + blo, n, lane);
+            }
         }
     }
     __syncthreads();
