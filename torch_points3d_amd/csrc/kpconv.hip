@@ -30,6 +30,8 @@ __device__ __forceinline__ void wave_lds_sync()
 constexpr int KP_BLOCK = 256;  // 4 waves, one query per wave
 constexpr int KP_MAX = 16;     // kernel points (15 in every reference config)
 constexpr int KP_NCH = 48;     // neighbours per LDS pass (covers every max_num_neighbors of the reference configs)
+constexpr int KP_GROUP = 16;   // neighbour rows fetched together in the forward accumulation
+static_assert(KP_NCH % KP_GROUP == 0 && KP_NCH <= 64, "phase A pads a chunk to whole groups, one lane per row");
 
 // Phase A of both per-query kernels: influence weight of every (neighbour, kernel point) pair of a chunk of <= KP_NCH
 // neighbours, into the wave's LDS slice.  Two steps so that a query costs two dependent global round trips instead of
@@ -43,8 +45,9 @@ __device__ __forceinline__ void kp_influence_weights(const float *__restrict__ s
                                                      float inv_extent, float gden, float (*w)[KP_MAX],
                                                      float (*dd)[KP_MAX], float4 *rel, int *ids, int lane)
 {
-    if (lane < cnt) {
-        const int64_t id = nbr_row[lane];
+    const int cntg = (cnt + KP_GROUP - 1) / KP_GROUP * KP_GROUP;  // rows [cnt, cntg) become shadows (zero weights)
+    if (lane < cntg) {
+        const int64_t id = lane < cnt ? nbr_row[lane] : -1;
         const bool shadow = id < 0 || id >= M;
         float4 r = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         if (!shadow) {
@@ -59,7 +62,7 @@ __device__ __forceinline__ void kp_influence_weights(const float *__restrict__ s
     const int k = lane & (KP_MAX - 1);
     const bool kreal = k < KP;
     const float kx = kreal ? kpts[k * 3 + 0] : 0.0f, ky = kreal ? kpts[k * 3 + 1] : 0.0f, kz = kreal ? kpts[k * 3 + 2] : 0.0f;
-    for (int n = lane / KP_MAX; n < cnt; n += 64 / KP_MAX) {
+    for (int n = lane / KP_MAX; n < cntg; n += 64 / KP_MAX) {
         const float4 r = rel[n];
         float wv = 0.0f, d2 = 3.0e38f;
         if (ids[n] >= 0 && kreal) {
@@ -129,25 +132,32 @@ __global__ __launch_bounds__(KP_BLOCK) void kpconv_weighted_kernel(
                                               gden, w, dd, rel, ids, lane);
             // ---- phase B: accumulate the neighbour rows into the KP accumulators (lanes over channels)
             if (c < Cin) {
-#pragma unroll 13
-                for (int n = 0; n < cnt; ++n) {
-                    const int id = ids[n];
-                    // shadow neighbours carry zero weights (phase A): reading row 0 instead keeps the loop branch-free
-                    const float v = feat[(size_t)max(id, 0) * Cin + c];
-                    const float4 w0 = *reinterpret_cast<const float4 *>(&w[n][0]);
-                    const float4 w1 = *reinterpret_cast<const float4 *>(&w[n][4]);
-                    const float4 w2 = *reinterpret_cast<const float4 *>(&w[n][8]);
-                    const float4 w3 = *reinterpret_cast<const float4 *>(&w[n][12]);
-                    // explicit fused multiply-adds: the translation unit is built with contraction off for the
-                    // distance expressions, the feature accumulation has no bit-exactness contract (1e-5 relative)
-                    acc[0] = __builtin_fmaf(w0.x, v, acc[0]);   acc[1] = __builtin_fmaf(w0.y, v, acc[1]);
-                    acc[2] = __builtin_fmaf(w0.z, v, acc[2]);   acc[3] = __builtin_fmaf(w0.w, v, acc[3]);
-                    acc[4] = __builtin_fmaf(w1.x, v, acc[4]);   acc[5] = __builtin_fmaf(w1.y, v, acc[5]);
-                    acc[6] = __builtin_fmaf(w1.z, v, acc[6]);   acc[7] = __builtin_fmaf(w1.w, v, acc[7]);
-                    acc[8] = __builtin_fmaf(w2.x, v, acc[8]);   acc[9] = __builtin_fmaf(w2.y, v, acc[9]);
-                    acc[10] = __builtin_fmaf(w2.z, v, acc[10]); acc[11] = __builtin_fmaf(w2.w, v, acc[11]);
-                    acc[12] = __builtin_fmaf(w3.x, v, acc[12]); acc[13] = __builtin_fmaf(w3.y, v, acc[13]);
-                    acc[14] = __builtin_fmaf(w3.z, v, acc[14]); acc[15] = __builtin_fmaf(w3.w, v, acc[15]);
+                // KP_GROUP neighbour rows are requested before any is used: the accumulation was a chain of dependent
+                // (LDS id -> global row) round trips, ~0.3 us per neighbour (measured with in-kernel clocks)
+                const int cntg = (cnt + KP_GROUP - 1) / KP_GROUP * KP_GROUP;
+                for (int g0 = 0; g0 < cntg; g0 += KP_GROUP) {
+                    float v[KP_GROUP];
+#pragma unroll
+                    for (int u = 0; u < KP_GROUP; ++u)  // shadow rows carry zero weights: row 0 stands in for them
+                        v[u] = feat[(size_t)max(ids[g0 + u], 0) * Cin + c];
+#pragma unroll
+                    for (int u = 0; u < KP_GROUP; ++u) {
+                        const int n = g0 + u;
+                        const float4 w0 = *reinterpret_cast<const float4 *>(&w[n][0]);
+                        const float4 w1 = *reinterpret_cast<const float4 *>(&w[n][4]);
+                        const float4 w2 = *reinterpret_cast<const float4 *>(&w[n][8]);
+                        const float4 w3 = *reinterpret_cast<const float4 *>(&w[n][12]);
+                        // explicit fused multiply-adds: the translation unit is built with contraction off for the
+                        // distance expressions, the feature accumulation has no bit-exactness contract (1e-5 relative)
+                        acc[0] = __builtin_fmaf(w0.x, v[u], acc[0]);   acc[1] = __builtin_fmaf(w0.y, v[u], acc[1]);
+                        acc[2] = __builtin_fmaf(w0.z, v[u], acc[2]);   acc[3] = __builtin_fmaf(w0.w, v[u], acc[3]);
+                        acc[4] = __builtin_fmaf(w1.x, v[u], acc[4]);   acc[5] = __builtin_fmaf(w1.y, v[u], acc[5]);
+                        acc[6] = __builtin_fmaf(w1.z, v[u], acc[6]);   acc[7] = __builtin_fmaf(w1.w, v[u], acc[7]);
+                        acc[8] = __builtin_fmaf(w2.x, v[u], acc[8]);   acc[9] = __builtin_fmaf(w2.y, v[u], acc[9]);
+                        acc[10] = __builtin_fmaf(w2.z, v[u], acc[10]); acc[11] = __builtin_fmaf(w2.w, v[u], acc[11]);
+                        acc[12] = __builtin_fmaf(w3.x, v[u], acc[12]); acc[13] = __builtin_fmaf(w3.y, v[u], acc[13]);
+                        acc[14] = __builtin_fmaf(w3.z, v[u], acc[14]); acc[15] = __builtin_fmaf(w3.w, v[u], acc[15]);
+                    }
                 }
             }
             wave_lds_sync();
