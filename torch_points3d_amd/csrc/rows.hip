@@ -94,9 +94,16 @@ __global__ __launch_bounds__(RW_BLOCK) void rows_gather_sum_kernel(const float *
                     acc = acc + v3;
                 }
             }
-            for (; t < cnt; ++t) {
-                const float v = base[(size_t)__builtin_amdgcn_readlane(my_r, t) * ld + c];
-                acc = acc + (ws ? rl_f(my_w, t) * v : v);
+            // tail of 1..3 rows (most runs of a grouping table are that short): requested together, summed in order
+            const int rem = cnt - t;
+            if (rem > 0) {
+                const int r0 = __builtin_amdgcn_readlane(my_r, t);
+                const int r1 = __builtin_amdgcn_readlane(my_r, min(t + 1, cnt - 1));
+                const int r2 = __builtin_amdgcn_readlane(my_r, min(t + 2, cnt - 1));
+                const float v0 = base[(size_t)r0 * ld + c], v1 = base[(size_t)r1 * ld + c], v2 = base[(size_t)r2 * ld + c];
+                acc = acc + (ws ? rl_f(my_w, t) * v0 : v0);
+                if (rem > 1) acc = acc + (ws ? rl_f(my_w, min(t + 1, cnt - 1)) * v1 : v1);
+                if (rem > 2) acc = acc + (ws ? rl_f(my_w, min(t + 2, cnt - 1)) * v2 : v2);
             }
         }
         if (c0 + lane < C) out[((size_t)b * nbins + dest) * C + c0 + lane] = acc;
