@@ -36,7 +36,8 @@ def _check(pos, batch):
 
 def voxel_cluster(pos, batch, size, return_counts=False, coord_bounds=None):
     """-> (cluster (N,), unique_pos_indices (K,), order (N,), cluster_start (K+1,)); all int64 on pos.device.
-    With return_counts=True also the number of clusters of every cloud (host int64 tensor).
+    With return_counts=True also the number of clusters of every cloud (host int64 tensor) and the coordinate extent
+    the key was built over (host int32 array: min x, y, z, max x, y, z, highest batch id, flag).
     coord_bounds: optional host sequence (min x, y, z, max x, y, z of round(pos / size), highest batch id) known to
     contain every point (e.g. derived from the bounding box of the cloud this one was sampled from); it replaces the
     device reduction and its host read.  The key only needs an enclosing extent, so a loose bound changes nothing.
@@ -51,7 +52,7 @@ def voxel_cluster(pos, batch, size, return_counts=False, coord_bounds=None):
     empty = torch.empty(0, dtype=torch.int64, device=dev)
     if N == 0:
         out = (empty, empty, empty, torch.zeros(1, dtype=torch.int64, device=dev))
-        return out + (torch.zeros(0, dtype=torch.int64),) if return_counts else out
+        return out + (torch.zeros(0, dtype=torch.int64), np.zeros(8, np.int32)) if return_counts else out
     pos = pos.detach().contiguous().float()
     if batch is not None:
         batch = batch.contiguous().long()
@@ -88,11 +89,11 @@ def voxel_cluster(pos, batch, size, return_counts=False, coord_bounds=None):
                 return voxel_cluster(pos, batch, size, return_counts=return_counts)
         K = int(meta_host[0])
     out = (cluster, last[:K], order, start[:K + 1])
-    voxel_cluster.last_bounds = bounds_host  # (GridSampling3D hands the extent on to the next, coarser level)
     if not return_counts:
         return out
     ends = torch.cummax(meta_host[1:], 0)[0]  # running cluster count after each cloud (empty clouds recorded 0)
-    return out + (torch.diff(ends, prepend=ends.new_zeros(1)),)
+    # + the coordinate extent the key was built over (GridSampling3D hands it on to the next, coarser level)
+    return out + (torch.diff(ends, prepend=ends.new_zeros(1)), bounds_host)
 
 
 def cluster_mean(x, order, cluster_start):
@@ -207,11 +208,10 @@ class GridSampling3D(object):
                 nb = _tp._segments(_tp._i64(batch))[1] - 1  # cached for a batch vector the searches have seen
             hint = [int(np.floor(pb[0][a] / size)) - 1 for a in range(3)] + \
                    [int(np.ceil(pb[1][a] / size)) + 1 for a in range(3)] + [max(nb, 0)]
-        cluster, unique_pos_indices, order, cluster_start, counts = voxel_cluster(
+        cluster, unique_pos_indices, order, cluster_start, counts, b = voxel_cluster(
             data.pos, batch, self._grid_size, return_counts=True, coord_bounds=hint)
         if data.pos.shape[0] > 0:
             if pb is None:
-                b = voxel_cluster.last_bounds
                 size = float(self._grid_size)
                 pb = ([(int(b[a]) - 0.5) * size for a in range(3)], [(int(b[3 + a]) + 0.5) * size for a in range(3)])
             data.pos_bounds = pb
