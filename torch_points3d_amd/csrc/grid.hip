@@ -221,13 +221,21 @@ __global__ __launch_bounds__(GQ_BLOCK) void grid_query_kernel(
                 j1v = cs[rowbase + x1 + 1];
             }
         }
-        for (int rr = 0; rr < 9 && !overflow; ++rr) {
+        // the first 64 points of all nine runs are requested before any is tested (a run is rarely longer): nine
+        // independent 16-byte loads per lane instead of nine dependent load -> test -> append rounds
+        float4 pre[9];
+#pragma unroll
+        for (int rr = 0; rr < 9; ++rr) {
+            const int j0 = __builtin_amdgcn_readlane(j0v, rr);
+            pre[rr] = sorted_pt[lo + min(j0 + lane, L - 1)];
+        }
+#pragma unroll
+        for (int rr = 0; rr < 9; ++rr) {
             const int j0 = __builtin_amdgcn_readlane(j0v, rr), j1 = __builtin_amdgcn_readlane(j1v, rr);
-            for (int j = j0; j < j1; j += 64) {
+            for (int j = j0; j < j1 && !overflow; j += 64) {
                 const int t = j + lane;
                 const bool valid = t < j1;
-                const int tt = valid ? t : j0;
-                const float4 pt = sorted_pt[lo + tt];
+                const float4 pt = (j == j0) ? pre[rr] : sorted_pt[lo + (valid ? t : j0)];
                 const float d = sqdist3(pt.x, pt.y, pt.z, qx, qy, qz);
                 const bool hit = valid && d < r2;
                 const unsigned long long mask = __ballot(hit);
