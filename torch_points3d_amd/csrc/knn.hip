@@ -130,45 +130,17 @@ __global__ __launch_bounds__(KQ_BLOCK) void grid_knn_kernel(
         if (MODE == 0) {
             float bd = 3.0e38f;
             int bi = 0x7fffffff;
-            // eight runs at a time: their first 64 points are requested together, then tested (a run is rarely longer);
-            // the nine runs of the first ring thus cost two load round trips instead of nine
-            {
-                const int ny = y1 - y0 + 1, nrows = (z1 - z0 + 1) * ny;
-                for (int r0 = 0; r0 < nrows; r0 += 64) {
-                    const int r = r0 + lane;
-                    int j0v = 0, j1v = 0;
-                    if (r < nrows) {
-                        const int rowbase = ((z0 + r / ny) * gi.gy + (y0 + r % ny)) * gi.gx;
-                        j0v = cs[rowbase + x0];
-                        j1v = cs[rowbase + x1 + 1];
-                    }
-                    const int cnt = min(64, nrows - r0);
-                    for (int g0 = 0; g0 < cnt; g0 += 8) {
-                        float4 pre[8];
-#pragma unroll
-                        for (int u = 0; u < 8; ++u) {
-                            const int j0 = __builtin_amdgcn_readlane(j0v, min(g0 + u, cnt - 1));
-                            pre[u] = sorted_pt[lo + min(j0 + lane, L - 1)];
-                        }
-#pragma unroll
-                        for (int u = 0; u < 8; ++u) {
-                            if (g0 + u >= cnt) continue;  // wave-uniform
-                            const int j0 = __builtin_amdgcn_readlane(j0v, g0 + u), j1 = __builtin_amdgcn_readlane(j1v, g0 + u);
-                            for (int j = j0 + lane; j - lane < j1; j += 64) {
-                                if (j < j1) {
-                                    const float4 pt = (j - lane == j0) ? pre[u] : sorted_pt[lo + j];
-                                    const float d = sqdist3(pt.x, pt.y, pt.z, qx, qy, qz);
-                                    const int id = __float_as_int(pt.w);
-                                    if (pair_less(d, id, bd, bi)) {
-                                        bd = d;
-                                        bi = id;
-                                    }
-                                }
-                            }
-                        }
+            for_each_run([&](int j0, int j1) {
+                for (int j = j0 + lane; j < j1; j += 64) {
+                    const float4 pt = sorted_pt[lo + j];
+                    const float d = sqdist3(pt.x, pt.y, pt.z, qx, qy, qz);
+                    const int id = __float_as_int(pt.w);
+                    if (pair_less(d, id, bd, bi)) {
+                        bd = d;
+                        bi = id;
                     }
                 }
-            }
+            });
             wave_argmin(bd, bi);
             const bool found = bi != 0x7fffffff;
             if (whole || (found && bd <= cover2)) {  // `whole` always ends the search (found unless the input is NaN)
