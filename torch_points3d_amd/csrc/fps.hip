@@ -118,21 +118,36 @@ __global__ __launch_bounds__(BLOCK) void fps_reg_kernel(const float *__restrict_
     float lx = p[0], ly = p[1], lz = p[2];
 
     for (int it = 1; it < npoint; ++it) {
-        // distance update + per-lane max VALUE only (the index is resolved once per wave, below)
-        float best = -1.0f;
+        // distance update + per-lane max VALUE only (the index is resolved once per wave, below); the maxima are kept
+        // per group of 8 slots so that the resolution can skip the groups that do not hold the wave's maximum
+        constexpr int NG = P >= 16 ? P / 8 : 1;  // slot groups
+        constexpr int GS = P / NG;               // slots per group
+        float gmax[NG];
+#pragma unroll
+        for (int g = 0; g < NG; ++g) gmax[g] = -1.0f;
 #pragma unroll
         for (int h = 0; h < H; ++h) {
             const f2 dx = px[h] - lx, dy = py[h] - ly, dz = pz[h] - lz;
             const f2 d = (dx * dx + dy * dy) + dz * dz;  // same order as sqdist3; contraction is off
             md[h][0] = fminf(md[h][0], d[0]);
             md[h][1] = fminf(md[h][1], d[1]);
-            best = fmaxf(fmaxf(best, md[h][0]), md[h][1]);
+            gmax[(2 * h) / GS] = fmaxf(fmaxf(gmax[(2 * h) / GS], md[h][0]), md[h][1]);
         }
-        // wave arg-max: max value, then the lowest index among the (lane, slot) pairs that hold it
+        float best = gmax[0];
+#pragma unroll
+        for (int g = 1; g < NG; ++g) best = fmaxf(best, gmax[g]);
+        // wave arg-max: max value, then the lowest index among the (lane, slot) pairs that hold it.  Only the groups in
+        // which some lane holds the maximum are scanned (in-kernel clocks: scanning all 32 slots in every lane cost
+        // 0.37 us of a 1.30 us step, more than the distance update itself)
         const float wv = wave_allmax(best);
         int bi = 0x7fffffff;
 #pragma unroll
-        for (int k = P - 1; k >= 0; --k) bi = (md[k / 2][k & 1] == wv) ? t + k * BLOCK : bi;  // lowest slot wins
+        for (int g = NG - 1; g >= 0; --g) {  // descending: a lower slot overwrites, the lowest slot wins
+            if (NG == 1 || __ballot(gmax[g] == wv)) {
+#pragma unroll
+                for (int k = (g + 1) * GS - 1; k >= g * GS; --k) bi = (md[k / 2][k & 1] == wv) ? t + k * BLOCK : bi;
+            }
+        }
         const int wi = wave_allmin(bi);
         // owner of wi inside this wave: thread wi % BLOCK (same wave by construction), slot wi / BLOCK
         const int wslot = (wi == 0x7fffffff) ? 0 : wi / BLOCK;
