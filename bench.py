@@ -271,13 +271,14 @@ def main():
     if graphed and rank == 0:
         # per-kernel HIP-event timing needs eager launches: the same K steps again, outside the headline region
         # (rank 0 only; no collective is involved in this pass)
-        world_saved, trainer.world = trainer.world, 1
+        saved = (trainer.world, trainer.reduce_always)
+        trainer.world, trainer.reduce_always = 1, False
         _lib.set_timer(timer)
         for _ in range(args.steps):
             trainer.eager_step()
         torch.cuda.synchronize()
         _lib.set_timer(None)
-        trainer.world = world_saved
+        trainer.world, trainer.reduce_always = saved
     log("timed region done: %.2f ms/step (host enqueue %.2f ms/step)" % (dt / args.steps * 1e3,
                                                                           t_enqueued / args.steps * 1e3))
 
