@@ -188,6 +188,92 @@ def cpu_baseline(sample_b, iters):
     }
 
 
+def run_kpconv(args):
+    """BASELINE configs[3]: KPConv rigid segmentation forward (radius neighbours + kernel-point convolution, unet_4,
+    in_feat 64, 25 neighbours), one synthetic cloud of 65 536 points at one point per 0.02 voxel, eval mode, fp32.
+    A step = one forward pass including grid sampling, radius searches and kNN up-sampling (nothing precomputed)."""
+    if args.gpus != 1 or int(os.environ.get("WORLD_SIZE", "1")) != 1:
+        raise SystemExit("--workload kpconv is a single-GPU line")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools"))
+    from bench_kpconv import synthetic_cloud
+    from torch_points3d_amd import _lib
+    from torch_points3d_amd.kpconv_blocks import PDData
+    from torch_points3d_amd.kpconv_unet import KPConv
+    _lib.load()
+    device = torch.device("cuda", 0)
+    torch.manual_seed(0)
+    n = 65536
+    model = KPConv("unet", input_nc=3, in_feat=64, in_grid_size=0.02, num_layers=4, output_nc=13).to(device).eval()
+    pos, batch = synthetic_cloud(n, 1, 0.02)
+    x = torch.cat([torch.ones(n, 1), torch.randn(n, 3)], 1)
+    dpos, dbatch, dx = pos.to(device), batch.to(device), x.to(device)
+
+    def step():
+        with torch.no_grad():
+            return model(PDData(pos=dpos, batch=dbatch, x=dx))
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    timer = _lib.KernelTimer()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    _lib.set_timer(timer)
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    _lib.set_timer(None)
+    per = {}
+    for (name, a), (cnt, tot) in timer.summary().items():
+        c, t = per.get(name, (0, 0.0))
+        per[name] = (c + cnt, t + tot)
+    dom, (dcnt, dtot) = max(per.items(), key=lambda kv: kv[1][1])
+    # algorithmic bytes of the dominant entry point (stage 1 of the convolution: neighbour ids + rows once, wf once),
+    # summed over its launches of one forward pass from the recorded sizes
+    alg = 0.0
+    for (name, a), (cnt, tot) in timer.summary().items():
+        if name == dom and name == "tp3d_kpconv_weighted_f32":
+            Nq, M, Mn, Cin, KP = a[0], a[1], a[2], a[3], a[4]
+            alg += cnt * (Nq * Mn * (8 + 4 * Cin) + Nq * KP * Cin * 4.0)
+    roof = {"kernel": dom, "bound": "hbm", "achieved": round(alg / 1e9 / (dtot / 1e3), 2) if alg else None, "peak": 8000.0,
+            "unit": "GB/s", "frac": round(alg / 1e9 / (dtot / 1e3) / 8000.0, 5) if alg else None, "traffic": None,
+            "launches": dcnt, "ms_per_step": round(dtot / args.steps, 4)}
+    base = None
+    if not args.no_cpu_baseline:
+        from oracle import tpk_ref
+        from oracle.kpconv_cpu import cpu_mirror
+        tpk_ref.build()
+        threads = cpu_share()
+        torch.set_num_threads(threads)
+        tpk_ref.set_num_threads(threads)
+        cpu, routed = cpu_mirror(model)
+        cpu.eval()
+        with routed(), torch.no_grad():
+            t1 = time.perf_counter()
+            ref = cpu(PDData(pos=pos, batch=batch, x=x))
+            sec = time.perf_counter() - t1
+        err = float((out.x.cpu() - ref.x).abs().max() / ref.x.abs().max())
+        base = {"value": n / sec, "unit": "points/s", "cores": threads, "kind": "port",
+                "sample": "1 forward of the same model on the same cloud: reference block logic mirrored on the CPU with "
+                          "oracle/tpk_ref_cpu.c radius search + kNN, oracle/voxel_ref.py grid sampling, PyTorch-CPU "
+                          "KPConv_ops / Linear / BatchNorm", "seconds": sec, "max_rel_diff_vs_gpu": err}
+    print(json.dumps({
+        "metric": "points/sec KPConv unet_4 forward N=65536", "value": round(n * args.steps / dt, 1), "unit": "points/s",
+        "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "KPConv rigid segmentation forward (applications/kpconv.py unet_4, in_feat 64, grid 0.02, 25 "
+                               "neighbours, 13 classes), one cloud of 65536 points (BASELINE configs[3]); sampling and "
+                               "searches inside the timed region", "launch": "eager"},
+        "roofline": roof, "cpu_baseline": base,
+        "entry_points": [{"entry": k, "launches_per_step": v[0] / args.steps, "ms_per_step": round(v[1] / args.steps, 4)}
+                         for k, v in sorted(per.items(), key=lambda kv: -kv[1][1])]}))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -204,7 +290,13 @@ def main():
                     "(rehearsal of the multi-process code path on a single-GPU box)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse "
                     "the multi-process path on a box with fewer GPUs than ranks)")
+    ap.add_argument("--workload", default="pointnet2", choices=["pointnet2", "kpconv"],
+                    help="pointnet2: the headline metric (BASELINE configs[1] shapes).  kpconv: BASELINE configs[3], "
+                         "KPConv unet_4 forward on one 65 536-point cloud, with the CPU mirror of the same modules on "
+                         "the oracle kernels as baseline (single GPU only; an extra line, not the headline)")
     args = ap.parse_args()
+    if args.workload == "kpconv":
+        return run_kpconv(args)
 
     global MODEL_CONFIG
     MODEL_CONFIG = args.model

@@ -7,6 +7,8 @@ import numpy as np
 import pytest
 import torch
 
+from oracle.kpconv_cpu import torch_knn_interpolate
+
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
@@ -79,19 +81,6 @@ def test_ball_query_large_cloud_uses_sorted_grid_build(hip, oracle, M, Nq, nsamp
     ref_idx, ref_d2 = oracle.ball_query(r, nsample, x, y, mode="partial_dense", batch_x=bx, batch_y=by, sort=sort)
     assert torch.equal(idx.cpu(), ref_idx)
     assert torch.equal(d2.cpu(), ref_d2)
-
-
-def torch_knn_interpolate(x, idx, d2):
-    """torch_geometric's knn_interpolate on given neighbours, literal (scatter_add in edge order)."""
-    Nq, k = idx.shape
-    y_idx = torch.arange(Nq).repeat_interleave(k)
-    x_idx = idx.reshape(-1)
-    keep = x_idx >= 0
-    w = 1.0 / torch.clamp(d2.reshape(-1, 1), min=1e-16)
-    y_idx, x_idx, w = y_idx[keep], x_idx[keep], w[keep]
-    num = torch.zeros(Nq, x.shape[1]).index_add_(0, y_idx, x[x_idx] * w)
-    den = torch.zeros(Nq, 1).index_add_(0, y_idx, w)
-    return num / den
 
 
 @pytest.mark.parametrize("k,C,C2", [(1, 64, 32), (3, 17, 0), (3, 128, 128), (5, 4, 3)])

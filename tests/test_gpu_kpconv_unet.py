@@ -9,39 +9,10 @@ import numpy as np
 import pytest
 import torch
 
-from oracle import voxel_ref
-from test_gpu_knn import torch_knn_interpolate
-from test_gpu_kpconv import torch_kpconv
+from oracle.kpconv_cpu import cpu_mirror
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
-
-
-class CpuSampler(object):
-    def __init__(self, size):
-        self.size = size
-
-    def __call__(self, data):
-        out = voxel_ref.grid_sampling_mean(data.pos.numpy(), self.size, batch=data.batch.numpy(), x=data.x.detach().numpy())
-        data.pos = torch.from_numpy(out["pos"])
-        data.batch = torch.from_numpy(out["batch"])
-        data.x = torch.from_numpy(out["x"])
-        data.grid_size = torch.tensor([self.size])
-        return data
-
-
-class CpuInterp(object):
-    def __init__(self, k, oracle):
-        self.k, self.oracle = k, oracle
-
-    def __call__(self, query, support, precomputed=None, skip=None):
-        idx, d2 = self.oracle.knn(self.k, query.pos, support.pos, query.batch, support.batch)
-        y = torch_knn_interpolate(query.x, idx, d2)
-        return y if skip is None else torch.cat([y, skip], dim=1)
-
-
-def cpu_kpconv_ops(q, s, nbr, feats, kp, W, extent, influence, aggregation):
-    return torch_kpconv(q, s, nbr, feats, kp, W, extent, influence, aggregation)
 
 
 def make_input(n, clouds, seed, nc):
@@ -53,12 +24,9 @@ def make_input(n, clouds, seed, nc):
 
 
 @pytest.mark.parametrize("n,clouds,in_feat,output_nc", [(12000, 2, 16, None), (20000, 3, 8, 5)])
-def test_unet_matches_cpu_mirror(oracle, monkeypatch, n, clouds, in_feat, output_nc):
-    from torch_points3d_amd import kpconv as kpconv_mod
-    from torch_points3d_amd import torchpoints as tp_mod
+def test_unet_matches_cpu_mirror(n, clouds, in_feat, output_nc):
     from torch_points3d_amd.kpconv_blocks import PDData, SimpleBlock
     from torch_points3d_amd.kpconv_unet import KPConv
-    from torch_points3d_amd.partial_dense import FPModule_PD
     torch.manual_seed(1)
     model = KPConv("unet", input_nc=3, in_feat=in_feat, in_grid_size=0.02, num_layers=4, output_nc=output_nc)
     pos, batch, x = make_input(n, clouds, n, 3)
@@ -76,20 +44,15 @@ def test_unet_matches_cpu_mirror(oracle, monkeypatch, n, clouds, in_feat, output
     loss.backward()
 
     # ---- CPU mirror: same modules, oracle kernels
-    cpu = copy.deepcopy(model)
+    cpu, routed = cpu_mirror(model)
     cpu_levels = []
     for m in cpu.modules():
         if isinstance(m, SimpleBlock):
-            if m.sampler is not None:
-                m.sampler = CpuSampler(m.sampler._grid_size)
             m.register_forward_hook(lambda mod, inp, out: cpu_levels.append((out.pos, out.batch, out.idx_neighboors)))
-        if isinstance(m, FPModule_PD):
-            m.upsample_op = CpuInterp(m.upsample_op.k, oracle)
-    monkeypatch.setattr(tp_mod, "ball_query", oracle.ball_query)
-    monkeypatch.setattr(kpconv_mod, "KPConv_ops", cpu_kpconv_ops)
     xc = x.clone().requires_grad_(True)
-    ref = cpu(PDData(pos=pos, batch=batch, x=xc))
-    (ref.x * torch.linspace(-1, 1, ref.x.shape[1])).sum().backward()
+    with routed():
+        ref = cpu(PDData(pos=pos, batch=batch, x=xc))
+        (ref.x * torch.linspace(-1, 1, ref.x.shape[1])).sum().backward()
 
     assert len(levels) == len(cpu_levels) == 10
     for (gp, gb, gi), (cp, cb, ci) in zip(levels, cpu_levels):
