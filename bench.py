@@ -274,6 +274,78 @@ def run_kpconv(args):
                          for k, v in sorted(per.items(), key=lambda kv: -kv[1][1])]}))
 
 
+def run_knn(args):
+    """BASELINE configs[4] leg: RandLA-Net's random subsample (ratio 0.25, with replacement) + exact kNN (k = 16) of the
+    sampled points in the full cloud (reference modules/RandLANet/modules.py:57-67), one room-shaped scene of 10^6
+    surface points.  A step = sampler + neighbour search; the unit is queries per second."""
+    if args.gpus != 1 or int(os.environ.get("WORLD_SIZE", "1")) != 1:
+        raise SystemExit("--workload knn is a single-GPU line")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools"))
+    from bench_knn import room
+    from torch_points3d_amd import _lib, torchpoints as tp
+    from torch_points3d_amd.randla import RandomSampler
+    _lib.load()
+    device = torch.device("cuda", 0)
+    n, k = 1000000, 16
+    pos_cpu = room(n)
+    pos = pos_cpu.to(device)
+    batch = torch.zeros(n, dtype=torch.long, device=device)
+    sampler = RandomSampler(ratio=0.25)
+
+    def step():
+        idx = sampler(pos, batch=batch)
+        q = pos[idx]
+        return idx, q, tp.knn(k, pos, q, batch, batch[idx])
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        idx, q, (nbr, d2) = step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    nq = q.shape[0]
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    by = batch[idx]
+    a.record()
+    for _ in range(args.steps):
+        tp.knn(k, pos, q, batch, by)
+    b.record()
+    torch.cuda.synchronize()
+    knn_ms = a.elapsed_time(b) / args.steps
+    alg = n * 12 + nq * 12 + nq * k * 12.0  # support + queries read once, (idx, dist2) written once
+    roof = {"kernel": "tp3d_knn_partial_dense_f32", "bound": "hbm", "achieved": round(alg / 1e9 / (knn_ms / 1e3), 2),
+            "peak": 8000.0, "unit": "GB/s", "frac": round(alg / 1e9 / (knn_ms / 1e3) / 8000.0, 5), "traffic": None,
+            "avg_launch_ms": round(knn_ms, 4),
+            "note": "grid build + query kernels of one call; the search is VALU / latency shaped, not bandwidth shaped"}
+    base = None
+    if not args.no_cpu_baseline:
+        from oracle import tpk_ref
+        tpk_ref.build()
+        threads = cpu_share()
+        tpk_ref.set_num_threads(threads)
+        sel = torch.randperm(nq)[:4096]
+        qs = q.cpu()[sel].contiguous()
+        t1 = time.perf_counter()
+        ref_idx, ref_d2 = tpk_ref.knn(k, pos_cpu, qs)
+        sec = time.perf_counter() - t1
+        same = bool(torch.equal(ref_idx, nbr.cpu()[sel]) and torch.equal(ref_d2, d2.cpu()[sel]))
+        base = {"value": sel.numel() / sec, "unit": "queries/s", "cores": threads, "kind": "port",
+                "sample": "%d of the %d queries, brute force over the 10^6 points (oracle/tpk_ref_cpu.c, OpenMP over "
+                          "queries)" % (sel.numel(), nq), "seconds": sec, "gpu_result_identical_on_sample": same}
+    print(json.dumps({
+        "metric": "queries/sec random-subsample + exact 16-NN, N=10^6", "value": round(nq * args.steps / dt, 1),
+        "unit": "queries/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "RandLA-Net sampling + neighbour search leg (BASELINE configs[4]): one room-shaped scene of "
+                               "10^6 surface points, 250000 queries drawn with replacement, k = 16", "launch": "eager"},
+        "roofline": roof, "cpu_baseline": base}))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -290,13 +362,17 @@ def main():
                     "(rehearsal of the multi-process code path on a single-GPU box)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse "
                     "the multi-process path on a box with fewer GPUs than ranks)")
-    ap.add_argument("--workload", default="pointnet2", choices=["pointnet2", "kpconv"],
+    ap.add_argument("--workload", default="pointnet2", choices=["pointnet2", "kpconv", "knn"],
                     help="pointnet2: the headline metric (BASELINE configs[1] shapes).  kpconv: BASELINE configs[3], "
                          "KPConv unet_4 forward on one 65 536-point cloud, with the CPU mirror of the same modules on "
-                         "the oracle kernels as baseline (single GPU only; an extra line, not the headline)")
+                         "the oracle kernels as baseline.  knn: BASELINE configs[4] leg, random subsample + exact 16-NN on "
+                         "a 10^6-point scene, brute-force oracle on a query sample as baseline.  (Both single GPU; "
+                         "extra lines, not the headline)")
     args = ap.parse_args()
     if args.workload == "kpconv":
         return run_kpconv(args)
+    if args.workload == "knn":
+        return run_knn(args)
 
     global MODEL_CONFIG
     MODEL_CONFIG = args.model
