@@ -3,7 +3,6 @@
 
 Indices are compared bit-exact with the brute-force oracle (oracle/tpk_ref_cpu.c: tpk_ref_knn_partial_dense_f32; same
 fp32 distance expression, ties by lower index).  Parity against torch_cluster's `knn` itself is unpinned (absent)."""
-import numpy as np
 import pytest
 import torch
 

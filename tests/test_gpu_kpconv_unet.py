@@ -5,7 +5,6 @@ plain PyTorch fp32.  Level geometry (sampled positions, neighbour tables) must a
 1e-3 of the output scale (ten BatchNorm-normalised blocks deep, library GEMMs on both sides)."""
 import copy
 
-import numpy as np
 import pytest
 import torch
 

@@ -11,7 +11,6 @@ for four layers: level 0 = SimpleBlock(FEAT+1 -> f) + ResnetBBlock(f -> 2f); lev
 (2^i f -> 2^i f, grid doubles) + ResnetBBlock(2^i f -> 2^(i+1) f); decoder = FPModule_PD(up_k = 1) with
 [48f, 8f], [16f, 4f], [8f, 2f], [4f, f] for four layers.
 """
-import torch
 import torch.nn as nn
 
 from . import fused as _fused
