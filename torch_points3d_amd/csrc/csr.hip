@@ -55,47 +55,6 @@ __device__ void block_exclusive_scan(CntPtr cnt, int n, int *s_wave /* CSR_BLOCK
 }
 
 
-// Bitonic sort of one bin (n <= 64 * NU slot ids) by one wave: element i lives in lane i & 63, register i >> 6.
-template <int NU, typename OrdT>
-__device__ __forceinline__ void wave_sort_bin(OrdT *__restrict__ bin, int n, int lane)
-{
-    int e[NU];
-#pragma unroll
-    for (int u = 0; u < NU; ++u) e[u] = (lane + 64 * u < n) ? (int)bin[lane + 64 * u] : 0x7fffffff;
-#pragma unroll
-    for (int size = 2; size <= 64 * NU; size <<= 1) {
-#pragma unroll
-        for (int stride = size >> 1; stride >= 1; stride >>= 1) {
-            if (stride >= 64) {  // partner in the same lane, another register
-#pragma unroll
-                for (int u = 0; u < NU; ++u) {
-                    const int pu = u ^ (stride >> 6);
-                    if (pu > u) {
-                        const bool up = (((u << 6) | lane) & size) == 0;
-                        const int a = e[u], b = e[pu];
-                        const bool swap = up ? a > b : a < b;
-                        e[u] = swap ? b : a;
-                        e[pu] = swap ? a : b;
-                    }
-                }
-            } else {
-#pragma unroll
-                for (int u = 0; u < NU; ++u) {
-                    const int other = __shfl_xor(e[u], stride);
-                    const bool up = (((u << 6) | lane) & size) == 0;
-                    const bool lower = (lane & stride) == 0;
-                    e[u] = (lower == up) ? min(e[u], other) : max(e[u], other);
-                }
-            }
-        }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_wave_barrier();  // (the loads above all happened before the first exchange)
-#pragma unroll
-    for (int u = 0; u < NU; ++u)
-        if (lane + 64 * u < n) bin[lane + 64 * u] = (OrdT)e[u];
-}
-
 // OrdT: uint16_t when L <= 65536 (LDS variant), int otherwise.
 template <typename OrdT, bool IN_LDS>
 __global__ __launch_bounds__(CSR_BLOCK) void csr_transpose_kernel(const int64_t *__restrict__ idx, int L, int nbins,
@@ -230,7 +189,10 @@ __global__ __launch_bounds__(CSR_BLOCK) void csr_transpose_kernel(const int64_t 
     }
 }
 
+bool csr_fits_lds(int L, int nbins);
 size_t csr_lds_bytes(int L, int nbins) { return (((size_t)nbins * 4 + 15) & ~(size_t)15) + (size_t)L * 2; }
+
+bool csr_fits_lds(int L, int nbins) { return L <= 65536 && csr_lds_bytes(L, nbins) <= (size_t)CSR_LDS_BYTES; }
 
 // Enqueue the transpose. start: B*(nbins+1) ints, order: B*L ints, wsorted: B*L floats or null,
 // scratch_ord: B*L ints, only touched when the tables do not fit LDS.

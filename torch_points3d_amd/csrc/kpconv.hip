@@ -205,10 +205,19 @@ TP3D_EXPORT int tp3d_kpconv_weighted_f32(const float *query, const float *suppor
 // recomputes the KP influence weights of each of its slots and accumulates coalesced d_wf row segments.
 namespace tp3d {
 
-__global__ void nbr_hist_kernel(const int64_t *__restrict__ nbr, int64_t slots, int64_t M, int *__restrict__ cnt)
+// bin of slot s: the table entry itself, or -- for a batch of per-cloud tables flattened into one -- the entry clamped
+// to its cloud's bins plus the cloud's offset
+__device__ __forceinline__ int64_t slot_bin(const int64_t *__restrict__ nbr, int64_t s, int64_t L, int64_t nbins)
+{
+    const int64_t m = nbr[s];
+    return L > 0 ? min(max(m, (int64_t)0), nbins - 1) + (s / L) * nbins : m;
+}
+
+__global__ void nbr_hist_kernel(const int64_t *__restrict__ nbr, int64_t slots, int64_t M, int *__restrict__ cnt,
+                                int64_t L, int64_t nbins)
 {
     for (int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; s < slots; s += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t m = nbr[s];
+        const int64_t m = slot_bin(nbr, s, L, nbins);
         if (m >= 0 && m < M) atomicAdd(&cnt[m], 1);
     }
 }
@@ -251,27 +260,50 @@ __global__ __launch_bounds__(1024) void nbr_scan_kernel(const int *__restrict__ 
 }
 
 __global__ void nbr_fill_kernel(const int64_t *__restrict__ nbr, int64_t slots, int64_t M, int *__restrict__ cursor,
-                                int *__restrict__ order)
+                                int *__restrict__ order, int64_t L, int64_t nbins)
 {
     for (int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; s < slots; s += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t m = nbr[s];
+        const int64_t m = slot_bin(nbr, s, L, nbins);
         if (m >= 0 && m < M) order[atomicAdd(&cursor[m], 1)] = (int)s;
     }
 }
 
-__global__ void nbr_sort_kernel(const int *__restrict__ start, int64_t M, int *__restrict__ order)
+// canonical order inside every bin (ascending slot id): one lane per bin for bins of up to NBR_SMALL_BIN slots
+// (insertion sort; the fill leaves them nearly sorted), a whole wave's bitonic network for larger ones -- a point that
+// hundreds of slots reference (padded tails of dense ball queries) would otherwise be hundreds of dependent global
+// round trips in one thread
+constexpr int NBR_SMALL_BIN = 24;
+__global__ __launch_bounds__(256) void nbr_sort_kernel(const int *__restrict__ start, int64_t M, int *__restrict__ order)
 {
+    const int lane = threadIdx.x & 63;
     const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (m >= M) return;
-    const int s0 = start[m], s1 = start[m + 1];
-    for (int a = s0 + 1; a < s1; ++a) {
-        const int v = order[a];
-        int p = a;
-        while (p > s0 && order[p - 1] > v) {
-            order[p] = order[p - 1];
-            --p;
+    int s0 = 0, s1 = 0;
+    if (m < M) {
+        s0 = start[m];
+        s1 = start[m + 1];
+    }
+    const int n = s1 - s0;
+    if (n <= NBR_SMALL_BIN || n > 1024) {
+        for (int a = s0 + 1; a < s1; ++a) {
+            const int v = order[a];
+            int p = a;
+            while (p > s0 && order[p - 1] > v) {
+                order[p] = order[p - 1];
+                --p;
+            }
+            order[p] = v;
         }
-        order[p] = v;
+    }
+    unsigned long long big = __ballot(n > NBR_SMALL_BIN && n <= 1024);
+    while (big) {  // wave-uniform
+        const int l = __builtin_ctzll(big);
+        big &= big - 1;
+        const int blo = __builtin_amdgcn_readlane(s0, l), bn = __builtin_amdgcn_readlane(n, l);
+        if (bn <= 64) wave_sort_bin<1>(order + blo, bn, lane);
+        else if (bn <= 128) wave_sort_bin<2>(order + blo, bn, lane);
+        else if (bn <= 256) wave_sort_bin<4>(order + blo, bn, lane);
+        else if (bn <= 512) wave_sort_bin<8>(order + blo, bn, lane);
+        else wave_sort_bin<16>(order + blo, bn, lane);
     }
 }
 
@@ -279,13 +311,14 @@ __global__ void nbr_sort_kernel(const int *__restrict__ start, int64_t M, int *_
 // (integer histogram -> scan -> fill -> per-bin insertion sort of its short run).  Entries outside [0, M) are skipped.
 // cnt, cursor: M ints; start: M + 1 ints; order: `slots` ints.
 int invert_table(const int64_t *idx, int64_t slots, int64_t M, int *cnt, int *start, int *cursor, int *order,
-                 hipStream_t s)
+                 hipStream_t s, int64_t per_cloud_slots, int64_t per_cloud_bins)
 {
     if (int rc = zero_async(cnt, (size_t)M * 4, s)) return rc;
     const unsigned gs = (unsigned)std::min<int64_t>((slots + 255) / 256, 4096);
-    hipLaunchKernelGGL(nbr_hist_kernel, dim3(gs), dim3(256), 0, s, idx, slots, M, cnt);
+    hipLaunchKernelGGL(nbr_hist_kernel, dim3(gs), dim3(256), 0, s, idx, slots, M, cnt, per_cloud_slots, per_cloud_bins);
     hipLaunchKernelGGL(nbr_scan_kernel, dim3(1), dim3(1024), 0, s, cnt, M, start, cursor);
-    hipLaunchKernelGGL(nbr_fill_kernel, dim3(gs), dim3(256), 0, s, idx, slots, M, cursor, order);
+    hipLaunchKernelGGL(nbr_fill_kernel, dim3(gs), dim3(256), 0, s, idx, slots, M, cursor, order, per_cloud_slots,
+                       per_cloud_bins);
     hipLaunchKernelGGL(nbr_sort_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, s, start, M, order);
     return check_launch();
 }

@@ -58,17 +58,18 @@ __global__ __launch_bounds__(RW_BLOCK) void rows_gather_sum_kernel(const float *
                                                                     const int *__restrict__ order,
                                                                     const float *__restrict__ wsorted, int nbins,
                                                                     int L, int rows_per_cloud, int ld, int col0,
-                                                                    int C, float *__restrict__ out)
+                                                                    int C, float *__restrict__ out, int flat)
 {
     const int lane = threadIdx.x & 63;
     const int64_t dest = (int64_t)blockIdx.x * (RW_BLOCK / 64) + (threadIdx.x >> 6);  // destination point k
     const int b = blockIdx.y;
     if (dest >= nbins) return;
-    const int *st = start + (size_t)b * (nbins + 1);
-    const int *od = order + (size_t)b * L;
-    const float *ws = wsorted ? wsorted + (size_t)b * L : nullptr;
+    // flat: one table over the whole batch (bins b*nbins + k, entries are batch-wide row ids); else one per cloud
+    const int *st = flat ? start + (size_t)b * nbins : start + (size_t)b * (nbins + 1);
+    const int *od = flat ? order : order + (size_t)b * L;
+    const float *ws = wsorted ? (flat ? wsorted : wsorted + (size_t)b * L) : nullptr;
     const int lo = st[dest], hi = st[dest + 1];
-    const float *base = grad_rows + (size_t)b * rows_per_cloud * ld + col0;
+    const float *base = grad_rows + (flat ? (size_t)0 : (size_t)b * rows_per_cloud * ld) + col0;
     for (int c0 = 0; c0 < C; c0 += 64) {
         const int c = min(c0 + lane, C - 1);
         float acc = 0.0f;
@@ -575,19 +576,22 @@ TP3D_EXPORT int tp3d_rows_scatter_bwd_f32(const float *grad_rows, const int64_t 
     if (!grad_rows || !idx || !workspace || B > 65535) return TP3D_E_BADARG;
     ScatterWorkspace w = carve_scatter_workspace(workspace, B, L, nbins, weight != nullptr);
     if (workspace_bytes < w.bytes) return TP3D_E_BADARG;
-    if (B == 1 && L >= 16384 && L >= 2 * nbins) {
-        // one large cloud (partial-dense decoders): the per-cloud transpose would be a single workgroup; invert the
-        // table over the whole device instead (scratch holds the histogram and the cursors), then turn slot ids into
-        // row ids and line the weights up with them
-        if (int rc = invert_table(idx, L, nbins, w.scratch, w.start, w.scratch + nbins, w.order, s)) return rc;
-        hipLaunchKernelGGL(slots_to_rows_kernel, dim3((L + 255) / 256), dim3(256), 0, s, w.order, weight, div, L, w.start,
-                           nbins, w.wsorted);
+    // One large cloud (partial-dense decoders), or clouds whose tables do not fit one workgroup's LDS (multi-scale
+    // grouping: 512 x 128 slots per cloud): invert ONE flat table over the whole device instead of one table per
+    // workgroup (scratch holds the histogram and the cursors), then turn slot ids into row ids and line the weights up.
+    const bool flat = L >= 2 * nbins && (int64_t)B * L < 0x7fffffff && (int64_t)B * nbins < 0x3fffffff &&
+                      ((B == 1 && L >= 16384) || !csr_fits_lds(L, nbins));
+    if (flat) {
+        const int64_t slots = (int64_t)B * L, bins = (int64_t)B * nbins;
+        if (int rc = invert_table(idx, slots, bins, w.scratch, w.start, w.scratch + bins, w.order, s, L, nbins)) return rc;
+        hipLaunchKernelGGL(slots_to_rows_kernel, dim3((unsigned)((slots + 255) / 256)), dim3(256), 0, s, w.order, weight, div,
+                           (int)slots, w.start, (int)bins, w.wsorted);
     } else if (int rc = csr_transpose(idx, B, L, nbins, div, weight, w.start, w.order, w.wsorted, w.scratch, s)) {
         return rc;
     }
     dim3 grid((nbins + RW_BLOCK / 64 - 1) / (RW_BLOCK / 64), B);
     hipLaunchKernelGGL(rows_gather_sum_kernel, grid, dim3(RW_BLOCK), 0, s, grad_rows, w.start, w.order, w.wsorted,
-                       nbins, L, L / div, ld, col0, C, grad_x_cl);
+                       nbins, L, L / div, ld, col0, C, grad_x_cl, flat ? 1 : 0);
     return check_launch();
 }
 

@@ -71,9 +71,13 @@ int csr_transpose(const int64_t *idx, int B, int L, int nbins, int div, const fl
 int gather_sum(const float *rows, const int *start, const int *order, const float *wsorted, int B, int C, int nbins,
                int Lrow, int Lslots, float *out, hipStream_t s);
 
-// kpconv.hip: multi-workgroup inverse of an index table (cnt, cursor: M ints; start: M + 1; order: slots)
+// kpconv.hip: multi-workgroup inverse of an index table (cnt, cursor: M ints; start: M + 1; order: slots).
+// per_cloud_slots > 0: idx is (clouds, per_cloud_slots) with values clamped to [0, per_cloud_bins); bin = cloud *
+// per_cloud_bins + value, M = clouds * per_cloud_bins (one flat table over the batch).
 int invert_table(const int64_t *idx, int64_t slots, int64_t M, int *cnt, int *start, int *cursor, int *order,
-                 hipStream_t s);
+                 hipStream_t s, int64_t per_cloud_slots = 0, int64_t per_cloud_bins = 0);
+// csr.hip: does the one-workgroup-per-cloud transpose fit LDS?
+bool csr_fits_lds(int L, int nbins);
 
 // grid.hip: uniform-grid radius search (build + query); seg/batch_y null => dense layout (more in grid.h)
 int grid_ball_query(const float *x, const float *y, const int64_t *seg, const int64_t *batch_y, int num_clouds,
@@ -86,6 +90,48 @@ __device__ __forceinline__ int lane_id() { return threadIdx.x & (kWave - 1); }
 __device__ __forceinline__ int lanes_below(unsigned long long mask)
 {
     return __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
+}
+
+
+// Bitonic sort of one bin (n <= 64 * NU slot ids) by one wave: element i lives in lane i & 63, register i >> 6.
+template <int NU, typename OrdT>
+__device__ __forceinline__ void wave_sort_bin(OrdT *__restrict__ bin, int n, int lane)
+{
+    int e[NU];
+#pragma unroll
+    for (int u = 0; u < NU; ++u) e[u] = (lane + 64 * u < n) ? (int)bin[lane + 64 * u] : 0x7fffffff;
+#pragma unroll
+    for (int size = 2; size <= 64 * NU; size <<= 1) {
+#pragma unroll
+        for (int stride = size >> 1; stride >= 1; stride >>= 1) {
+            if (stride >= 64) {  // partner in the same lane, another register
+#pragma unroll
+                for (int u = 0; u < NU; ++u) {
+                    const int pu = u ^ (stride >> 6);
+                    if (pu > u) {
+                        const bool up = (((u << 6) | lane) & size) == 0;
+                        const int a = e[u], b = e[pu];
+                        const bool swap = up ? a > b : a < b;
+                        e[u] = swap ? b : a;
+                        e[pu] = swap ? a : b;
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int u = 0; u < NU; ++u) {
+                    const int other = __shfl_xor(e[u], stride);
+                    const bool up = (((u << 6) | lane) & size) == 0;
+                    const bool lower = (lane & stride) == 0;
+                    e[u] = (lower == up) ? min(e[u], other) : max(e[u], other);
+                }
+            }
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();  // (the loads above all happened before the first exchange)
+#pragma unroll
+    for (int u = 0; u < NU; ++u)
+        if (lane + 64 * u < n) bin[lane + 64 * u] = (OrdT)e[u];
 }
 
 }  // namespace tp3d
