@@ -509,8 +509,9 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline(args.cpu_sample_clouds, args.cpu_sample_iters)
         value = world * B_PER_GPU * args.steps / dt
+        grouping = "MSG" if MODEL_CONFIG.endswith("_ms") else "SSG"
         line = {
-            "metric": "point-clouds/sec fwd+bwd PointNet++SSG B=32 N=16384",
+            "metric": "point-clouds/sec fwd+bwd PointNet++%s B=32 N=16384" % grouping,
             "value": round(value, 2),
             "unit": "point-clouds/s",
             "n_gpus": world,
@@ -522,8 +523,9 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": "PointNet++ SSG (%s) train step fwd+bwd+Adam, B=32 per GPU, N=16384, "
-                                   "FEAT=3, 10 classes, pos~U[-1,1]^3 (BASELINE configs[1])" % MODEL_CONFIG,
+            "config": {"workload": "PointNet++ %s (%s) train step fwd+bwd+Adam, B=32 per GPU, N=16384, "
+                                   "FEAT=3, 10 classes, pos~U[-1,1]^3 (BASELINE configs[%d])"
+                                   % (grouping, MODEL_CONFIG, 2 if grouping == "MSG" else 1),
                        "launch": "hip-graph replay" if graphed else "eager",
                        "global_batch": world * B_PER_GPU, "points": N_POINTS,
                        "parallelism": "dp%d (whole clouds per rank, one flat gradient all-reduce over RCCL "
