@@ -448,8 +448,59 @@ def make_unet4_config_case():
     print("wrote %s" % path)
 
 
+def make_rsconv_case():
+    """Relation-Shape convolution, dense format (modules/RSConv/dense.py:18-190, 398-476): the reference's own
+    RSConvSharedMSGDown / RSConvMSGDown over the oracle kernels, two stacked levels (first-layer mapper with the
+    feature-raising branch, then a plain mapper), distinct clouds, train-mode BatchNorm, one backward."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("_ref_rsconv_dense",
+                                                  os.path.join(REF, "torch_points3d/modules/RSConv/dense.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+
+    g = torch.Generator().manual_seed(4321)
+    pos = torch.rand(2, 500, 3, generator=g) * 2 - 1
+    feats = torch.randn(2, 500, 4, generator=g)
+    torch.manual_seed(21)
+    # level 0: shared mapper over two scales; features = [centred xyz (3) | x (4)] raised 7 -> 16
+    l0 = mod.RSConvSharedMSGDown(npoint=128, radii=[0.3, 0.45], nsample=[12, 20],
+                                 down_conv_nn=[[10, 8, 16], [4 + 3, 16]], channel_raising_nn=[16, 24])
+    # level 1: one mapper per scale; features = [centred xyz (3) | 48 channels]
+    l1 = mod.RSConvMSGDown(npoint=32, radii=[0.6, 0.9], nsample=[16, 24], down_conv_nn=[10, 16, 48 + 3],
+                           channel_raising_nn=[48 + 3, 40])
+    l0.train()
+    l1.train()
+    rec = {"pos": pos, "x": feats}
+    for name, m in (("l0", l0), ("l1", l1)):
+        for k, v in m.state_dict().items():
+            rec["state/%s/%s" % (name, k)] = v.detach().clone()
+    x_in = feats.clone().requires_grad_(True)
+    d0 = l0(_Bag(pos=pos, x=x_in.transpose(1, 2).contiguous()))
+    d1 = l1(d0)
+    rec["l0_x"], rec["l0_pos"], rec["l1_x"], rec["l1_pos"] = d0.x, d0.pos, d1.x, d1.pos
+    cot = torch.randn(d1.x.shape, generator=torch.Generator().manual_seed(22))
+    (d1.x * cot).sum().backward()
+    rec["cotangent"] = cot
+    rec["grad_x_in"] = x_in.grad
+    rec["grad_l0_msg_conv"] = l0._mapper.nn["mlp_msg"][0][0].weight.grad
+    rec["grad_l1_raise_conv"] = l1.mlp_out[0].weight.grad
+    # what the modules obtained at the kernel boundary
+    fps0 = tpk_ref.furthest_point_sample(pos, 128)
+    rec["fps0"] = fps0
+    for s, (r, ns) in enumerate(zip([0.3, 0.45], [12, 20])):
+        rec["ball0_%d_idx" % s] = tpk_ref.ball_query(r, ns, pos, d0.pos)[0]
+    rec["fps1"] = tpk_ref.furthest_point_sample(d0.pos, 32)
+    for s, (r, ns) in enumerate(zip([0.6, 0.9], [16, 24])):
+        rec["ball1_%d_idx" % s] = tpk_ref.ball_query(r, ns, d0.pos, d1.pos)[0]
+    path = os.path.join(HERE, "rsconv_dense.npz")
+    np.savez_compressed(path, **to_np(rec))
+    print("wrote %s (%.1f KiB)" % (path, os.path.getsize(path) / 1024.0))
+
+
 def main():
     install_stubs()
+    if sys.argv[1:] == ["rsconv"]:  # only this fixture (the others are unchanged)
+        return make_rsconv_case()
     make_kpconv_case()
     from torch_points3d_amd.pointnet2 import unet_config
 
@@ -489,6 +540,8 @@ def main():
                innermost=[24 + 20 + 3, 32, 48], up_conv_nn=[[48 + 44, 32, 32], [32 + 28, 24, 24], [24 + 3, 16, 16]],
                normalize_xyz=[False, False], save_sampling_id=[False, False])
     make_case("small_msg", msg, 3, 5, pos, feats, seed=11, store_weights=True)
+
+    make_rsconv_case()
 
     # (4) KPConv blocks + FPModule_PD through the reference's own classes (last: it replaces further modules by stubs)
     make_kpconv_blocks_case()

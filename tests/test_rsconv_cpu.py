@@ -1,0 +1,46 @@
+"""Relation-Shape convolution mirror (torch_points3d_amd.rsconv) driven by the CPU oracle must reproduce what the
+REFERENCE's RSConvSharedMSGDown / RSConvMSGDown produced (tests/golden/rsconv_dense.npz, make_golden.py rsconv).
+Pins the [absolute xyz, centred xyz, features] channel order, the shared-mapper state_dict layout and train-mode BN."""
+import torch
+
+from conftest import load_golden
+from torch_points3d_amd.dense import Data
+from torch_points3d_amd.rsconv import RSConvMSGDown, RSConvSharedMSGDown
+
+
+def build_levels(g, kernels, device="cpu"):
+    torch.manual_seed(0)
+    l0 = RSConvSharedMSGDown(npoint=128, radii=[0.3, 0.45], nsample=[12, 20],
+                             down_conv_nn=[[10, 8, 16], [4 + 3, 16]], channel_raising_nn=[16, 24], kernels=kernels)
+    l1 = RSConvMSGDown(npoint=32, radii=[0.6, 0.9], nsample=[16, 24], down_conv_nn=[10, 16, 48 + 3],
+                       channel_raising_nn=[48 + 3, 40], kernels=kernels)
+    for name, m in (("l0", l0), ("l1", l1)):
+        pre = "state/%s/" % name
+        stored = {k[len(pre):]: v for k, v in g.items() if k.startswith(pre)}
+        assert set(stored) == set(m.state_dict()), "state_dict keys differ from the reference module's"
+        m.load_state_dict(stored, strict=True)
+    return l0.to(device).train(), l1.to(device).train()
+
+
+def test_rsconv_mirror_reproduces_reference_modules(oracle):
+    g = load_golden("rsconv_dense")
+    l0, l1 = build_levels(g, oracle)
+    x_in = g["x"].clone().requires_grad_(True)
+    d0 = l0(Data(pos=g["pos"], x=x_in.transpose(1, 2).contiguous()))
+    d1 = l1(d0)
+    # same PyTorch CPU ops in the same order as the reference modules
+    for got, key in ((d0.x, "l0_x"), (d0.pos, "l0_pos"), (d1.x, "l1_x"), (d1.pos, "l1_pos")):
+        torch.testing.assert_close(got.detach(), g[key], rtol=1e-4, atol=1e-5, msg=lambda m, k=key: k + ": " + m)
+    (d1.x * g["cotangent"]).sum().backward()
+    torch.testing.assert_close(x_in.grad, g["grad_x_in"], rtol=1e-4, atol=1e-6)
+    torch.testing.assert_close(l0._mapper.nn["mlp_msg"][0][0].weight.grad, g["grad_l0_msg_conv"], rtol=1e-4, atol=1e-6)
+    torch.testing.assert_close(l1.mlp_out[0].weight.grad, g["grad_l1_raise_conv"], rtol=1e-4, atol=1e-6)
+
+
+def test_shared_mapper_is_one_module():
+    l0 = RSConvSharedMSGDown(npoint=8, radii=[0.3, 0.45], nsample=[4, 4], down_conv_nn=[[10, 8, 16], [7, 16]],
+                             channel_raising_nn=[16, 24], kernels=object())
+    assert l0.mlps[0]._mapper is l0.mlps[1]._mapper is l0._mapper
+    l1 = RSConvMSGDown(npoint=8, radii=[0.3, 0.45], nsample=[4, 4], down_conv_nn=[10, 16, 51],
+                       channel_raising_nn=[51, 40], kernels=object())
+    assert l1.mlps[0]._mapper is not l1.mlps[1]._mapper and l1._mapper is l1.mlps[1]._mapper

@@ -8,6 +8,7 @@
 //
 // Reference semantics: the weight gradient of Conv2d 1x1 (bias=False) inside MLP2D
 // (torch_points3d/core/common_modules/dense_modules.py:5-12,25-29) -- computed by autograd in the reference.
+#include <cstdlib>
 #include <type_traits>
 
 #include "tp3d_common.h"
@@ -27,7 +28,9 @@ __global__ __launch_bounds__(TN_BLOCK) void gemm_tn_partial_kernel(const float *
                                                                     float *__restrict__ partial /*[S][N][K]*/)
 {
     constexpr int TN = 2 * WM * 32, TK = 2 * WN * 32;
-    constexpr int TN_BR = 64 / (WM * WN);  // ~16-32 KiB staged per step whatever the tile shape
+    // ~16-32 KiB staged per step whatever the tile shape (three-tile-wide shapes: 16 rows, so that every thread
+    // owns whole float4 slots of both operands)
+    constexpr int TN_BR = (WM * WN) % 3 == 0 ? 16 : 64 / (WM * WN);
     constexpr int LDN = TN + 4, LDK = TK + 4;  // +4 floats: keeps float4 stores aligned, spreads rows over banks
     __shared__ __attribute__((aligned(16))) float sY[TN_BR * LDN];
     __shared__ __attribute__((aligned(16))) float sA[TN_BR * LDK];
@@ -71,7 +74,8 @@ __global__ __launch_bounds__(TN_BLOCK) void gemm_tn_partial_kernel(const float *
 
     // ---- software pipeline: the loads of step i+1 are in flight while step i runs on the MFMA pipe
     constexpr int PY = TN_BR * (TN / 4) / TN_BLOCK, PA = TN_BR * (TK / 4) / TN_BLOCK;  // float4 slots per thread
-    static_assert(PY >= 1 && PA >= 1, "tile too small for the thread count");
+    static_assert(PY >= 1 && PA >= 1 && PY * TN_BLOCK == TN_BR * (TN / 4) && PA * TN_BLOCK == TN_BR * (TK / 4),
+                  "staged tile must be a whole number of float4 slots per thread");
     float4 ry[PY], ra[PA];
     auto fetch = [&](int64_t r0) {
 #pragma unroll
@@ -159,7 +163,12 @@ static TnPlan plan_tn(int64_t M, int N, int K)
 {
     TnPlan p;
     p.wm = N > 64 ? 2 : 1;
-    p.wn = K > 64 ? 2 : 1;
+    // K just above a multiple of 128 (131 = 128 features + xyz): 192-wide tiles halve the padded columns and read dY
+    // once instead of twice; wider K: 192 only where it strictly removes padded columns
+    if (K <= 64) p.wn = 1;
+    else if (K <= 128) p.wn = 2;
+    else if (K <= 192) p.wn = 3;
+    else p.wn = ((K + 191) / 192) * 192 < ((K + 127) / 128) * 128 ? 3 : 2;
     p.tn = 64 * p.wm;
     p.tk = 64 * p.wn;
     p.tiles_n = (N + p.tn - 1) / p.tn;
@@ -168,7 +177,12 @@ static TnPlan plan_tn(int64_t M, int N, int K)
     // ~4 workgroups per CU (256 CUs) keep the MFMA pipes fed; at least 256 rows per split, at most 512 splits
     // (every split writes an N x K partial tile that the reduction pass reads back)
     int64_t want = (1024 + tiles - 1) / tiles;
-    int64_t max_by_rows = (M + 255) / 256;
+    static const int min_rows = [] {  // tuning switch (rows per split floor)
+        const char *e = getenv("TP3D_TN_MIN_ROWS");
+        const int v = e ? atoi(e) : 0;
+        return v >= 64 ? v : 256;
+    }();
+    int64_t max_by_rows = (M + min_rows - 1) / min_rows;
     int64_t s = want < max_by_rows ? want : max_by_rows;
     if (s < 1) s = 1;
     if (s > 512) s = 512;
@@ -209,7 +223,9 @@ TP3D_EXPORT int tp3d_gemm_tn_f32(const float *dY, const float *A, int64_t M, int
         else if (va) TP3D_TN_LAUNCH(WM_, WN_, false, true);                                                         \
         else TP3D_TN_LAUNCH(WM_, WN_, false, false);                                                                \
     } while (0)
-    if (p.wm == 2 && p.wn == 2) TP3D_TN_ALIGN(2, 2);
+    if (p.wm == 2 && p.wn == 3) TP3D_TN_ALIGN(2, 3);
+    else if (p.wn == 3) TP3D_TN_ALIGN(1, 3);
+    else if (p.wm == 2 && p.wn == 2) TP3D_TN_ALIGN(2, 2);
     else if (p.wm == 2) TP3D_TN_ALIGN(2, 1);
     else if (p.wn == 2) TP3D_TN_ALIGN(1, 2);
     else TP3D_TN_ALIGN(1, 1);
