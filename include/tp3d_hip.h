@@ -35,7 +35,7 @@ extern "C" {
 #define TP3D_E_UNSORTED (-3) /* reserved: batch vector not sorted (checked by the host wrapper) */
 #define TP3D_E_TOOBIG (-4)   /* size exceeds what the kernel's index arithmetic supports */
 
-#define TP3D_ABI_VERSION 15
+#define TP3D_ABI_VERSION 16
 
 int tp3d_abi_version(void);
 const char *tp3d_strerror(int code);
@@ -271,6 +271,30 @@ int tp3d_knn_dense_f32(const float *x, const float *y, int B, int N, int np, int
  *   (tp3d_rows_scatter_bwd_f32 with B = 1). */
 int tp3d_knn_interpolate_fwd_f32(const float *x, const int64_t *idx, const float *dist2, const float *skip, int64_t Nq,
                                  int k, int C, int C2, int ld, float *out, float *wnorm, void *stream);
+
+/* RandLA-Net local feature aggregation over a fixed-k neighbour table (modules/RandLANet/modules.py:9-54; the reference
+ * runs it as a torch_geometric MessagePassing over the edge list of torch_cluster's knn).  Edge e = q*k + n.
+ *
+ * relative position encoding (modules.py:36-41): out (Nq*k, 12) rows
+ *   [q_pos[q] (3), s_pos[j] (3), q_pos[q] - s_pos[j] (3), |q_pos[q] - s_pos[j]| (1), 0, 0],  j = nbr[e];
+ *   a missing neighbour (j < 0 or j >= M) gives a zero row. */
+int tp3d_randla_relpos_f32(const float *q_pos, const float *s_pos, const int64_t *nbr, int64_t Nq, int k, int64_t M,
+                           float *out, void *stream);
+
+/* attentive pooling (modules.py:46-52 with aggr="add"):  out[q, c] = sum_n softmax_c(g[e, :])[c] * f[e, c]
+ *   g (Nq*k, ldg) attention scores, f (Nq*k, ldf) edge features (C <= ldg, ldf; C, ldf <= 256), out (Nq, C).
+ *   nbr (Nq*k) or NULL: edges with nbr[e] < 0 are left out of the sum.
+ * backward: dg (Nq*k, ldg) columns [0, C) and df (Nq*k, ldf) all columns (padding zeroed) are overwritten:
+ *   df = s * dout[q];  dg = s * (f * dout[q] - sum_c s * f * dout[q]),  s = softmax_c(g[e, :]). */
+int tp3d_attn_pool_fwd_f32(const float *g, const float *f, const int64_t *nbr, int64_t Nq, int k, int C, int ldg, int ldf,
+                           float *out, void *stream);
+int tp3d_attn_pool_bwd_f32(const float *g, const float *f, const float *dout, const int64_t *nbr, int64_t Nq, int k, int C,
+                           int ldg, int ldf, float *dg, float *df, void *stream);
+
+/* Skinny row GEMM of the edge-wise MLPs (modules/RandLANet/modules.py:20-22; nn.Linear inside MLP,
+ * core/common_modules/base_modules.py:29-43):  Y (M, N) = A (M, K; row stride lda >= K) * W (N, K)^T,  N, K <= 32.
+ * One row per lane, k ascending per output.  Y is dense (row stride N). */
+int tp3d_gemm_skinny_f32(const float *A, const float *W, int64_t M, int N, int K, int lda, float *Y, void *stream);
 
 /* Strided shortcut of the KPConv ResnetBBlock (modules/KPConv/blocks.py:206-210):
  *   out[q, c] = max over n of x[neighbors[q,n], c], a shadow neighbour (-1 or >= M) contributing 0.0

@@ -79,6 +79,26 @@ def gemm_tn(dY, A):
     return out
 
 
+SKINNY_MAX = 32       # tp3d_gemm_skinny_f32: both channel counts at most this
+SKINNY_MIN_ROWS = 32768
+
+
+def gemm_skinny(A, W):
+    """A (M,K) @ W (N,K)^T -> (M,N) for K, N <= 32 and many rows: one row per lane (csrc/gemm_skinny.hip)."""
+    dev = A.device
+    A, W = A.contiguous(), W.contiguous()
+    M, K = A.shape
+    N = W.shape[0]
+    Y = torch.empty((M, N), dtype=torch.float32, device=dev)
+    with _lib.on_device(dev):
+        _lib.call("tp3d_gemm_skinny_f32", _lib.ptr(A), _lib.ptr(W), M, N, K, K, _lib.ptr(Y), _lib.stream_ptr(dev))
+    return Y
+
+
+def _is_skinny(M, a, b):
+    return M >= SKINNY_MIN_ROWS and a <= SKINNY_MAX and b <= SKINNY_MAX
+
+
 def gemm_rows(A, Bt, want_stats=False):
     """A (M,K) @ Bt (N,K)^T -> (M,N) with the fp32 MFMA rows kernel (csrc/gemm_rows.hip); optionally also the
     per-128-row-block column sums / sums of squares for BatchNorm.  K must be a multiple of 4."""
@@ -145,6 +165,9 @@ class _LinearBNAct(torch.autograd.Function):
         if own_gemm:
             # the dense contraction on the fp32 MFMA rows kernel; BatchNorm statistics come out of its epilogue
             Y, part = gemm_rows(A, W2, want_stats=training)
+        elif _is_skinny(M, Kp, Cout):
+            Y = gemm_skinny(A, W2)  # edge-wise MLPs of a few channels: a pure stream, one row per lane
+            part = None
         else:
             Y = torch.mm(A, W2.t())  # plain library GEMM (unaligned channel counts, e.g. the 10-class head)
             part = None
@@ -194,7 +217,9 @@ class _LinearBNAct(torch.autograd.Function):
         dW = gemm_tn(dY, A)[:, :Cin].reshape(wshape) if ctx.needs_input_grad[1] else None
         # input gradient: nothing to fuse into its epilogue, and the library GEMM is 10-25 % faster than the rows
         # kernel on these shapes (same measurement), so it stays a plain library GEMM
-        dA = torch.mm(dY, W2) if ctx.needs_input_grad[0] else None
+        dA = None
+        if ctx.needs_input_grad[0]:
+            dA = gemm_skinny(dY, W2.t()) if _is_skinny(M, W2.shape[1], Cout) else torch.mm(dY, W2)
         dbias = None
         if has_bias and ctx.needs_input_grad[7]:
             # batch statistics remove the bias from the output (gradient exactly zero); running statistics do not

@@ -17,10 +17,62 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import _lib
 from . import fused as _fused
 from . import torchpoints as _tp
 from .kpconv_blocks import PDData
-from .partial_dense import MLP
+from .partial_dense import MLP, _KnnInterpolate
+
+
+def relative_position_rows(pos_q, pos_s, nbr):
+    """(Nq*k, 12) rows [pos_i, pos_j, pos_i - pos_j, |pos_i - pos_j|, 0, 0] of the edges of a fixed-k table
+    (modules.py:36-41); positions carry no gradient."""
+    Nq, k = nbr.shape
+    dev = pos_q.device
+    pq, ps = _tp._f32(pos_q), _tp._f32(pos_s)
+    nb = _tp._i64(nbr)
+    out = torch.empty((Nq * k, 12), dtype=torch.float32, device=dev)
+    with _lib.on_device(dev):
+        _lib.call("tp3d_randla_relpos_f32", _lib.ptr(pq), _lib.ptr(ps), _lib.ptr(nb), Nq, k, ps.shape[0], _lib.ptr(out),
+                  _lib.stream_ptr(dev))
+    return out
+
+
+class _AttentivePool(torch.autograd.Function):
+    """out (Nq, C) = sum over the k edges of a query of softmax_c(g[e]) * f[e, :C]   (modules.py:46-52, aggr="add")."""
+
+    @staticmethod
+    def forward(ctx, g, f, nbr, C):
+        g, f = g.contiguous(), f.contiguous()
+        Nq, k = nbr.shape
+        dev = g.device
+        if g.shape[0] != Nq * k or f.shape[0] != Nq * k or g.shape[1] < C or f.shape[1] < C:
+            raise ValueError("attentive_pool: g %s / f %s do not match a (%d, %d) neighbour table with %d channels"
+                             % (tuple(g.shape), tuple(f.shape), Nq, k, C))
+        out = torch.empty((Nq, C), dtype=torch.float32, device=dev)
+        with _lib.on_device(dev):
+            _lib.call("tp3d_attn_pool_fwd_f32", _lib.ptr(g), _lib.ptr(f), _lib.ptr(nbr), Nq, k, C, g.shape[1],
+                      f.shape[1], _lib.ptr(out), _lib.stream_ptr(dev))
+        ctx.save_for_backward(g, f, nbr)
+        ctx.C = C
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        g, f, nbr = ctx.saved_tensors
+        Nq, k = nbr.shape
+        dev = g.device
+        dout = dout.float().contiguous()
+        dg = torch.empty_like(g) if g.shape[1] == ctx.C else torch.zeros_like(g)
+        df = torch.empty_like(f)
+        with _lib.on_device(dev):
+            _lib.call("tp3d_attn_pool_bwd_f32", _lib.ptr(g), _lib.ptr(f), _lib.ptr(dout), _lib.ptr(nbr), Nq, k, ctx.C,
+                      g.shape[1], f.shape[1], _lib.ptr(dg), _lib.ptr(df), _lib.stream_ptr(dev))
+        return dg, df, None, None
+
+
+def attentive_pool(g, f, nbr, C):
+    return _AttentivePool.apply(g, f, nbr, C)
 
 
 class RandomSampler(object):
@@ -56,11 +108,14 @@ class RandlaKernel(nn.Module):
         self.point_pos_nn = MLP(point_pos_nn)
         self.attention_nn = MLP(attention_nn)
         self.global_nn = MLP(global_nn)
+        self.fused = kwargs.get("fused", True)
 
     def forward(self, x, pos, nbr):
         """x (M,C) or None, pos = (query positions (Nq,3), support positions (M,3)), nbr (Nq,k) rows of the support"""
         pos_q, pos_s = pos
         Nq, k = nbr.shape
+        if pos_s.is_cuda and self.fused:
+            return self._forward_fused(x, pos_q, pos_s, nbr)
         j = nbr.reshape(-1)
         pos_i = pos_q.repeat_interleave(k, dim=0)
         pos_j = pos_s[j]
@@ -73,6 +128,21 @@ class RandlaKernel(nn.Module):
         msg = s_ij * fij_hat
         return _fused.rows_mlp(self.global_nn, msg.reshape(Nq, k, -1).sum(dim=1))
 
+    def _forward_fused(self, x, pos_q, pos_s, nbr):
+        """Same arithmetic; the edge-wise pieces between the MLPs are HIP row kernels (csrc/randla.hip) and the
+        neighbour-feature gather + concatenation is the k = 1 case of the interpolation kernel (weight exactly 1),
+        whose backward is the atomic-free inverse-index gather."""
+        Nq, k = nbr.shape
+        nbr = _tp._i64(nbr)
+        rij = _fused.rows_mlp(self.point_pos_nn, relative_position_rows(pos_q, pos_s, nbr))
+        xs = _tp._f32(pos_s) if x is None else x
+        C = xs.shape[1] + rij.shape[1]
+        edges = nbr.reshape(-1, 1)
+        ones = torch.ones((edges.shape[0], 1), dtype=torch.float32, device=nbr.device)
+        fij_hat = _KnnInterpolate.apply(xs, rij, edges, ones, (C + 3) // 4 * 4)  # (Nq*k, pad4(C)) = [x_j | rij | 0]
+        g_fij = _fused.rows_mlp(self.attention_nn, fij_hat)
+        return _fused.rows_mlp(self.global_nn, attentive_pool(g_fij, fij_hat, nbr, C))
+
 
 class RandlaConv(nn.Module):
     def __init__(self, ratio=None, k=None, *args, **kwargs):
@@ -84,7 +154,7 @@ class RandlaConv(nn.Module):
             kwargs["attention_nn"][0] = kwargs["attention_nn"][-1] = kwargs.get("nb_feature") * 2
             kwargs["down_conv_nn"][0] = kwargs.get("nb_feature") * 2
         self._conv = RandlaKernel(point_pos_nn=kwargs["point_pos_nn"], attention_nn=kwargs["attention_nn"],
-                                  global_nn=kwargs["down_conv_nn"])
+                                  global_nn=kwargs["down_conv_nn"], fused=kwargs.get("fused", True))
 
     def forward(self, data, **kwargs):
         x, pos, batch = data.x, data.pos, data.batch
