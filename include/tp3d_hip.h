@@ -35,7 +35,7 @@ extern "C" {
 #define TP3D_E_UNSORTED (-3) /* reserved: batch vector not sorted (checked by the host wrapper) */
 #define TP3D_E_TOOBIG (-4)   /* size exceeds what the kernel's index arithmetic supports */
 
-#define TP3D_ABI_VERSION 16
+#define TP3D_ABI_VERSION 17
 
 int tp3d_abi_version(void);
 const char *tp3d_strerror(int code);
@@ -170,11 +170,13 @@ int tp3d_interp_concat_fwd_f32(const float *feat_cl, const int64_t *idx, const f
                                int B, int m, int n, int C1, int C2, int ld, float *out, void *stream);
 
 /* Tall-skinny GEMM of a shared-MLP layer, fp32 MFMA:  C[M,N] = A[M,K] * Bt[N,K]^T  (row-major, K % 4 == 0).
- * Forward: A = rows, Bt = W exactly as nn.Conv2d stores it (Cout x Cin).  With stat_partial != NULL the epilogue also writes,
- * per block of 128 rows, the column sums and sums of squares of C: stat_partial[block][2][N]
- * (tp3d_gemm_rows_stat_floats(M, N) floats), which tp3d_bn_finalize_f32 turns into the BatchNorm statistics --
+ * Forward: A = rows, Bt = W exactly as nn.Conv2d stores it (Cout x Cin).  With stat_partial != NULL the epilogue also writes
+ * partial column sums and sums of squares of C: stat_partial[chunk][2][N], chunk < tp3d_gemm_rows_stat_chunks(M, N)
+ * (one row per 128-row block, or one per persistent workgroup when the launch fills the grid; the buffer holds
+ * tp3d_gemm_rows_stat_floats(M, N) floats), which tp3d_bn_finalize_f32 turns into the BatchNorm statistics --
  * the separate statistics pass over C (tp3d_bn_stats_f32) is then not needed. */
 size_t tp3d_gemm_rows_stat_floats(int64_t M, int N);
+int tp3d_gemm_rows_stat_chunks(int64_t M, int N);
 int tp3d_gemm_rows_f32(const float *A, const float *Bt, int64_t M, int N, int K, float *C, float *stat_partial,
                        void *stream);
 int tp3d_bn_finalize_f32(const float *partial, int chunks, int64_t M, int C, float eps, float momentum,

@@ -213,7 +213,8 @@ def test_sharded_step_same_trajectory():
 
 
 @pytest.mark.parametrize("M,N,K", [(1000, 64, 8), (4096, 128, 132), (70000, 128, 128), (33, 8, 4), (20000, 256, 260),
-                                   (5000, 1024, 512), (262144, 128, 64), (129, 132, 68), (4096, 256, 1280)])
+                                   (5000, 1024, 512), (262144, 128, 64), (129, 132, 68), (4096, 256, 1280),
+                                   (140000, 256, 64), (50000, 384, 32)])
 def test_gemm_rows_matches_fp64_and_stats(M, N, K):
     """fp32 MFMA rows GEMM (forward / input-gradient contraction) + fused BatchNorm statistics epilogue"""
     from torch_points3d_amd import fused
@@ -225,12 +226,13 @@ def test_gemm_rows_matches_fp64_and_stats(M, N, K):
     err = float((C.double() - ref).abs().max())
     lib = float((torch.mm(A, Bm).double() - ref).abs().max())
     assert err <= max(2.0 * lib, 1e-5 * float(ref.abs().max())), (err, lib)
-    chunks = (M + 127) // 128
+    from torch_points3d_amd import _lib
+    chunks = _lib.load().tp3d_gemm_rows_stat_chunks(M, N)  # one row per 128-row block, or per persistent workgroup
+    assert chunks == (M + 127) // 128 or chunks == 1024 // ((N + 127) // 128)
     p = part[: chunks * 2 * N * 4].view(torch.float32).view(chunks, 2, N)
     torch.testing.assert_close(p[:, 0].double().sum(0), ref.sum(0), rtol=1e-4, atol=1e-3 * float(ref.abs().max()))
     torch.testing.assert_close(p[:, 1].double().sum(0), (ref * ref).sum(0), rtol=1e-4, atol=1e-2)
     # the statistics rows end exactly at chunks*2*N floats: a guard band behind them must stay untouched
-    from torch_points3d_amd import _lib
     guard = torch.full((chunks * 2 * N + 8 * 2 * N,), 7.0, device=DEV)
     C2 = torch.empty_like(C)
     _lib.call("tp3d_gemm_rows_f32", A.data_ptr(), Bm.t().contiguous().data_ptr(), M, N, K, C2.data_ptr(), guard.data_ptr(),

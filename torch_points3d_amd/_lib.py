@@ -55,8 +55,8 @@ SIGNATURES = {
 }
 MISC = ("tp3d_abi_version", "tp3d_strerror", "tp3d_last_hip_error", "tp3d_scatter_workspace_bytes",
         "tp3d_bn_workspace_floats", "tp3d_gemm_tn_workspace_floats", "tp3d_ball_query_workspace_bytes",
-        "tp3d_gemm_rows_stat_floats", "tp3d_kpconv_bwd_workspace_bytes", "tp3d_voxel_workspace_bytes", "tp3d_knn_workspace_bytes", "tp3d_kpconv_grad_workspace_bytes")
-ABI_VERSION = 16
+        "tp3d_gemm_rows_stat_floats", "tp3d_gemm_rows_stat_chunks", "tp3d_kpconv_bwd_workspace_bytes", "tp3d_voxel_workspace_bytes", "tp3d_knn_workspace_bytes", "tp3d_kpconv_grad_workspace_bytes")
+ABI_VERSION = 17
 
 _handle = None
 
@@ -98,6 +98,8 @@ def load():
     h.tp3d_kpconv_bwd_workspace_bytes.argtypes = [_l, _l]
     h.tp3d_gemm_rows_stat_floats.restype = ctypes.c_size_t
     h.tp3d_gemm_rows_stat_floats.argtypes = [_l, _i]
+    h.tp3d_gemm_rows_stat_chunks.restype = ctypes.c_int
+    h.tp3d_gemm_rows_stat_chunks.argtypes = [_l, _i]
     h.tp3d_kpconv_grad_workspace_bytes.restype = ctypes.c_size_t
     h.tp3d_kpconv_grad_workspace_bytes.argtypes = [_l, _l, _i]
     h.tp3d_knn_workspace_bytes.restype = ctypes.c_size_t

@@ -1,6 +1,8 @@
 // Tall-skinny fp32 GEMM of the shared MLPs with the BatchNorm statistics fused into its epilogue:
 //     C[M,N] = A[M,K] * Bt[N,K]^T       M = B*npoint*nsample rows (up to ~1e6), N, K <= ~1300, K contiguous in both
-//     stats (optional): per 128-row block, per column: sum and sum of squares of C  -> tp3d_bn_finalize_f32
+//     stats (optional): per column, sum and sum of squares of C in `chunks` partial rows -> tp3d_bn_finalize_f32
+//     (one row per 128-row block; launches that fill the persistent grid keep one running row per workgroup instead:
+//     1024 / tiles_n rows whatever M is, so the finalize pass stays small)
 // Forward pass:  Y = rows @ W^T   (Bt = W as stored: Cout x Cin)  + column statistics of Y (saves a full read of Y)
 // Reference semantics: Conv2d 1x1 (bias=False) followed by BatchNorm2d in training mode
 // (torch_points3d/core/common_modules/dense_modules.py:5-12,25-29).
@@ -21,7 +23,9 @@ constexpr int GR_BLOCK_T = 256;
 constexpr int GR_BM = 128, GR_BN = 128, GR_BK = 32;
 constexpr int GR_LD = GR_BK + 4;  // 36-float pitch
 
-template <bool STATS>
+// STATS: 0 none, 1 one statistics row per 128-row block, 2 one row per workgroup (needs gridDim.x % (8*tiles_n) == 0:
+// every item of a workgroup then lies in the same column tile)
+template <int STATS>
 __global__ __launch_bounds__(GR_BLOCK_T) void gemm_rows_kernel(const float *__restrict__ A, const float *__restrict__ Bt,
                                                                 int64_t M, int N, int K, int tiles_n, int64_t items,
                                                                 float *__restrict__ C, float *__restrict__ partial)
@@ -70,6 +74,8 @@ __global__ __launch_bounds__(GR_BLOCK_T) void gemm_rows_kernel(const float *__re
     decode(item, m0, n0, rb);
     fetch(m0, n0, 0);
 
+    const int n0_first = n0;
+    float run1[2] = {0.0f, 0.0f}, run2[2] = {0.0f, 0.0f};  // STATS == 2: this thread's share over all its items
     f32x16 acc[2][2];
     while (item < items) {
 #pragma unroll
@@ -128,7 +134,24 @@ __global__ __launch_bounds__(GR_BLOCK_T) void gemm_rows_kernel(const float *__re
                     if (m < M && n < N) C[m * N + n] = acc[i][j][e];
                 }
             }
-        if (STATS) {
+        if (STATS == 2) {
+            // rows past M (and whole padding items) were staged as zeros, so they add nothing to either sum
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                float s1 = 0.0f, s2 = 0.0f;
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const float v = acc[i][j][e];
+                        s1 += v;
+                        s2 += v * v;
+                    }
+                run1[j] += s1;
+                run2[j] += s2;
+            }
+        }
+        if (STATS == 1) {
             // rows past M were staged as zeros, so they add nothing to either sum
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
@@ -160,17 +183,64 @@ __global__ __launch_bounds__(GR_BLOCK_T) void gemm_rows_kernel(const float *__re
         n0 = nn0;
         rb = nrb;
     }
+    if (STATS == 2) {
+        // all K-loop barriers are behind: one exchange for the whole walk
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            float s1 = run1[j] + __shfl_xor(run1[j], 32), s2 = run2[j] + __shfl_xor(run2[j], 32);
+            if (lh == 0) {
+                s_st[0][wr][(wc * 2 + j) * 32 + l31] = s1;
+                s_st[1][wr][(wc * 2 + j) * 32 + l31] = s2;
+            }
+        }
+        __syncthreads();
+        const int per = 8 * tiles_n;
+        const int64_t slot = (int64_t)(blockIdx.x / per) * 8 + (blockIdx.x & 7);
+        if (tid < GR_BN && n0_first + tid < N) {
+            partial[((size_t)slot * 2 + 0) * N + n0_first + tid] = s_st[0][0][tid] + s_st[0][1][tid];
+            partial[((size_t)slot * 2 + 1) * N + n0_first + tid] = s_st[1][0][tid] + s_st[1][1][tid];
+        }
+    }
 }
 
 }  // namespace tp3d
 
 using namespace tp3d;
 
-// number of 128-row blocks = number of statistic chunks the epilogue writes
+namespace {
+constexpr int GR_GRID = 1024;  // persistent: 4 workgroups per CU, a multiple of 8
+struct RowsPlan {
+    int tiles_n;
+    int64_t row_blocks, items, blocks;
+    bool per_workgroup;  // statistics rows: one per workgroup instead of one per 128-row block
+    int64_t chunks;
+};
+RowsPlan rows_plan(int64_t M, int N)
+{
+    RowsPlan p;
+    p.tiles_n = (N + GR_BN - 1) / GR_BN;
+    p.row_blocks = (M + GR_BM - 1) / GR_BM;
+    const int64_t groups = (p.row_blocks + 7) / 8;
+    p.items = groups * 8 * p.tiles_n;  // items past the last row block stage zeros and store nothing
+    p.blocks = p.items < GR_GRID ? p.items : GR_GRID;
+    p.per_workgroup = p.blocks == GR_GRID && GR_GRID % (8 * p.tiles_n) == 0;
+    p.chunks = p.per_workgroup ? GR_GRID / p.tiles_n : p.row_blocks;
+    return p;
+}
+}  // namespace
+
+// upper bound of the statistics buffer (one row per 128-row block)
 TP3D_EXPORT size_t tp3d_gemm_rows_stat_floats(int64_t M, int N)
 {
     if (M <= 0 || N <= 0) return 0;
     return (size_t)((M + GR_BM - 1) / GR_BM) * 2 * (size_t)N;
+}
+
+// number of statistics rows tp3d_gemm_rows_f32 writes for this shape = `chunks` of tp3d_bn_finalize_f32
+TP3D_EXPORT int tp3d_gemm_rows_stat_chunks(int64_t M, int N)
+{
+    if (M <= 0 || N <= 0) return 0;
+    return (int)rows_plan(M, N).chunks;
 }
 
 TP3D_EXPORT int tp3d_gemm_rows_f32(const float *A, const float *Bt, int64_t M, int N, int K, float *C,
@@ -179,17 +249,18 @@ TP3D_EXPORT int tp3d_gemm_rows_f32(const float *A, const float *Bt, int64_t M, i
     if (M < 0 || N <= 0 || K <= 0 || (K & 3)) return TP3D_E_BADARG;  // operand rows must be 16-byte aligned
     if (M == 0) return TP3D_OK;
     if (!A || !Bt || !C) return TP3D_E_BADARG;
-    const int tiles_n = (N + GR_BN - 1) / GR_BN;
-    const int64_t row_blocks = (M + GR_BM - 1) / GR_BM;
-    const int64_t groups = (row_blocks + 7) / 8;
-    const int64_t items = groups * 8 * tiles_n;  // items past the last row block stage zeros and store nothing
-    const int64_t blocks = items < 1024 ? items : 1024;  // persistent: 4 workgroups per CU, a multiple of 8
+    const RowsPlan p = rows_plan(M, N);
+    const int tiles_n = p.tiles_n;
+    const int64_t items = p.items, blocks = p.blocks;
     hipStream_t s = (hipStream_t)stream;
-    if (stat_partial)
-        hipLaunchKernelGGL(gemm_rows_kernel<true>, dim3((unsigned)blocks), dim3(GR_BLOCK_T), 0, s, A, Bt, M, N, K, tiles_n,
+    if (stat_partial && p.per_workgroup)
+        hipLaunchKernelGGL(gemm_rows_kernel<2>, dim3((unsigned)blocks), dim3(GR_BLOCK_T), 0, s, A, Bt, M, N, K, tiles_n,
+                           items, C, stat_partial);
+    else if (stat_partial)
+        hipLaunchKernelGGL(gemm_rows_kernel<1>, dim3((unsigned)blocks), dim3(GR_BLOCK_T), 0, s, A, Bt, M, N, K, tiles_n,
                            items, C, stat_partial);
     else
-        hipLaunchKernelGGL(gemm_rows_kernel<false>, dim3((unsigned)blocks), dim3(GR_BLOCK_T), 0, s, A, Bt, M, N, K, tiles_n,
+        hipLaunchKernelGGL(gemm_rows_kernel<0>, dim3((unsigned)blocks), dim3(GR_BLOCK_T), 0, s, A, Bt, M, N, K, tiles_n,
                            items, C, stat_partial);
     return check_launch();
 }

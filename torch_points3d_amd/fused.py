@@ -174,7 +174,8 @@ class _LinearBNAct(torch.autograd.Function):
         with _lib.on_device(dev):
             if part is not None:
                 stats = torch.empty((4, Cout), dtype=torch.float32, device=dev)  # mean, invstd, scale, shift
-                _lib.call("tp3d_bn_finalize_f32", _lib.ptr(part), (M + 127) // 128, M, Cout, float(bn.eps),
+                _lib.call("tp3d_bn_finalize_f32", _lib.ptr(part), _lib.load().tp3d_gemm_rows_stat_chunks(M, Cout), M, Cout,
+                          float(bn.eps),
                           float(bn.momentum), _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(bn.running_mean),
                           _lib.ptr(bn.running_var), _lib.ptr(stats[0]), _lib.ptr(stats[1]), _lib.ptr(stats[2]),
                           _lib.ptr(stats[3]), st)
