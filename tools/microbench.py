@@ -41,7 +41,7 @@ def bench_gemm_tn(reps):
 def bench_gemm_rows(reps):
     for M, N, K in [(524288, 128, 132), (524288, 128, 128), (1048576, 64, 8), (1048576, 64, 64), (1048576, 128, 64),
                     (262144, 128, 132), (262144, 128, 128), (262144, 256, 128), (16384, 256, 1280), (16384, 128, 384),
-                    (524288, 132, 128), (1048576, 8, 64), (4096, 1024, 512)]:
+                    (524288, 132, 128), (1048576, 8, 64), (4096, 1024, 512), (4096, 256, 1280), (4096, 256, 260), (4096, 512, 256)]:
         A = torch.randn(M, K, device=DEV)
         Bm = torch.randn(K, N, device=DEV)
         Bt = Bm.t().contiguous()

@@ -116,7 +116,11 @@ __global__ __launch_bounds__(RW_BLOCK) void rows_gather_sum_kernel(const float *
 // A workgroup is a (column-thread x row-lane) tile: V floats per column thread (float4 when C % 4 == 0), the
 // row lanes stride over the chunk with 4 independent rows in flight each, so every wave keeps several KiB
 // of coalesced loads outstanding (the first version had one 256-B row per wave in flight: 0.46 TB/s).
-constexpr int ST_ROWS = 256;  // rows per workgroup
+constexpr int ST_ROWS = 256;        // rows per workgroup, large matrices
+constexpr int ST_ROWS_SMALL = 32;   // small matrices: the pass is a chain of dependent loads per thread, so more and
+                                    // shorter workgroups (a 4096-row layer took 27 us with 16 workgroups of 256 rows)
+constexpr int64_t ST_SMALL_BELOW = 131072;
+static inline int stat_rows(int64_t R) { return R >= ST_SMALL_BELOW ? ST_ROWS : ST_ROWS_SMALL; }
 
 struct StatTile {
     int colthreads, rowlanes, gridx;
@@ -139,14 +143,14 @@ template <int V, int MODE>
 __global__ __launch_bounds__(RW_BLOCK) void colreduce_partial_kernel(
     const float *__restrict__ Y, const float *__restrict__ dA, const float *__restrict__ scale,
     const float *__restrict__ shift, const float *__restrict__ mean, const float *__restrict__ invstd, float slope,
-    int64_t M, int C, int colthreads, float *__restrict__ partial /*[chunks][2][C]*/)
+    int64_t M, int C, int colthreads, int chunk_rows, float *__restrict__ partial /*[chunks][2][C]*/)
 {
     __shared__ float s1[RW_BLOCK * V], s2[RW_BLOCK * V];
     const int ct = threadIdx.x % colthreads, rl = threadIdx.x / colthreads;
     const int rowlanes = RW_BLOCK / colthreads;
     const int c = (blockIdx.x * colthreads + ct) * V;
-    const int64_t r0 = (int64_t)blockIdx.y * ST_ROWS;
-    const int64_t r1 = min(r0 + ST_ROWS, M);
+    const int64_t r0 = (int64_t)blockIdx.y * chunk_rows;
+    const int64_t r1 = min(r0 + chunk_rows, M);
     float a[V], q[V], sc[V], sh[V], mu[V], is[V];
 #pragma unroll
     for (int v = 0; v < V; ++v) {
@@ -365,14 +369,14 @@ __global__ __launch_bounds__(RW_BLOCK) void bn_pool_bwd_partial_kernel(const flo
                                                                         const float *__restrict__ shift,
                                                                         const float *__restrict__ mean,
                                                                         const float *__restrict__ invstd, float slope,
-                                                                        int64_t G, int ns, int C,
+                                                                        int64_t G, int ns, int C, int chunk_rows,
                                                                         float *__restrict__ partial)
 {
     __shared__ float s1[4][64], s2[4][64];
     const int tc = threadIdx.x & 63, tr = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + tc;
-    const int64_t g0 = (int64_t)blockIdx.y * ST_ROWS;
-    const int64_t g1 = min(g0 + ST_ROWS, G);
+    const int64_t g0 = (int64_t)blockIdx.y * chunk_rows;
+    const int64_t g1 = min(g0 + chunk_rows, G);
     float a = 0.0f, q = 0.0f;
     if (c < C) {
         const float sc = scale[c], sh = shift[c], mu = mean[c], is = invstd[c];
@@ -453,22 +457,27 @@ __global__ __launch_bounds__(RW_BLOCK) void bn_act_bwd_apply_kernel(
 }
 
 // pooled variant: dP (G, C) reaches only the arg-max row of each group; one lane per (group, channel) walks ns rows
+// (few groups: the ns rows are cut into `split` segments with a lane each, so that the launch still fills the chip)
 __global__ __launch_bounds__(RW_BLOCK) void bn_pool_bwd_apply_kernel(
     const float *__restrict__ dP, const int *__restrict__ arg, const float *__restrict__ Y,
     const float *__restrict__ scale, const float *__restrict__ shift, const float *__restrict__ mean,
     const float *__restrict__ invstd, const float *__restrict__ dbeta, const float *__restrict__ dgamma, float slope,
-    int64_t G, int ns, int C, int training, float *__restrict__ dY)
+    int64_t G, int ns, int C, int split, int training, float *__restrict__ dY)
 {
-    const int64_t total = G * C;
+    const int64_t GC = G * C, total = GC * split;
+    const int seg_len = (ns + split - 1) / split;
     const float invM = 1.0f / (float)(G * ns);
-    for (int64_t e = (int64_t)blockIdx.x * RW_BLOCK + threadIdx.x; e < total; e += (int64_t)gridDim.x * RW_BLOCK) {
+    for (int64_t w = (int64_t)blockIdx.x * RW_BLOCK + threadIdx.x; w < total; w += (int64_t)gridDim.x * RW_BLOCK) {
+        const int seg = (int)(w / GC);
+        const int64_t e = w - (int64_t)seg * GC;
         const int64_t g = e / C;
         const int c = (int)(e - g * C);
         const float sc = scale[c], sh = shift[c], mu = mean[c], is = invstd[c], db = dbeta[c], dg = dgamma[c];
         const float dp = dP[e];
         const int sa = arg[e];
         const size_t base = (size_t)g * ns * C + c;
-        for (int s = 0; s < ns; ++s) {
+        const int s_end = min(ns, (seg + 1) * seg_len);
+        for (int s = seg * seg_len; s < s_end; ++s) {
             const float y = Y[base + (size_t)s * C];
             dY[base + (size_t)s * C] = bn_bwd_elem(s == sa ? dp : 0.0f, y, sc, sh, mu, is, db, dg, slope, invM, training);
         }
@@ -598,7 +607,10 @@ TP3D_EXPORT int tp3d_rows_scatter_bwd_f32(const float *grad_rows, const int64_t 
 TP3D_EXPORT size_t tp3d_bn_workspace_floats(int64_t M, int C)
 {
     if (M < 0 || C < 0) return 0;
-    return (size_t)((M + ST_ROWS - 1) / ST_ROWS) * 2 * (size_t)C;
+    // covers the reduction over M rows and over any M / ns pooled groups (which may fall in the small-matrix regime)
+    int64_t chunks = M >= ST_SMALL_BELOW ? (M + ST_ROWS - 1) / ST_ROWS : (M + ST_ROWS_SMALL - 1) / ST_ROWS_SMALL;
+    if (M >= ST_SMALL_BELOW && chunks < ST_SMALL_BELOW / ST_ROWS_SMALL) chunks = ST_SMALL_BELOW / ST_ROWS_SMALL;
+    return (size_t)chunks * 2 * (size_t)C;
 }
 
 TP3D_EXPORT int tp3d_bn_stats_f32(const float *Y, int64_t M, int C, float eps, float momentum, const float *gamma,
@@ -609,7 +621,8 @@ TP3D_EXPORT int tp3d_bn_stats_f32(const float *Y, int64_t M, int C, float eps, f
     if (M <= 0 || C <= 0 || !mean || !invstd || !scale || !shift) return TP3D_E_BADARG;
     if (!training && (!running_mean || !running_var)) return TP3D_E_BADARG;
     hipStream_t s = (hipStream_t)stream;
-    const int chunks = (int)((M + ST_ROWS - 1) / ST_ROWS);
+    const int crow = stat_rows(M);
+    const int chunks = (int)((M + crow - 1) / crow);
     if (training) {
         if (!Y || !workspace) return TP3D_E_BADARG;
         if (chunks > 65535) return TP3D_E_TOOBIG;
@@ -617,12 +630,12 @@ TP3D_EXPORT int tp3d_bn_stats_f32(const float *Y, int64_t M, int C, float eps, f
             const StatTile t = stat_tile(C, 4);
             hipLaunchKernelGGL((colreduce_partial_kernel<4, 0>), dim3(t.gridx, chunks), dim3(RW_BLOCK), 0, s, Y,
                                (const float *)nullptr, (const float *)nullptr, (const float *)nullptr,
-                               (const float *)nullptr, (const float *)nullptr, 0.0f, M, C, t.colthreads, workspace);
+                               (const float *)nullptr, (const float *)nullptr, 0.0f, M, C, t.colthreads, crow, workspace);
         } else {
             const StatTile t = stat_tile(C, 1);
             hipLaunchKernelGGL((colreduce_partial_kernel<1, 0>), dim3(t.gridx, chunks), dim3(RW_BLOCK), 0, s, Y,
                                (const float *)nullptr, (const float *)nullptr, (const float *)nullptr,
-                               (const float *)nullptr, (const float *)nullptr, 0.0f, M, C, t.colthreads, workspace);
+                               (const float *)nullptr, (const float *)nullptr, 0.0f, M, C, t.colthreads, crow, workspace);
         }
         if (int rc = check_launch()) return rc;
     }
@@ -681,26 +694,30 @@ TP3D_EXPORT int tp3d_bn_act_bwd_f32(const float *dA, const int *argmax, const fl
         return TP3D_E_BADARG;
     hipStream_t s = (hipStream_t)stream;
     const int64_t R = argmax ? M / ns : M;  // rows of the reduction domain
-    const int chunks = (int)((R + ST_ROWS - 1) / ST_ROWS);
+    const int crow = stat_rows(R);
+    const int chunks = (int)((R + crow - 1) / crow);
     if (chunks > 65535) return TP3D_E_TOOBIG;
     if (argmax) {
         hipLaunchKernelGGL(bn_pool_bwd_partial_kernel, dim3((C + 63) / 64, chunks), dim3(RW_BLOCK), 0, s, dA, argmax, Y,
-                           scale, shift, mean, invstd, slope, R, ns, C, workspace);
+                           scale, shift, mean, invstd, slope, R, ns, C, crow, workspace);
     } else if ((C & 3) == 0) {
         const StatTile t = stat_tile(C, 4);
         hipLaunchKernelGGL((colreduce_partial_kernel<4, 1>), dim3(t.gridx, chunks), dim3(RW_BLOCK), 0, s, Y, dA, scale,
-                           shift, mean, invstd, slope, M, C, t.colthreads, workspace);
+                           shift, mean, invstd, slope, M, C, t.colthreads, crow, workspace);
     } else {
         const StatTile t = stat_tile(C, 1);
         hipLaunchKernelGGL((colreduce_partial_kernel<1, 1>), dim3(t.gridx, chunks), dim3(RW_BLOCK), 0, s, Y, dA, scale,
-                           shift, mean, invstd, slope, M, C, t.colthreads, workspace);
+                           shift, mean, invstd, slope, M, C, t.colthreads, crow, workspace);
     }
     if (int rc = check_launch()) return rc;
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(RW_BLOCK), 0, s, workspace, chunks, C, dbeta, dgamma);
     if (int rc = check_launch()) return rc;
-    if (argmax)
-        hipLaunchKernelGGL(bn_pool_bwd_apply_kernel, dim3(grid_for(R * C)), dim3(RW_BLOCK), 0, s, dA, argmax, Y, scale,
-                           shift, mean, invstd, dbeta, dgamma, slope, R, ns, C, training, dY);
+    if (argmax) {
+        int split = (int)((262144 + R * C - 1) / (R * C));  // ~4 waves per SIMD worth of lanes
+        split = split < 1 ? 1 : (split > ns ? ns : split);
+        hipLaunchKernelGGL(bn_pool_bwd_apply_kernel, dim3(grid_for(R * C * split)), dim3(RW_BLOCK), 0, s, dA, argmax, Y,
+                           scale, shift, mean, invstd, dbeta, dgamma, slope, R, ns, C, split, training, dY);
+    }
     else if ((C & 3) == 0)
         hipLaunchKernelGGL(bn_act_bwd_apply_kernel<4>, dim3(grid_for(M * C / 4)), dim3(RW_BLOCK), 0, s, dA, Y, scale,
                            shift, mean, invstd, dbeta, dgamma, slope, M, C, training, dY);
