@@ -8,6 +8,8 @@
 //   torch_points3d/modules/pointnet2/dense.py:72-73   max over nsample
 //   torch_points3d/core/base_conv/dense.py:132-144    inverse-distance 3-NN interpolation (+ skip concat :117)
 // HBM-bound: each kernel reads and writes every activation byte at most once per pass.
+#include <cstdlib>
+
 #include "tp3d_common.h"
 
 namespace tp3d {
@@ -52,7 +54,10 @@ __device__ __forceinline__ float rl_f(float x, int lane)
 }
 
 // grad_x_cl[b,k,:] = sum over slots l (ascending) with idx[b,l]==k of grad_rows[(b,l), col0 + :]   (CSR gather)
-// one wave per destination point, lanes over channels: every read is a contiguous row segment.
+// one wave per destination point, lanes over channels: every read is a contiguous row segment.  NP = channel slots per
+// lane (c = lane + 64 p): a row of up to 64 NP channels is fetched in one traversal of the run, so 4 NP independent
+// loads are in flight per lane (two traversals of 64 channels each ran the 128-channel decoder tables at 1.6 TB/s).
+template <int NP>
 __global__ __launch_bounds__(RW_BLOCK) void rows_gather_sum_kernel(const float *__restrict__ grad_rows,
                                                                     const int *__restrict__ start,
                                                                     const int *__restrict__ order,
@@ -70,11 +75,16 @@ __global__ __launch_bounds__(RW_BLOCK) void rows_gather_sum_kernel(const float *
     const float *ws = wsorted ? (flat ? wsorted : wsorted + (size_t)b * L) : nullptr;
     const int lo = st[dest], hi = st[dest + 1];
     const float *base = grad_rows + (flat ? (size_t)0 : (size_t)b * rows_per_cloud * ld) + col0;
-    for (int c0 = 0; c0 < C; c0 += 64) {
-        const int c = min(c0 + lane, C - 1);
-        float acc = 0.0f;
+    for (int c0 = 0; c0 < C; c0 += 64 * NP) {
+        int c[NP];
+        float acc[NP];
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            c[p] = min(c0 + p * 64 + lane, C - 1);
+            acc[p] = 0.0f;
+        }
         // the run's (row, weight) pairs are fetched 64 at a time with one coalesced load, then broadcast lane by
-        // lane (v_readlane), so four independent row reads are in flight instead of a dependent index->row chain
+        // lane (v_readlane), so independent row reads are in flight instead of a dependent index->row chain
         for (int j0 = lo; j0 < hi; j0 += 64) {
             const int cnt = min(64, hi - j0);
             const int my_r = (lane < cnt) ? od[j0 + lane] : 0;
@@ -83,16 +93,29 @@ __global__ __launch_bounds__(RW_BLOCK) void rows_gather_sum_kernel(const float *
             for (; t + 4 <= cnt; t += 4) {
                 const int r0 = __builtin_amdgcn_readlane(my_r, t), r1 = __builtin_amdgcn_readlane(my_r, t + 1);
                 const int r2 = __builtin_amdgcn_readlane(my_r, t + 2), r3 = __builtin_amdgcn_readlane(my_r, t + 3);
-                const float v0 = base[(size_t)r0 * ld + c], v1 = base[(size_t)r1 * ld + c];
-                const float v2 = base[(size_t)r2 * ld + c], v3 = base[(size_t)r3 * ld + c];
+                float v0[NP], v1[NP], v2[NP], v3[NP];
+#pragma unroll
+                for (int p = 0; p < NP; ++p) {
+                    v0[p] = base[(size_t)r0 * ld + c[p]];
+                    v1[p] = base[(size_t)r1 * ld + c[p]];
+                    v2[p] = base[(size_t)r2 * ld + c[p]];
+                    v3[p] = base[(size_t)r3 * ld + c[p]];
+                }
                 if (ws) {
-                    acc = acc + rl_f(my_w, t) * v0;
-                    acc = acc + rl_f(my_w, t + 1) * v1;
-                    acc = acc + rl_f(my_w, t + 2) * v2;
-                    acc = acc + rl_f(my_w, t + 3) * v3;
+                    const float w0 = rl_f(my_w, t), w1 = rl_f(my_w, t + 1), w2 = rl_f(my_w, t + 2), w3 = rl_f(my_w, t + 3);
+#pragma unroll
+                    for (int p = 0; p < NP; ++p) {
+                        acc[p] = acc[p] + w0 * v0[p];
+                        acc[p] = acc[p] + w1 * v1[p];
+                        acc[p] = acc[p] + w2 * v2[p];
+                        acc[p] = acc[p] + w3 * v3[p];
+                    }
                 } else {
-                    acc = ((acc + v0) + v1) + v2;
-                    acc = acc + v3;
+#pragma unroll
+                    for (int p = 0; p < NP; ++p) {
+                        acc[p] = ((acc[p] + v0[p]) + v1[p]) + v2[p];
+                        acc[p] = acc[p] + v3[p];
+                    }
                 }
             }
             // tail of 1..3 rows (most runs of a grouping table are that short): requested together, summed in order
@@ -101,13 +124,21 @@ __global__ __launch_bounds__(RW_BLOCK) void rows_gather_sum_kernel(const float *
                 const int r0 = __builtin_amdgcn_readlane(my_r, t);
                 const int r1 = __builtin_amdgcn_readlane(my_r, min(t + 1, cnt - 1));
                 const int r2 = __builtin_amdgcn_readlane(my_r, min(t + 2, cnt - 1));
-                const float v0 = base[(size_t)r0 * ld + c], v1 = base[(size_t)r1 * ld + c], v2 = base[(size_t)r2 * ld + c];
-                acc = acc + (ws ? rl_f(my_w, t) * v0 : v0);
-                if (rem > 1) acc = acc + (ws ? rl_f(my_w, min(t + 1, cnt - 1)) * v1 : v1);
-                if (rem > 2) acc = acc + (ws ? rl_f(my_w, min(t + 2, cnt - 1)) * v2 : v2);
+                const float w0 = ws ? rl_f(my_w, t) : 1.0f, w1 = ws ? rl_f(my_w, min(t + 1, cnt - 1)) : 1.0f,
+                            w2 = ws ? rl_f(my_w, min(t + 2, cnt - 1)) : 1.0f;
+#pragma unroll
+                for (int p = 0; p < NP; ++p) {
+                    const float v0 = base[(size_t)r0 * ld + c[p]], v1 = base[(size_t)r1 * ld + c[p]],
+                                v2 = base[(size_t)r2 * ld + c[p]];
+                    acc[p] = acc[p] + (ws ? w0 * v0 : v0);
+                    if (rem > 1) acc[p] = acc[p] + (ws ? w1 * v1 : v1);
+                    if (rem > 2) acc[p] = acc[p] + (ws ? w2 * v2 : v2);
+                }
             }
         }
-        if (c0 + lane < C) out[((size_t)b * nbins + dest) * C + c0 + lane] = acc;
+#pragma unroll
+        for (int p = 0; p < NP; ++p)
+            if (c0 + p * 64 + lane < C) out[((size_t)b * nbins + dest) * C + c0 + p * 64 + lane] = acc[p];
     }
 }
 
@@ -521,6 +552,46 @@ __global__ __launch_bounds__(RW_BLOCK) void interp_concat_fwd_kernel(const float
     }
 }
 
+// same, four output columns per thread (ld % 4 == 0, C1 % 4 == 0): one row decode, one index/weight fetch and three
+// 16-byte feature loads per float4 stored -- the one-column kernel above spent its time on per-element address
+// arithmetic (216 us for the 277 MB decoder tensor); per-element arithmetic and its order are unchanged
+__global__ __launch_bounds__(RW_BLOCK) void interp_concat_fwd4_kernel(const float *__restrict__ feat_cl,
+                                                                       const int64_t *__restrict__ idx,
+                                                                       const float *__restrict__ w,
+                                                                       const float *__restrict__ skip_cl, int m, int n,
+                                                                       int C1, int C2, int ld, int64_t total4,
+                                                                       float *__restrict__ out)
+{
+    const int Cw = C1 + C2, q = ld >> 2;
+    for (int64_t e4 = (int64_t)blockIdx.x * RW_BLOCK + threadIdx.x; e4 < total4; e4 += (int64_t)gridDim.x * RW_BLOCK) {
+        const int64_t row = e4 / q;  // b*n + i
+        const int c = (int)(e4 - row * q) * 4;
+        float4 v;
+        if (c < C1) {  // C1 % 4 == 0: the four columns are all interpolated ones
+            const int b = (int)(row / n);
+            const int64_t *ip = idx + row * 3;
+            const float *wp = w + row * 3;
+            const int k0 = min(max((int)ip[0], 0), m - 1), k1 = min(max((int)ip[1], 0), m - 1),
+                      k2 = min(max((int)ip[2], 0), m - 1);
+            const float w0 = wp[0], w1 = wp[1], w2 = wp[2];
+            const float *fb = feat_cl + (size_t)b * m * C1 + c;
+            const float4 f0 = *reinterpret_cast<const float4 *>(fb + (size_t)k0 * C1);
+            const float4 f1 = *reinterpret_cast<const float4 *>(fb + (size_t)k1 * C1);
+            const float4 f2 = *reinterpret_cast<const float4 *>(fb + (size_t)k2 * C1);
+            v.x = (w0 * f0.x + w1 * f1.x) + w2 * f2.x;
+            v.y = (w0 * f0.y + w1 * f1.y) + w2 * f2.y;
+            v.z = (w0 * f0.z + w1 * f1.z) + w2 * f2.z;
+            v.w = (w0 * f0.w + w1 * f1.w) + w2 * f2.w;
+        } else {
+            float t[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) t[j] = (c + j < Cw) ? skip_cl[row * C2 + (c + j - C1)] : 0.0f;
+            v = make_float4(t[0], t[1], t[2], t[3]);
+        }
+        *reinterpret_cast<float4 *>(out + e4 * 4) = v;
+    }
+}
+
 // inverse-distance weights exactly as the reference builds them (core/base_conv/dense.py:137-139):
 //   r_t = 1/(dist_t + 1e-8);  w_t = r_t / ((r0 + r1) + r2)
 __global__ void idw_weights_kernel(const float *__restrict__ dist, int64_t rows, float *__restrict__ w)
@@ -588,8 +659,14 @@ TP3D_EXPORT int tp3d_rows_scatter_bwd_f32(const float *grad_rows, const int64_t 
     // One large cloud (partial-dense decoders), or clouds whose tables do not fit one workgroup's LDS (multi-scale
     // grouping: 512 x 128 slots per cloud): invert ONE flat table over the whole device instead of one table per
     // workgroup (scratch holds the histogram and the cursors), then turn slot ids into row ids and line the weights up.
+    // (measured on the 49 152-slot decoder tables, which fit LDS: flat 523 us vs per-cloud 354 us, so off by default)
+    static const int flat_min_l = [] {  // tuning switch: tables of at least this many slots per cloud go flat too
+        const char *e = getenv("TP3D_SCATTER_FLAT_MIN_L");
+        const int v = e ? atoi(e) : 0;
+        return v > 0 ? v : 0x7fffffff;
+    }();
     const bool flat = L >= 2 * nbins && (int64_t)B * L < 0x7fffffff && (int64_t)B * nbins < 0x3fffffff &&
-                      ((B == 1 && L >= 16384) || !csr_fits_lds(L, nbins));
+                      ((B == 1 && L >= 16384) || !csr_fits_lds(L, nbins) || L >= flat_min_l);
     if (flat) {
         const int64_t slots = (int64_t)B * L, bins = (int64_t)B * nbins;
         if (int rc = invert_table(idx, slots, bins, w.scratch, w.start, w.scratch + bins, w.order, s, L, nbins)) return rc;
@@ -599,8 +676,15 @@ TP3D_EXPORT int tp3d_rows_scatter_bwd_f32(const float *grad_rows, const int64_t 
         return rc;
     }
     dim3 grid((nbins + RW_BLOCK / 64 - 1) / (RW_BLOCK / 64), B);
-    hipLaunchKernelGGL(rows_gather_sum_kernel, grid, dim3(RW_BLOCK), 0, s, grad_rows, w.start, w.order, w.wsorted,
-                       nbins, L, L / div, ld, col0, C, grad_x_cl, flat ? 1 : 0);
+    if (C > 128)
+        hipLaunchKernelGGL(rows_gather_sum_kernel<4>, grid, dim3(RW_BLOCK), 0, s, grad_rows, w.start, w.order, w.wsorted,
+                           nbins, L, L / div, ld, col0, C, grad_x_cl, flat ? 1 : 0);
+    else if (C > 64)
+        hipLaunchKernelGGL(rows_gather_sum_kernel<2>, grid, dim3(RW_BLOCK), 0, s, grad_rows, w.start, w.order, w.wsorted,
+                           nbins, L, L / div, ld, col0, C, grad_x_cl, flat ? 1 : 0);
+    else
+        hipLaunchKernelGGL(rows_gather_sum_kernel<1>, grid, dim3(RW_BLOCK), 0, s, grad_rows, w.start, w.order, w.wsorted,
+                           nbins, L, L / div, ld, col0, C, grad_x_cl, flat ? 1 : 0);
     return check_launch();
 }
 
@@ -735,8 +819,12 @@ TP3D_EXPORT int tp3d_interp_concat_fwd_f32(const float *feat_cl, const int64_t *
     const int64_t total = (int64_t)B * n * ld;
     if (total == 0) return TP3D_OK;
     if (!out || (C1 > 0 && (!feat_cl || !idx || !weight)) || (C2 > 0 && !skip_cl)) return TP3D_E_BADARG;
-    hipLaunchKernelGGL(interp_concat_fwd_kernel, dim3(grid_for(total)), dim3(RW_BLOCK), 0, (hipStream_t)stream,
-                       feat_cl, idx, weight, skip_cl, m, n, C1, C2, ld, total, out);
+    if ((ld & 3) == 0 && (C1 & 3) == 0 && (((uintptr_t)feat_cl | (uintptr_t)out) & 15) == 0)
+        hipLaunchKernelGGL(interp_concat_fwd4_kernel, dim3(grid_for(total / 4)), dim3(RW_BLOCK), 0, (hipStream_t)stream,
+                           feat_cl, idx, weight, skip_cl, m, n, C1, C2, ld, total / 4, out);
+    else
+        hipLaunchKernelGGL(interp_concat_fwd_kernel, dim3(grid_for(total)), dim3(RW_BLOCK), 0, (hipStream_t)stream,
+                           feat_cl, idx, weight, skip_cl, m, n, C1, C2, ld, total, out);
     return check_launch();
 }
 
