@@ -48,6 +48,47 @@ __global__ __launch_bounds__(RW_BLOCK) void group_concat_fwd_kernel(const float 
     }
 }
 
+// same, four output columns per thread (ld % 4 == 0): one row decode and one index fetch per float4 stored; the
+// feature columns of a quad are contiguous in x_cl (offset by the three xyz columns, hence 4-byte aligned only)
+struct __attribute__((packed, aligned(4))) f4u {
+    float v[4];
+};
+__global__ __launch_bounds__(RW_BLOCK) void group_concat_fwd4_kernel(const float *__restrict__ pos,
+                                                                      const float *__restrict__ new_pos,
+                                                                      const float *__restrict__ x_cl,
+                                                                      const int64_t *__restrict__ idx, int N, int np,
+                                                                      int ns, int C, int ld, float radius,
+                                                                      int normalize, int64_t total4,
+                                                                      float *__restrict__ out)
+{
+    const int Cw = C + 3, q = ld >> 2;
+    for (int64_t e4 = (int64_t)blockIdx.x * RW_BLOCK + threadIdx.x; e4 < total4; e4 += (int64_t)gridDim.x * RW_BLOCK) {
+        const int64_t row = e4 / q;
+        const int c = (int)(e4 - row * q) * 4;
+        const int64_t bj = row / ns;  // b*np + j
+        const int b = (int)(bj / np);
+        const int k = min(max((int)idx[row], 0), N - 1);
+        float t[4];
+        if (c == 0) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                float v = pos[((size_t)b * N + k) * 3 + j] - new_pos[bj * 3 + j];
+                if (normalize) v = v / radius;  // the reference divides (modules/pointnet2/dense.py:41-42)
+                t[j] = v;
+            }
+            t[3] = C > 0 ? x_cl[((size_t)b * N + k) * C] : 0.0f;
+        } else if (c + 3 < Cw) {  // four feature columns c-3 .. c
+            const f4u f = *reinterpret_cast<const f4u *>(x_cl + ((size_t)b * N + k) * C + (c - 3));
+#pragma unroll
+            for (int j = 0; j < 4; ++j) t[j] = f.v[j];
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) t[j] = (c + j < Cw) ? x_cl[((size_t)b * N + k) * C + (c + j - 3)] : 0.0f;
+        }
+        *reinterpret_cast<float4 *>(out + e4 * 4) = make_float4(t[0], t[1], t[2], t[3]);
+    }
+}
+
 __device__ __forceinline__ float rl_f(float x, int lane)
 {
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), lane));
@@ -376,7 +417,22 @@ __global__ __launch_bounds__(RW_BLOCK) void bn_act_maxpool_kernel(const float *_
         const float *y = Y + (size_t)g * ns * C + c;
         float best = -INFINITY;
         int bs = 0;
-        for (int s = 0; s < ns; ++s) {
+        int s = 0;
+        for (; s + 8 <= ns; s += 8) {  // eight independent row loads in flight, compared in row order
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = y[(size_t)(s + u) * C];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const float z = v[u] * sc + sh;
+                const float a = z > 0.0f ? z : z * slope;
+                if (a > best) {
+                    best = a;
+                    bs = s + u;
+                }
+            }
+        }
+        for (; s < ns; ++s) {
             const float z = y[(size_t)s * C] * sc + sh;
             const float a = z > 0.0f ? z : z * slope;
             if (a > best) {
@@ -625,8 +681,12 @@ TP3D_EXPORT int tp3d_group_concat_fwd_f32(const float *pos, const float *new_pos
     const int64_t total = (int64_t)B * np * ns * ld;
     if (total == 0) return TP3D_OK;
     if (!pos || !new_pos || !idx || !out || (C > 0 && !x_cl)) return TP3D_E_BADARG;
-    hipLaunchKernelGGL(group_concat_fwd_kernel, dim3(grid_for(total)), dim3(RW_BLOCK), 0, (hipStream_t)stream, pos,
-                       new_pos, x_cl, idx, N, np, ns, C, ld, radius, normalize, total, out);
+    if ((ld & 3) == 0 && ((uintptr_t)out & 15) == 0)
+        hipLaunchKernelGGL(group_concat_fwd4_kernel, dim3(grid_for(total / 4)), dim3(RW_BLOCK), 0, (hipStream_t)stream,
+                           pos, new_pos, x_cl, idx, N, np, ns, C, ld, radius, normalize, total / 4, out);
+    else
+        hipLaunchKernelGGL(group_concat_fwd_kernel, dim3(grid_for(total)), dim3(RW_BLOCK), 0, (hipStream_t)stream, pos,
+                           new_pos, x_cl, idx, N, np, ns, C, ld, radius, normalize, total, out);
     return check_launch();
 }
 
