@@ -70,6 +70,10 @@ __global__ __launch_bounds__(CSR_BLOCK) void csr_transpose_kernel(const int64_t 
     const int64_t *ib = idx + (size_t)b * L;
     int *g_start = start + (size_t)b * (nbins + 1);
     int *g_order = order + (size_t)b * L;
+    // gridDim.y workgroups share a cloud (in-LDS tables only): each builds the full histogram (cheap) but fills, sorts
+    // and writes only its contiguous range of bins -- the per-bin sorts are what the pass spends its time on
+    const int part = blockIdx.y, parts = gridDim.y;
+    const int k_lo = (int)((int64_t)nbins * part / parts), k_hi = (int)((int64_t)nbins * (part + 1) / parts);
 
     int *cnt;   // nbins ints: histogram -> bin start -> bin end
     OrdT *ord;  // L slot ids
@@ -104,6 +108,8 @@ __global__ __launch_bounds__(CSR_BLOCK) void csr_transpose_kernel(const int64_t 
     }
     __syncthreads();
     block_exclusive_scan(cnt, nbins, s_wave);
+    const int j_lo = k_lo < nbins ? cnt[k_lo] : L;  // first slot position of this workgroup's bins (read before the fill)
+    __syncthreads();
     for (int base = 0; base < L; base += PER * CSR_BLOCK) {
         if (!keep) {
 #pragma unroll
@@ -115,8 +121,8 @@ __global__ __launch_bounds__(CSR_BLOCK) void csr_transpose_kernel(const int64_t 
 #pragma unroll
         for (int u = 0; u < PER; ++u) {
             if (base + u * CSR_BLOCK < L) {  // workgroup-uniform: the barrier is reached by every thread
-                if (vals[u] >= 0) {
-                    const int pos = atomicAdd(&cnt[vals[u]], 1);  // cnt[k] ends as the END of bin k
+                if (vals[u] >= k_lo && vals[u] < k_hi) {
+                    const int pos = atomicAdd(&cnt[vals[u]], 1);  // cnt[k] ends as the END of bin k (own bins)
                     ord[pos] = (OrdT)(base + u * CSR_BLOCK + tid);
                 }
                 __syncthreads();
@@ -130,8 +136,8 @@ __global__ __launch_bounds__(CSR_BLOCK) void csr_transpose_kernel(const int64_t 
     // would serialise hundreds of dependent LDS steps in one thread (measured: 78 of 95 us for SA2's table), so a whole
     // wave sorts such a bin instead: its slots sit in registers (up to 16 per lane) and go through a bitonic network
     // (in-lane exchanges for strides >= 64, wave shuffles below).
-    for (int k = tid; k < nbins; k += CSR_BLOCK) {
-        const int lo = k ? cnt[k - 1] : 0, hi = cnt[k];
+    for (int k = k_lo + tid; k < k_hi; k += CSR_BLOCK) {
+        const int lo = k == k_lo ? j_lo : cnt[k - 1], hi = cnt[k];
         if (hi - lo > CSR_SMALL_BIN && hi - lo <= 64 * CSR_RANK_SLOTS) continue;  // ranked by a wave below
         for (int a = lo + 1; a < hi; ++a) {
             OrdT v = ord[a];
@@ -145,11 +151,11 @@ __global__ __launch_bounds__(CSR_BLOCK) void csr_transpose_kernel(const int64_t 
     }
     {
         const int lane = tid & 63, wave = tid >> 6;
-        for (int k0 = wave * 64; k0 < nbins; k0 += (CSR_BLOCK / 64) * 64) {
+        for (int k0 = k_lo + wave * 64; k0 < k_hi; k0 += (CSR_BLOCK / 64) * 64) {
             const int k = k0 + lane;
             int lo = 0, hi = 0;
-            if (k < nbins) {
-                lo = k ? cnt[k - 1] : 0;
+            if (k < k_hi) {
+                lo = k == k_lo ? j_lo : cnt[k - 1];
                 hi = cnt[k];
             }
             unsigned long long big = __ballot(hi - lo > CSR_SMALL_BIN && hi - lo <= 64 * CSR_RANK_SLOTS);
@@ -166,14 +172,15 @@ __global__ __launch_bounds__(CSR_BLOCK) void csr_transpose_kernel(const int64_t 
         }
     }
     __syncthreads();
-    for (int j = tid; j < L; j += CSR_BLOCK) {
+    const int j_hi = k_hi > k_lo ? cnt[k_hi - 1] : j_lo;
+    for (int j = j_lo + tid; j < j_hi; j += CSR_BLOCK) {
         const int s = (int)ord[j];
         if (wsorted) wsorted[(size_t)b * L + j] = weight[(size_t)b * L + s];
         g_order[j] = s / div;
     }
     if (IN_LDS) {
-        for (int k = tid; k < nbins; k += CSR_BLOCK) g_start[k] = k ? cnt[k - 1] : 0;
-        if (tid == 0) g_start[nbins] = L;
+        for (int k = k_lo + tid; k < k_hi; k += CSR_BLOCK) g_start[k] = k == k_lo ? j_lo : cnt[k - 1];
+        if (tid == 0 && part == parts - 1) g_start[nbins] = L;
     } else {
         // cnt aliases g_start and holds bin ENDS: shift by one bin (every thread reads before anyone writes)
         const int per = (nbins + CSR_BLOCK - 1) / CSR_BLOCK;
@@ -204,8 +211,11 @@ int csr_transpose(const int64_t *idx, int B, int L, int nbins, int div, const fl
         static bool attr_set[64] = {false};
         allow_large_dynamic_lds(reinterpret_cast<const void *>(&csr_transpose_kernel<uint16_t, true>), CSR_LDS_BYTES,
                                 attr_set);
-        hipLaunchKernelGGL((csr_transpose_kernel<uint16_t, true>), dim3(B), dim3(CSR_BLOCK), lds, s, idx, L, nbins, div,
-                           weight, start, order, wsorted, scratch_ord);
+        // few clouds with large tables leave most of the chip idle: up to four workgroups per cloud, each a bin range
+        int parts = 1;
+        while (parts < 4 && B * parts * 2 <= 256 && nbins >= parts * 2 * 64 && L >= 8192) parts *= 2;
+        hipLaunchKernelGGL((csr_transpose_kernel<uint16_t, true>), dim3(B, parts), dim3(CSR_BLOCK), lds, s, idx, L, nbins,
+                           div, weight, start, order, wsorted, scratch_ord);
     } else {
         hipLaunchKernelGGL((csr_transpose_kernel<int, false>), dim3(B), dim3(CSR_BLOCK), 0, s, idx, L, nbins, div,
                            weight, start, order, wsorted, scratch_ord);
