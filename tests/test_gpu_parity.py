@@ -181,6 +181,36 @@ def test_grouping_fwd_bwd(hip, oracle, B, C, N, npnt, ns):
     assert torch.equal(g2, fa.grad)  # no atomics: bitwise reproducible run to run
 
 
+@pytest.mark.parametrize("npnt,ns,N", [(64, 128, 300), (600, 128, 300), (40, 64, 2000)])
+def test_grouping_bwd_giant_bins(hip, oracle, npnt, ns, N):
+    """Dense ball queries pad with their first hit: when that is the same point for many queries, one destination
+    collects thousands of slots (here npnt * (ns - 40)).  The inverse-index build sorts such a bin window segment by
+    window segment; the accumulation order -- hence the result -- must still be the oracle's, bit for bit.
+    (600 x 128 slots do not fit the in-LDS tables: second code path.)"""
+    B, C = 2, 5
+    g = torch.Generator().manual_seed(npnt + ns)
+    feat = torch.randn(B, C, N, generator=g)
+    idx = torch.randint(0, N, (B, npnt, ns), generator=g)
+    idx[:, :, 40:] = 0  # every query: 40 hits, then padding with point 0
+    idx[1, :, 40:] = idx[1, :1, :1]  # second cloud: another shared first hit
+    cot = torch.randn(B, C, npnt, ns, generator=g)
+    fa = feat.clone().to(DEV).requires_grad_(True)
+    fb = feat.clone().requires_grad_(True)
+    hip.grouping_operation(fa, idx.to(DEV)).backward(cot.to(DEV))
+    oracle.grouping_operation(fb, idx).backward(cot)
+    assert torch.equal(fa.grad.cpu(), fb.grad)
+    # the channel-last rows path (fused set abstraction) goes through the same tables
+    from torch_points3d_amd import fused
+    pos = torch.rand(B, N, 3, generator=g).to(DEV)
+    new_pos = pos[:, :npnt].contiguous() if npnt <= N else pos.repeat(1, 3, 1)[:, :npnt].contiguous()
+    xa = feat.transpose(1, 2).contiguous().to(DEV).requires_grad_(True)
+    rows = fused.group_concat(pos, new_pos, xa, idx.to(DEV), 1.0, False)
+    cot_rows = torch.zeros_like(rows)
+    cot_rows[:, 3:3 + C] = cot.permute(0, 2, 3, 1).reshape(-1, C).to(DEV)
+    rows.backward(cot_rows)
+    assert torch.equal(xa.grad.transpose(1, 2).cpu(), fb.grad)
+
+
 def test_strided_and_int32_inputs_are_normalised(hip, oracle):
     x = cloud(2, 400, 5)
     xt = x.transpose(1, 2).contiguous().transpose(1, 2)  # non-contiguous view

@@ -56,6 +56,16 @@ __device__ void block_exclusive_scan(CntPtr cnt, int n, int *s_wave /* CSR_BLOCK
 
 
 // OrdT: uint16_t when L <= 65536 (LDS variant), int otherwise.
+template <typename OrdT>
+__device__ __forceinline__ void wave_sort_any(OrdT *bin, int n, int lane)
+{
+    if (n <= 64) wave_sort_bin<1>(bin, n, lane);
+    else if (n <= 128) wave_sort_bin<2>(bin, n, lane);
+    else if (n <= 256) wave_sort_bin<4>(bin, n, lane);
+    else if (n <= 512) wave_sort_bin<8>(bin, n, lane);
+    else wave_sort_bin<16>(bin, n, lane);
+}
+
 template <typename OrdT, bool IN_LDS>
 __global__ __launch_bounds__(CSR_BLOCK) void csr_transpose_kernel(const int64_t *__restrict__ idx, int L, int nbins,
                                                                    int div, const float *__restrict__ weight,
@@ -138,7 +148,7 @@ __global__ __launch_bounds__(CSR_BLOCK) void csr_transpose_kernel(const int64_t 
     // (in-lane exchanges for strides >= 64, wave shuffles below).
     for (int k = k_lo + tid; k < k_hi; k += CSR_BLOCK) {
         const int lo = k == k_lo ? j_lo : cnt[k - 1], hi = cnt[k];
-        if (hi - lo > CSR_SMALL_BIN && hi - lo <= 64 * CSR_RANK_SLOTS) continue;  // ranked by a wave below
+        if (hi - lo > CSR_SMALL_BIN) continue;  // sorted by a wave below
         for (int a = lo + 1; a < hi; ++a) {
             OrdT v = ord[a];
             int p = a;
@@ -158,16 +168,31 @@ __global__ __launch_bounds__(CSR_BLOCK) void csr_transpose_kernel(const int64_t 
                 lo = k == k_lo ? j_lo : cnt[k - 1];
                 hi = cnt[k];
             }
-            unsigned long long big = __ballot(hi - lo > CSR_SMALL_BIN && hi - lo <= 64 * CSR_RANK_SLOTS);
+            unsigned long long big = __ballot(hi - lo > CSR_SMALL_BIN);
             while (big) {
                 const int l = __builtin_ctzll(big);
                 big &= big - 1;
-                const int blo = __builtin_amdgcn_readlane(lo, l), n = __builtin_amdgcn_readlane(hi, l) - blo;
-                if (n <= 64) wave_sort_bin<1>(ord + blo, n, lane);
-                else if (n <= 128) wave_sort_bin<2>(ord + blo, n, lane);
-                else if (n <= 256) wave_sort_bin<4>(ord + blo, n, lane);
-                else if (n <= 512) wave_sort_bin<8>(ord + blo, n, lane);
-                else wave_sort_bin<16>(ord + blo, n, lane);
+                const int blo = __builtin_amdgcn_readlane(lo, l), bhi = __builtin_amdgcn_readlane(hi, l);
+                if (bhi - blo <= 64 * CSR_RANK_SLOTS) {
+                    wave_sort_any(ord + blo, bhi - blo, lane);
+                    continue;
+                }
+                // A bin of more than 1024 slots (the first hit of many padded dense-ball queries): the fill pass above
+                // walked the slots one 1024-slot window at a time with a barrier in between, so the bin is a sequence
+                // of per-window segments that are already in window order -- sorting each segment (<= 1024 slots, found
+                // by bisection on slot / 1024) sorts the bin.  One thread's insertion sort took 2.5 ms here.
+                int a = blo;
+                while (a < bhi) {
+                    const int w = (int)ord[a] / CSR_BLOCK;
+                    int x = a + 1, y = bhi;  // first position in (a, bhi] whose window differs
+                    while (x < y) {
+                        const int mid = (x + y) >> 1;
+                        if ((int)ord[mid] / CSR_BLOCK == w) x = mid + 1;
+                        else y = mid;
+                    }
+                    if (x - a > 1) wave_sort_any(ord + a, x - a, lane);
+                    a = x;
+                }
             }
         }
     }
