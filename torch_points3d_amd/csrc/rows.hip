@@ -10,6 +10,8 @@
 // HBM-bound: each kernel reads and writes every activation byte at most once per pass.
 #include <cstdlib>
 
+#include <type_traits>
+
 #include "tp3d_common.h"
 
 namespace tp3d {
@@ -131,34 +133,29 @@ __global__ __launch_bounds__(RW_BLOCK) void rows_gather_sum_kernel(const float *
             const int my_r = (lane < cnt) ? od[j0 + lane] : 0;
             const float my_w = (ws && lane < cnt) ? ws[j0 + lane] : 1.0f;
             int t = 0;
-            for (; t + 4 <= cnt; t += 4) {
-                const int r0 = __builtin_amdgcn_readlane(my_r, t), r1 = __builtin_amdgcn_readlane(my_r, t + 1);
-                const int r2 = __builtin_amdgcn_readlane(my_r, t + 2), r3 = __builtin_amdgcn_readlane(my_r, t + 3);
-                float v0[NP], v1[NP], v2[NP], v3[NP];
+            // U rows per step, all their loads issued before the first add (a destination that collects thousands of
+            // slots -- the shared first hit of padded ball queries -- is one wave's serial walk: latency per step counts)
+            auto take = [&](auto utag) {
+                constexpr int U = decltype(utag)::value;
+                int r[U];
+                float wv[U], v[U][NP];
 #pragma unroll
-                for (int p = 0; p < NP; ++p) {
-                    v0[p] = base[(size_t)r0 * ld + c[p]];
-                    v1[p] = base[(size_t)r1 * ld + c[p]];
-                    v2[p] = base[(size_t)r2 * ld + c[p]];
-                    v3[p] = base[(size_t)r3 * ld + c[p]];
+                for (int u = 0; u < U; ++u) {
+                    r[u] = __builtin_amdgcn_readlane(my_r, t + u);
+                    wv[u] = ws ? rl_f(my_w, t + u) : 1.0f;
                 }
-                if (ws) {
-                    const float w0 = rl_f(my_w, t), w1 = rl_f(my_w, t + 1), w2 = rl_f(my_w, t + 2), w3 = rl_f(my_w, t + 3);
 #pragma unroll
-                    for (int p = 0; p < NP; ++p) {
-                        acc[p] = acc[p] + w0 * v0[p];
-                        acc[p] = acc[p] + w1 * v1[p];
-                        acc[p] = acc[p] + w2 * v2[p];
-                        acc[p] = acc[p] + w3 * v3[p];
-                    }
-                } else {
+                for (int u = 0; u < U; ++u)
 #pragma unroll
-                    for (int p = 0; p < NP; ++p) {
-                        acc[p] = ((acc[p] + v0[p]) + v1[p]) + v2[p];
-                        acc[p] = acc[p] + v3[p];
-                    }
-                }
-            }
+                    for (int p = 0; p < NP; ++p) v[u][p] = base[(size_t)r[u] * ld + c[p]];
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+#pragma unroll
+                    for (int p = 0; p < NP; ++p) acc[p] = acc[p] + (ws ? wv[u] * v[u][p] : v[u][p]);  // slot order
+                t += U;
+            };
+            while (t + 8 <= cnt) take(std::integral_constant<int, 8>());
+            if (t + 4 <= cnt) take(std::integral_constant<int, 4>());
             // tail of 1..3 rows (most runs of a grouping table are that short): requested together, summed in order
             const int rem = cnt - t;
             if (rem > 0) {
