@@ -199,11 +199,6 @@ def test_grouping_bwd_giant_bins(hip, oracle, npnt, ns, N):
     hip.grouping_operation(fa, idx.to(DEV)).backward(cot.to(DEV))
     oracle.grouping_operation(fb, idx).backward(cot)
     assert torch.equal(fa.grad.cpu(), fb.grad)
-    if npnt * ns > 65536:
-        # tables that do not fit LDS take the flat device-wide inversion on the rows path, whose arrival order is
-        # arbitrary: a bin of > 1024 slots is insertion-sorted by one thread there (correct, but tens of seconds for
-        # this synthetic 52 800-slot bin; DESIGN.md section 8 lists it as open)
-        return
     # the channel-last rows path (fused set abstraction) goes through the same tables
     from torch_points3d_amd import fused
     pos = torch.rand(B, N, 3, generator=g).to(DEV)

@@ -361,6 +361,8 @@ ScatterWorkspace carve_scatter_workspace(void *ws, int B, int L, int nbins, bool
         w.wsorted = reinterpret_cast<float *>(p + off);
         off += up((size_t)B * L * 4);
     }
+    w.merge_tmp = reinterpret_cast<int *>(p + off);
+    off += up((size_t)B * L * 4);
     w.bytes = off;
     return w;
 }

@@ -273,7 +273,47 @@ __global__ void nbr_fill_kernel(const int64_t *__restrict__ nbr, int64_t slots, 
 // hundreds of slots reference (padded tails of dense ball queries) would otherwise be hundreds of dependent global
 // round trips in one thread
 constexpr int NBR_SMALL_BIN = 24;
-__global__ __launch_bounds__(256) void nbr_sort_kernel(const int *__restrict__ start, int64_t M, int *__restrict__ order)
+// A bin of more than 1024 slots, sorted by one wave: 1024-slot runs through the bitonic network, then log2(runs) merge
+// passes between `order` and `tmp` -- every lane merges an equal share of a run pair, its split found by bisection
+// (merge path).  Slot ids are unique, so the result is the ascending order whatever the arrival order was.
+// (one thread's insertion sort needed tens of seconds for a 52 800-slot bin)
+__device__ void wave_merge_sort_bin(int *order, int *tmp, int n, int lane)
+{
+    for (int a = 0; a < n; a += 1024) wave_sort_bin<16>(order + a, min(1024, n - a), lane);
+    int *src = order, *dst = tmp;
+    for (int width = 1024; width < n; width <<= 1) {
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        for (int lo = 0; lo < n; lo += 2 * width) {
+            const int mid = min(lo + width, n), hi = min(lo + 2 * width, n);
+            const int *A = src + lo, *B = src + mid;
+            const int na = mid - lo, nb = hi - mid, total = hi - lo;
+            const int per = (total + 63) / 64;
+            const int o0 = min(lane * per, total), o1 = min(o0 + per, total);
+            // i = how many of the first o0 outputs come from A: smallest i with A[i] > B[o0 - i - 1]
+            int x = max(0, o0 - nb), y = min(o0, na);
+            while (x < y) {
+                const int i = (x + y) >> 1, j = o0 - i;
+                if (j > 0 && A[i] < B[j - 1]) x = i + 1;
+                else y = i;
+            }
+            int i = x, j = o0 - x;
+            for (int o = o0; o < o1; ++o) {
+                const bool from_a = j >= nb || (i < na && A[i] < B[j]);
+                dst[lo + o] = from_a ? A[i++] : B[j++];
+            }
+        }
+        int *t = src;
+        src = dst;
+        dst = t;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    if (src != order)
+        for (int e = lane; e < n; e += 64) order[e] = src[e];
+}
+
+__global__ __launch_bounds__(256) void nbr_sort_kernel(const int *__restrict__ start, int64_t M, int *order, int *tmp)
 {
     const int lane = threadIdx.x & 63;
     const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -283,7 +323,7 @@ __global__ __launch_bounds__(256) void nbr_sort_kernel(const int *__restrict__ s
         s1 = start[m + 1];
     }
     const int n = s1 - s0;
-    if (n <= NBR_SMALL_BIN || n > 1024) {
+    if (n <= NBR_SMALL_BIN || (n > 1024 && !tmp)) {
         for (int a = s0 + 1; a < s1; ++a) {
             const int v = order[a];
             int p = a;
@@ -305,13 +345,22 @@ __global__ __launch_bounds__(256) void nbr_sort_kernel(const int *__restrict__ s
         else if (bn <= 512) wave_sort_bin<8>(order + blo, bn, lane);
         else wave_sort_bin<16>(order + blo, bn, lane);
     }
+    if (tmp) {
+        unsigned long long giant = __ballot(n > 1024);
+        while (giant) {  // wave-uniform
+            const int l = __builtin_ctzll(giant);
+            giant &= giant - 1;
+            const int blo = __builtin_amdgcn_readlane(s0, l), bn = __builtin_amdgcn_readlane(n, l);
+            wave_merge_sort_bin(order + blo, tmp + blo, bn, lane);
+        }
+    }
 }
 
 // Inverse of an index table over any number of workgroups: for every bin m the slots that reference it, ascending
 // (integer histogram -> scan -> fill -> per-bin insertion sort of its short run).  Entries outside [0, M) are skipped.
 // cnt, cursor: M ints; start: M + 1 ints; order: `slots` ints.
 int invert_table(const int64_t *idx, int64_t slots, int64_t M, int *cnt, int *start, int *cursor, int *order,
-                 hipStream_t s, int64_t per_cloud_slots, int64_t per_cloud_bins)
+                 hipStream_t s, int64_t per_cloud_slots, int64_t per_cloud_bins, int *merge_tmp)
 {
     if (int rc = zero_async(cnt, (size_t)M * 4, s)) return rc;
     const unsigned gs = (unsigned)std::min<int64_t>((slots + 255) / 256, 4096);
@@ -319,7 +368,7 @@ int invert_table(const int64_t *idx, int64_t slots, int64_t M, int *cnt, int *st
     hipLaunchKernelGGL(nbr_scan_kernel, dim3(1), dim3(1024), 0, s, cnt, M, start, cursor);
     hipLaunchKernelGGL(nbr_fill_kernel, dim3(gs), dim3(256), 0, s, idx, slots, M, cursor, order, per_cloud_slots,
                        per_cloud_bins);
-    hipLaunchKernelGGL(nbr_sort_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, s, start, M, order);
+    hipLaunchKernelGGL(nbr_sort_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, s, start, M, order, merge_tmp);
     return check_launch();
 }
 

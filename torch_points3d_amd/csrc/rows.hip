@@ -768,7 +768,8 @@ TP3D_EXPORT int tp3d_rows_scatter_bwd_f32(const float *grad_rows, const int64_t 
                       ((B == 1 && L >= 16384) || !csr_fits_lds(L, nbins) || L >= flat_min_l);
     if (flat) {
         const int64_t slots = (int64_t)B * L, bins = (int64_t)B * nbins;
-        if (int rc = invert_table(idx, slots, bins, w.scratch, w.start, w.scratch + bins, w.order, s, L, nbins)) return rc;
+        if (int rc = invert_table(idx, slots, bins, w.scratch, w.start, w.scratch + bins, w.order, s, L, nbins, w.merge_tmp))
+            return rc;
         hipLaunchKernelGGL(slots_to_rows_kernel, dim3((unsigned)((slots + 255) / 256)), dim3(256), 0, s, w.order, weight, div,
                            (int)slots, w.start, (int)bins, w.wsorted);
     } else if (int rc = csr_transpose(idx, B, L, nbins, div, weight, w.start, w.order, w.wsorted, w.scratch, s)) {

@@ -63,6 +63,7 @@ struct ScatterWorkspace {
     int *order;      // B*L
     int *scratch;    // B*L (only touched when a cloud's tables do not fit LDS)
     float *wsorted;  // B*L or null
+    int *merge_tmp;  // B*L: second buffer of the run merge that sorts bins of more than 1024 slots (flat inversion)
     size_t bytes;
 };
 ScatterWorkspace carve_scatter_workspace(void *ws, int B, int L, int nbins, bool with_weights);
@@ -75,7 +76,7 @@ int gather_sum(const float *rows, const int *start, const int *order, const floa
 // per_cloud_slots > 0: idx is (clouds, per_cloud_slots) with values clamped to [0, per_cloud_bins); bin = cloud *
 // per_cloud_bins + value, M = clouds * per_cloud_bins (one flat table over the batch).
 int invert_table(const int64_t *idx, int64_t slots, int64_t M, int *cnt, int *start, int *cursor, int *order,
-                 hipStream_t s, int64_t per_cloud_slots = 0, int64_t per_cloud_bins = 0);
+                 hipStream_t s, int64_t per_cloud_slots = 0, int64_t per_cloud_bins = 0, int *merge_tmp = nullptr);
 // csr.hip: does the one-workgroup-per-cloud transpose fit LDS?
 bool csr_fits_lds(int L, int nbins);
 
