@@ -214,7 +214,7 @@ def test_sharded_step_same_trajectory():
 
 @pytest.mark.parametrize("M,N,K", [(1000, 64, 8), (4096, 128, 132), (70000, 128, 128), (33, 8, 4), (20000, 256, 260),
                                    (5000, 1024, 512), (262144, 128, 64), (129, 132, 68), (4096, 256, 1280),
-                                   (140000, 256, 64), (50000, 384, 32)])
+                                   (140000, 256, 64), (50000, 384, 32), (130100, 128, 8)])
 def test_gemm_rows_matches_fp64_and_stats(M, N, K):
     """fp32 MFMA rows GEMM (forward / input-gradient contraction) + fused BatchNorm statistics epilogue"""
     from torch_points3d_amd import fused
@@ -229,6 +229,7 @@ def test_gemm_rows_matches_fp64_and_stats(M, N, K):
     from torch_points3d_amd import _lib
     chunks = _lib.load().tp3d_gemm_rows_stat_chunks(M, N)  # one row per 128-row block, or per persistent workgroup
     assert chunks == (M + 127) // 128 or chunks == 1024 // ((N + 127) // 128)
+    assert part.numel() >= chunks * 2 * N * 4
     p = part[: chunks * 2 * N * 4].view(torch.float32).view(chunks, 2, N)
     torch.testing.assert_close(p[:, 0].double().sum(0), ref.sum(0), rtol=1e-4, atol=1e-3 * float(ref.abs().max()))
     torch.testing.assert_close(p[:, 1].double().sum(0), (ref * ref).sum(0), rtol=1e-4, atol=1e-2)

@@ -229,11 +229,14 @@ RowsPlan rows_plan(int64_t M, int N)
 }
 }  // namespace
 
-// upper bound of the statistics buffer (one row per 128-row block)
+// size of the statistics buffer: one row per 128-row block, or per persistent workgroup -- whichever is more (the item
+// count is rounded up to groups of 8 row blocks, so 1017..1023 row blocks already fill the 1024-workgroup grid)
 TP3D_EXPORT size_t tp3d_gemm_rows_stat_floats(int64_t M, int N)
 {
     if (M <= 0 || N <= 0) return 0;
-    return (size_t)((M + GR_BM - 1) / GR_BM) * 2 * (size_t)N;
+    const RowsPlan p = rows_plan(M, N);
+    const int64_t rows = p.chunks > p.row_blocks ? p.chunks : p.row_blocks;
+    return (size_t)rows * 2 * (size_t)N;
 }
 
 // number of statistics rows tp3d_gemm_rows_f32 writes for this shape = `chunks` of tp3d_bn_finalize_f32
