@@ -184,6 +184,16 @@ static TnPlan plan_tn(int64_t M, int N, int K)
     }();
     int64_t max_by_rows = (M + min_rows - 1) / min_rows;
     int64_t s = want < max_by_rows ? want : max_by_rows;
+    static const bool fill_small = [] {  // off by default: see DESIGN.md (a full-suite run aborted with it on)
+        const char *e = getenv("TP3D_TN_FILL_SMALL");
+        return e && atoi(e) > 0;
+    }();
+    if (fill_small && s * tiles < 256) {  // few rows and few tiles: shorter splits (>= 64 rows) until every CU has work
+        int64_t s2 = (256 + tiles - 1) / tiles;
+        const int64_t by64 = (M + 63) / 64;
+        if (s2 > by64) s2 = by64;
+        if (s2 > s) s = s2;
+    }
     if (s < 1) s = 1;
     if (s > 512) s = 512;
     p.rows_per_split = ((M + s - 1) / s + TN_BR_MAX - 1) / TN_BR_MAX * TN_BR_MAX;
