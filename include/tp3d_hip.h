@@ -35,7 +35,7 @@ extern "C" {
 #define TP3D_E_UNSORTED (-3) /* reserved: batch vector not sorted (checked by the host wrapper) */
 #define TP3D_E_TOOBIG (-4)   /* size exceeds what the kernel's index arithmetic supports */
 
-#define TP3D_ABI_VERSION 17
+#define TP3D_ABI_VERSION 18
 
 int tp3d_abi_version(void);
 const char *tp3d_strerror(int code);
@@ -308,6 +308,24 @@ int tp3d_nbr_maxpool_fwd_f32(const float *x, const int64_t *neighbors, int64_t N
 int tp3d_nbr_maxpool_bwd_f32(const float *grad_out, const int32_t *argmax, const int64_t *neighbors, int64_t Nq,
                              int64_t M, int Mn, int C, float *d_x, void *inverse, size_t inverse_bytes,
                              int inverse_ready, void *stream);
+
+/* =====================================================================================================
+ * Launch plans (host arithmetic only, no device work): what an entry point WILL do for given sizes -- how it
+ * splits the rows, how many partial rows it writes, how it carves its workspace.  tests/test_plans_cpu.py sweeps
+ * them against the workspace-size queries above, so that "the extent a kernel writes <= the size the caller was
+ * told to allocate" is checked for every shape without a GPU.  All return 0 or TP3D_E_BADARG.
+ * ===================================================================================================== */
+/* plan[8]: splits, rows per split, tile rows (N side), tile columns (K side), tiles, rows staged per step,
+ * workspace floats written, first row of the last split */
+int tp3d_gemm_tn_plan(int64_t M, int N, int K, int64_t *plan);
+/* plan[6]: column tiles, row blocks, work items, workgroups, statistics rows written, 1 = one row per workgroup */
+int tp3d_gemm_rows_plan(int64_t M, int N, int64_t *plan);
+/* plan[3]: rows per chunk, chunks, workspace floats written by tp3d_bn_stats_f32 (pooled_ns = 0) or
+ * tp3d_bn_act_bwd_f32 (pooled_ns = its ns; 1 for the dense form) */
+int tp3d_bn_plan(int64_t M, int C, int pooled_ns, int64_t *plan);
+/* plan[8]: byte offsets of start, order, scratch, wsorted (-1 = none), merge_tmp; workspace bytes; 1 = table
+ * inverted flat over the batch; ints of scratch that path needs */
+int tp3d_scatter_plan(int B, int L, int nbins, int with_weights, int64_t *plan);
 
 #ifdef __cplusplus
 }

@@ -49,3 +49,15 @@ def load_golden(name):
             v = v.astype(np.int64)
         out[k] = torch.from_numpy(v) if v.dtype != np.float64 else v
     return out
+
+
+@pytest.fixture(autouse=True)
+def _guard_bands(request):
+    """TP3D_TEST_CANARY=1: run every GPU test with guard bands around all device buffers, checked after each C-ABI
+    call (tests/canary.py) -- the diagnostic mode for out-of-bounds writes."""
+    if os.environ.get("TP3D_TEST_CANARY") and "gpu" in request.keywords and torch.cuda.is_available():
+        from canary import Canary
+        with Canary():
+            yield
+    else:
+        yield

@@ -93,21 +93,15 @@ def bench_kpconv(reps):
 
 def bench_grid(reps):
     """Radius search on single clouds at KPConv density (one point per 0.02 voxel, r = 0.05, 25 slots): in-LDS grid
-    build (one workgroup per cloud) against the sort-based build (TP3D_GRID_GLOBAL_MIN lowers the switch-over)."""
+    build (one workgroup per cloud, clouds up to 65 536 points) and the sort-based build beyond."""
     import os
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     from bench_kpconv import synthetic_cloud
     for n, clouds in [(8192, 1), (16384, 1), (32768, 1), (65536, 1), (65536, 4), (262144, 16)]:
         pos, batch = synthetic_cloud(n, clouds, 0.02)
         pos, batch = pos.to(DEV), batch.to(DEV)
-        for mode, env in (("lds-build", None), ("sort-build", "1024")):
-            if env is None:
-                os.environ.pop("TP3D_GRID_GLOBAL_MIN", None)
-            else:
-                os.environ["TP3D_GRID_GLOBAL_MIN"] = env
-            t = timeit(lambda: tp.ball_query(0.05, 25, pos, pos, mode="partial_dense", batch_x=batch, batch_y=batch), reps)
-            print("ball_query partial N=%d clouds=%d %-10s %8.1f us" % (n, clouds, mode, t * 1e3))
-        os.environ.pop("TP3D_GRID_GLOBAL_MIN", None)
+        t = timeit(lambda: tp.ball_query(0.05, 25, pos, pos, mode="partial_dense", batch_x=batch, batch_y=batch), reps)
+        print("ball_query partial N=%d clouds=%d %8.1f us" % (n, clouds, t * 1e3))
 
 
 def bench_kpconv_bwd(reps):

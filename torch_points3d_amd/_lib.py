@@ -52,11 +52,16 @@ SIGNATURES = {
     "tp3d_randla_relpos_f32": [_p, _p, _p, _l, _i, _l, _p, _p],
     "tp3d_attn_pool_fwd_f32": [_p, _p, _p, _l, _i, _i, _i, _i, _p, _p],
     "tp3d_attn_pool_bwd_f32": [_p, _p, _p, _p, _l, _i, _i, _i, _i, _p, _p, _p],
+    # launch plans (host arithmetic; the last argument is a HOST int64 array)
+    "tp3d_gemm_tn_plan": [_l, _i, _i, _p],
+    "tp3d_gemm_rows_plan": [_l, _i, _p],
+    "tp3d_bn_plan": [_l, _i, _i, _p],
+    "tp3d_scatter_plan": [_i, _i, _i, _i, _p],
 }
 MISC = ("tp3d_abi_version", "tp3d_strerror", "tp3d_last_hip_error", "tp3d_scatter_workspace_bytes",
         "tp3d_bn_workspace_floats", "tp3d_gemm_tn_workspace_floats", "tp3d_ball_query_workspace_bytes",
         "tp3d_gemm_rows_stat_floats", "tp3d_gemm_rows_stat_chunks", "tp3d_kpconv_bwd_workspace_bytes", "tp3d_voxel_workspace_bytes", "tp3d_knn_workspace_bytes", "tp3d_kpconv_grad_workspace_bytes")
-ABI_VERSION = 17
+ABI_VERSION = 18
 
 _handle = None
 
@@ -144,6 +149,15 @@ def set_timer(timer):
 
 
 _fn_cache = {}
+_post_call_hook = None
+
+
+def set_post_call_hook(hook):
+    """Install (or remove, with None) `hook(name, args)`, run after every C-ABI call: the guard-band checker of
+    tests/canary.py uses it to name the entry point that wrote outside a buffer.  Returns the previous hook."""
+    global _post_call_hook
+    prev, _post_call_hook = _post_call_hook, hook
+    return prev
 
 
 def call(name, *args):
@@ -151,6 +165,14 @@ def call(name, *args):
     fn = _fn_cache.get(name)
     if fn is None:
         fn = _fn_cache[name] = getattr(load(), name)
+    if _post_call_hook is not None:
+        rc = fn(*args)
+        if rc == 0:
+            _post_call_hook(name, args)
+            return
+        h = load()
+        raise Tp3dError("%s failed: %s (code %d, hipError %d)" % (
+            name, h.tp3d_strerror(rc).decode(), rc, h.tp3d_last_hip_error()))
     if _timer is not None:
         a = torch.cuda.Event(enable_timing=True)
         b = torch.cuda.Event(enable_timing=True)

@@ -21,10 +21,10 @@ HIPCC_FLAGS = [
     "-ffp-contract=off",
     "-fno-honor-nans",  # fminf/fmaxf -> bare v_min/v_max (no canonicalising v_max x,x); inputs are finite clouds
     "-fPIC",
-    "-shared",
     "-fvisibility=hidden",
     "-std=c++17",
 ]
+OBJ_DIR = os.path.join(CSRC, "_obj")
 
 
 def _hipcc():
@@ -46,15 +46,51 @@ def is_stale():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def _headers():
+    return glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(ROOT, "include", "*.h"))
+
+
 def build_library(force=False, verbose=False):
-    """Compile every HIP source into torch_points3d_amd/libtp3d_hip.so. Returns the path."""
+    """Compile every HIP source into torch_points3d_amd/libtp3d_hip.so. Returns the path.
+
+    One object file per source (csrc/_obj/, rebuilt only when the source or a header is newer), compiled in
+    parallel, then one link: a one-file change costs one hipcc run instead of the whole library."""
     if not force and not is_stale():
         return LIB_PATH
-    cmd = [_hipcc()] + HIPCC_FLAGS + ["-I" + os.path.join(ROOT, "include"), "-I" + CSRC, "-o", LIB_PATH] + sources()
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    hipcc = _hipcc()
+    inc = ["-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
+    hdr_time = max([os.path.getmtime(h) for h in _headers()] + [os.path.getmtime(os.path.abspath(__file__))])
+    jobs, objs = [], []
+    for src in sources():
+        obj = os.path.join(OBJ_DIR, os.path.basename(src)[:-4] + ".o")
+        objs.append(obj)
+        if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), hdr_time):
+            jobs.append([hipcc] + HIPCC_FLAGS + inc + ["-c", src, "-o", obj])
+    workers = max(1, min(len(jobs), (os.cpu_count() or 2)))
+    running = []
+    failed = None
+    for cmd in jobs:
+        if verbose:
+            print(" ".join(cmd))
+        while len(running) >= workers:
+            failed = _reap(running) or failed
+        running.append((cmd, subprocess.Popen(cmd)))
+    while running:
+        failed = _reap(running) or failed
+    if failed:
+        raise subprocess.CalledProcessError(1, failed)
+    link = [hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB_PATH] + objs
     if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
+        print(" ".join(link))
+    subprocess.check_call(link)
     return LIB_PATH
+
+
+def _reap(running):
+    """Wait for the oldest compile job; returns its command line if it failed."""
+    cmd, proc = running.pop(0)
+    return cmd if proc.wait() != 0 else None
 
 
 if __name__ == "__main__":

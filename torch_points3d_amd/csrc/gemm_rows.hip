@@ -246,6 +246,21 @@ TP3D_EXPORT int tp3d_gemm_rows_stat_chunks(int64_t M, int N)
     return (int)rows_plan(M, N).chunks;
 }
 
+// plan[0..5] = column tiles, row blocks, work items, workgroups launched, statistics rows written (= chunks),
+// 1 when they are one per workgroup (else one per 128-row block)
+TP3D_EXPORT int tp3d_gemm_rows_plan(int64_t M, int N, int64_t *plan)
+{
+    if (M <= 0 || N <= 0 || !plan) return TP3D_E_BADARG;
+    const RowsPlan p = rows_plan(M, N);
+    plan[0] = p.tiles_n;
+    plan[1] = p.row_blocks;
+    plan[2] = p.items;
+    plan[3] = p.blocks;
+    plan[4] = p.chunks;
+    plan[5] = p.per_workgroup ? 1 : 0;
+    return TP3D_OK;
+}
+
 TP3D_EXPORT int tp3d_gemm_rows_f32(const float *A, const float *Bt, int64_t M, int N, int K, float *C,
                                    float *stat_partial, void *stream)
 {

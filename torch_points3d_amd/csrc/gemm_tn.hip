@@ -177,11 +177,7 @@ static TnPlan plan_tn(int64_t M, int N, int K)
     // ~4 workgroups per CU (256 CUs) keep the MFMA pipes fed; at least 256 rows per split, at most 512 splits
     // (every split writes an N x K partial tile that the reduction pass reads back)
     int64_t want = (1024 + tiles - 1) / tiles;
-    static const int min_rows = [] {  // tuning switch (rows per split floor)
-        const char *e = getenv("TP3D_TN_MIN_ROWS");
-        const int v = e ? atoi(e) : 0;
-        return v >= 64 ? v : 256;
-    }();
+    const int min_rows = 256;
     int64_t max_by_rows = (M + min_rows - 1) / min_rows;
     int64_t s = want < max_by_rows ? want : max_by_rows;
     static const bool fill_small = [] {  // off by default: see DESIGN.md (a full-suite run aborted with it on)
@@ -210,6 +206,23 @@ TP3D_EXPORT size_t tp3d_gemm_tn_workspace_floats(int64_t M, int N, int K)
     if (M <= 0 || N <= 0 || K <= 0) return 0;
     const TnPlan p = plan_tn(M, N, K);
     return (size_t)p.splits * (size_t)N * (size_t)K;
+}
+
+// plan[0..7] = splits, rows per split, tile rows (N side), tile columns (K side), tiles, rows staged per step,
+// workspace floats the partial kernel writes, last row a split starts at
+TP3D_EXPORT int tp3d_gemm_tn_plan(int64_t M, int N, int K, int64_t *plan)
+{
+    if (M <= 0 || N <= 0 || K <= 0 || !plan) return TP3D_E_BADARG;
+    const TnPlan p = plan_tn(M, N, K);
+    plan[0] = p.splits;
+    plan[1] = p.rows_per_split;
+    plan[2] = p.tn;
+    plan[3] = p.tk;
+    plan[4] = (int64_t)p.tiles_n * p.tiles_k;
+    plan[5] = (p.wm * p.wn) % 3 == 0 ? 16 : 64 / (p.wm * p.wn);
+    plan[6] = (int64_t)p.splits * N * K;
+    plan[7] = (int64_t)(p.splits - 1) * p.rows_per_split;
+    return TP3D_OK;
 }
 
 TP3D_EXPORT int tp3d_gemm_tn_f32(const float *dY, const float *A, int64_t M, int N, int K, float *out,

@@ -510,16 +510,8 @@ int grid_edge_for(int Lmax)
     return G;
 }
 
-// Clouds larger than this use the sort-based builder (tunable for experiments: TP3D_GRID_GLOBAL_MIN)
-static int grid_global_min_points()
-{
-    const char *e = getenv("TP3D_GRID_GLOBAL_MIN");
-    if (e && *e) {
-        const int v = atoi(e);
-        if (v > 0) return v < GRID_LDS_MAX_POINTS ? v : GRID_LDS_MAX_POINTS;
-    }
-    return GRID_LDS_MAX_POINTS;
-}
+// Clouds larger than this use the sort-based builder
+static int grid_global_min_points() { return GRID_LDS_MAX_POINTS; }
 
 GridPlan grid_plan(int Lmax)
 {

@@ -8,8 +8,6 @@
 //   torch_points3d/modules/pointnet2/dense.py:72-73   max over nsample
 //   torch_points3d/core/base_conv/dense.py:132-144    inverse-distance 3-NN interpolation (+ skip concat :117)
 // HBM-bound: each kernel reads and writes every activation byte at most once per pass.
-#include <cstdlib>
-
 #include <type_traits>
 
 #include "tp3d_common.h"
@@ -742,6 +740,31 @@ __global__ void slots_to_rows_kernel(int *__restrict__ order, const float *__res
 }
 }  // namespace tp3d
 
+namespace tp3d {
+static bool scatter_goes_flat(int B, int L, int nbins)
+{
+    return L >= 2 * nbins && (int64_t)B * L < 0x7fffffff && (int64_t)B * nbins < 0x3fffffff &&
+           ((B == 1 && L >= 16384) || !csr_fits_lds(L, nbins));
+}
+}  // namespace tp3d
+
+// plan[0..7] = byte offsets of start, order, scratch, wsorted (-1 without weights), merge_tmp in the workspace, its
+// size in bytes, 1 when the table is inverted flat over the whole batch, ints of `scratch` that path uses
+TP3D_EXPORT int tp3d_scatter_plan(int B, int L, int nbins, int with_weights, int64_t *plan)
+{
+    if (B <= 0 || L <= 0 || nbins <= 0 || !plan) return TP3D_E_BADARG;
+    const ScatterWorkspace w = carve_scatter_workspace(nullptr, B, L, nbins, with_weights != 0);
+    plan[0] = (char *)w.start - (char *)nullptr;
+    plan[1] = (char *)w.order - (char *)nullptr;
+    plan[2] = (char *)w.scratch - (char *)nullptr;
+    plan[3] = w.wsorted ? (char *)w.wsorted - (char *)nullptr : -1;
+    plan[4] = (char *)w.merge_tmp - (char *)nullptr;
+    plan[5] = (int64_t)w.bytes;
+    plan[6] = scatter_goes_flat(B, L, nbins) ? 1 : 0;
+    plan[7] = plan[6] ? 2 * (int64_t)B * nbins : 0;  // invert_table: histogram + cursors
+    return TP3D_OK;
+}
+
 TP3D_EXPORT int tp3d_rows_scatter_bwd_f32(const float *grad_rows, const int64_t *idx, const float *weight, int B,
                                           int L, int div, int nbins, int ld, int col0, int C, float *grad_x_cl,
                                           void *workspace, size_t workspace_bytes, void *stream)
@@ -759,13 +782,7 @@ TP3D_EXPORT int tp3d_rows_scatter_bwd_f32(const float *grad_rows, const int64_t 
     // grouping: 512 x 128 slots per cloud): invert ONE flat table over the whole device instead of one table per
     // workgroup (scratch holds the histogram and the cursors), then turn slot ids into row ids and line the weights up.
     // (measured on the 49 152-slot decoder tables, which fit LDS: flat 523 us vs per-cloud 354 us, so off by default)
-    static const int flat_min_l = [] {  // tuning switch: tables of at least this many slots per cloud go flat too
-        const char *e = getenv("TP3D_SCATTER_FLAT_MIN_L");
-        const int v = e ? atoi(e) : 0;
-        return v > 0 ? v : 0x7fffffff;
-    }();
-    const bool flat = L >= 2 * nbins && (int64_t)B * L < 0x7fffffff && (int64_t)B * nbins < 0x3fffffff &&
-                      ((B == 1 && L >= 16384) || !csr_fits_lds(L, nbins) || L >= flat_min_l);
+    const bool flat = scatter_goes_flat(B, L, nbins);
     if (flat) {
         const int64_t slots = (int64_t)B * L, bins = (int64_t)B * nbins;
         if (int rc = invert_table(idx, slots, bins, w.scratch, w.start, w.scratch + bins, w.order, s, L, nbins, w.merge_tmp))
@@ -795,6 +812,19 @@ TP3D_EXPORT size_t tp3d_bn_workspace_floats(int64_t M, int C)
     int64_t chunks = M >= ST_SMALL_BELOW ? (M + ST_ROWS - 1) / ST_ROWS : (M + ST_ROWS_SMALL - 1) / ST_ROWS_SMALL;
     if (M >= ST_SMALL_BELOW && chunks < ST_SMALL_BELOW / ST_ROWS_SMALL) chunks = ST_SMALL_BELOW / ST_ROWS_SMALL;
     return (size_t)chunks * 2 * (size_t)C;
+}
+
+// plan[0..2] = rows per chunk, chunks, workspace floats written, for the reduction tp3d_bn_stats_f32 (pooled_ns = 0)
+// or tp3d_bn_act_bwd_f32 (pooled_ns = ns of its argmax form, else 1) runs over an (M, C) matrix
+TP3D_EXPORT int tp3d_bn_plan(int64_t M, int C, int pooled_ns, int64_t *plan)
+{
+    if (M <= 0 || C <= 0 || pooled_ns < 0 || !plan) return TP3D_E_BADARG;
+    const int64_t R = pooled_ns > 1 ? M / pooled_ns : M;
+    const int crow = stat_rows(R);
+    plan[0] = crow;
+    plan[1] = (R + crow - 1) / crow;
+    plan[2] = plan[1] * 2 * C;
+    return TP3D_OK;
 }
 
 TP3D_EXPORT int tp3d_bn_stats_f32(const float *Y, int64_t M, int C, float eps, float momentum, const float *gamma,
