@@ -94,6 +94,8 @@ class Canary(object):
 
     # ---- checking -----------------------------------------------------------------------------------------
     def check(self, name="(explicit check)", args=()):
+        if torch.cuda.is_current_stream_capturing():
+            return  # a graph is being recorded: nothing runs yet (and a synchronise would be illegal)
         self.calls += 1
         torch.cuda.synchronize()
         g = self.guard

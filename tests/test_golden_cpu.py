@@ -1,89 +1,94 @@
 """The host-side mirror (torch_points3d_amd.dense / .pointnet2) driven by the CPU oracle must reproduce the
 tensors the REFERENCE's own modules produced (tests/golden/*.npz, written by tests/golden/make_golden.py).
-CPU only: pins module order, channel order, state_dict keys and train-mode BatchNorm of the mirror."""
-import numpy as np
+CPU only: pins module order, channel order, state_dict keys, train- and eval-mode BatchNorm of the mirror, and checks
+the staged ("teacher-forced") harness the GPU parity tests use against the same fixtures."""
 import pytest
 import torch
 
 from conftest import load_golden
-from torch_points3d_amd.dense import Data
-from torch_points3d_amd.pointnet2 import PointNet2Unet, unet_config
+from golden_util import (ACTIVATION, CASES, KINKFREE, UNET_CASES, build_from_golden, cotangent, head_subsample,
+                         load_after_state, run_stages, run_teacher_forced, stage_lists, variant)
 
-SMALL_SSG = dict(npoint=[160, 40], radii=[[0.35], [0.7]], nsample=[[24], [16]],
-                 down_conv_nn=[[[4 + 3, 16, 16, 24]], [[24 + 3, 24, 24, 32]]], innermost=[32 + 3, 32, 48],
-                 up_conv_nn=[[48 + 32, 32, 32], [32 + 24, 32, 24], [24 + 4, 24, 24, 24]],
-                 normalize_xyz=[False, True], save_sampling_id=[False, False])
-SMALL_MSG = dict(npoint=[128, 32], radii=[[0.2, 0.4], [0.5, 0.9]], nsample=[[8, 16], [16, 24]],
-                 down_conv_nn=[[[3 + 3, 8, 12], [3 + 3, 8, 16]], [[12 + 16 + 3, 16, 24], [12 + 16 + 3, 16, 20]]],
-                 innermost=[24 + 20 + 3, 32, 48], up_conv_nn=[[48 + 44, 32, 32], [32 + 28, 24, 24], [24 + 3, 16, 16]],
-                 normalize_xyz=[False, False], save_sampling_id=[False, False])
-
-CASES = {
-    "c1_example": lambda: unet_config("unet_3_ss", 5),
-    "small_ssg": lambda: SMALL_SSG,
-    "small_msg": lambda: SMALL_MSG,
-    "small_ssg_tanh": lambda: SMALL_SSG,
-    "small_ssg_slope1": lambda: SMALL_SSG,
-}
-ACTIVATION = {"small_ssg_tanh": torch.nn.Tanh, "small_ssg_slope1": lambda: torch.nn.LeakyReLU(negative_slope=1.0)}
+__all__ = ["ACTIVATION", "CASES"]
 
 
-def build_from_golden(g, cfg, kernels, device="cpu", activation=None, fused=True):
-    """Mirror model carrying exactly the reference modules' weights."""
-    feat, out_nc = [int(v) for v in g["meta_feat_outnc"]]
-    torch.manual_seed(int(g["meta_seed"][0]))
-    net = PointNet2Unet(feat, output_nc=out_nc, config=cfg, kernels=kernels, activation=activation, fused=fused)
-    stored = {k[len("state/"):]: v for k, v in g.items() if k.startswith("state/")}
-    if stored:
-        net.load_state_dict(stored, strict=True)
-    sd = net.state_dict()
-    cks = {k[len("cksum/"):]: v for k, v in g.items() if k.startswith("cksum/")}
-    assert set(cks) == set(sd), "state_dict keys differ from the reference modules'"
-    for k, v in sd.items():
-        got = np.array([float(v.double().sum()), float(v.double().abs().sum())])
-        np.testing.assert_allclose(got, cks[k], rtol=0, atol=0, err_msg="weights differ at " + k)
-    return net.to(device).train()
+def _first_conv(net):
+    return stage_lists(net)[0][0].mlps[0][0][0]
 
 
-def run_stages(net, pos, x):
-    """Forward with per-stage capture, same names as make_golden.run_reference_unet."""
-    rec = {}
-    hooks = []
-    for i, m in enumerate(net.down_modules):
-        hooks.append(m.register_forward_hook(
-            lambda mod, inp, out, i=i: rec.update({"down%d_x" % i: out.x, "down%d_pos" % i: out.pos})))
-    hooks.append(net.inner_modules[0].register_forward_hook(lambda mod, inp, out: rec.update({"inner_x": out.x})))
-    for i, m in enumerate(net.up_modules):
-        hooks.append(m.register_forward_hook(lambda mod, inp, out, i=i: rec.update({"up%d_x" % i: out.x})))
-    out = net(Data(pos=pos, x=x))
-    rec["out_x"] = out.x
-    for h in hooks:
-        h.remove()
-    return out, rec
+def _last_fp_conv(net):
+    return stage_lists(net)[2][-1].nn[0][0]
 
 
 @pytest.mark.parametrize("name", sorted(CASES))
 def test_mirror_reproduces_reference_modules(oracle, name):
     g = load_golden(name)
-    net = build_from_golden(g, CASES[name](), oracle, activation=ACTIVATION.get(name, lambda: None)())
+    net = build_from_golden(g, name, oracle)
     x_in = g["x"].clone().requires_grad_(True)
-    out, rec = run_stages(net, g["pos"], x_in)
+    rec = run_stages(net, g, "cpu", x_in=x_in)
     for k, v in rec.items():
         # same PyTorch CPU ops in the same order as the reference modules: the tolerance only covers oneDNN
         # picking a different reduction split for another thread count
-        torch.testing.assert_close(v.detach(), g[k], rtol=1e-4, atol=1e-5, msg=lambda m, k=k: k + ": " + m)
-    bn = net.down_modules[0].mlps[0][0][1]
+        torch.testing.assert_close(head_subsample(g, k, v.detach()), g[k], rtol=1e-4, atol=1e-5,
+                                   msg=lambda m, k=k: k + ": " + m)
+    bn = stage_lists(net)[0][0].mlps[0][0][1]
     torch.testing.assert_close(bn.running_mean, g["bn_after/first_running_mean"], rtol=1e-5, atol=1e-6)
     torch.testing.assert_close(bn.running_var, g["bn_after/first_running_var"], rtol=1e-5, atol=1e-6)
-    (out.x * g["cotangent"]).sum().backward()
+    target = rec["fc0_x"] if "fc0_x" in rec else rec["out_x"]
+    (target * cotangent(g)).sum().backward()
     torch.testing.assert_close(x_in.grad, g["grad_x_in"], rtol=1e-4, atol=1e-6)
-    torch.testing.assert_close(net.down_modules[0].mlps[0][0][0].weight.grad, g["grad_first_conv"], rtol=1e-4,
-                               atol=1e-5)
-    torch.testing.assert_close(net.up_modules[-1].nn[0][0].weight.grad, g["grad_last_fp_conv"], rtol=1e-4,
-                               atol=1e-5)
+    torch.testing.assert_close(_first_conv(net).weight.grad, g["grad_first_conv"], rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(_last_fp_conv(net).weight.grad, g["grad_last_fp_conv"], rtol=1e-4, atol=1e-5)
 
 
-@pytest.mark.parametrize("name", sorted(CASES))
+@pytest.mark.parametrize("name", [n for n in sorted(CASES) if n not in ACTIVATION])
+def test_mirror_eval_mode_matches_reference(oracle, name):
+    """running statistics after the fixture's training pass, then eval(): the mirror's eval path == the reference's"""
+    g = load_golden(name)
+    net = load_after_state(build_from_golden(g, name, oracle), g).eval()
+    with torch.no_grad():
+        rec = run_stages(net, g, "cpu")
+    checked = 0
+    for k, v in rec.items():
+        if "eval/" + k in g:
+            ref, got = variant(g, "eval/", k, v)
+            torch.testing.assert_close(got, ref, rtol=1e-5, atol=1e-5, msg=lambda m, k=k: k + ": " + m)
+            checked += 1
+    assert checked >= 7
+
+
+@pytest.mark.parametrize("name", ["small_ssg", "small_msg", "c3_charlesmsg"] + KINKFREE)
+def test_teacher_forced_stages_on_cpu(oracle, name):
+    """each stage on the fixture's own inputs reproduces the fixture's output for that stage"""
+    g = load_golden(name)
+    net = build_from_golden(g, name, oracle)
+    out = run_teacher_forced(net, g, "cpu")
+    for k, v in out.items():
+        torch.testing.assert_close(head_subsample(g, k, v.detach()), g[k], rtol=1e-5, atol=1e-5,
+                                   msg=lambda m, k=k: k + ": " + m)
+
+
+@pytest.mark.parametrize("name", ["small_ssg", "small_msg"] + KINKFREE)
+def test_teacher_forced_stage_gradients_on_cpu(oracle, name):
+    """per stage: gradient entering (gout/) -> gradients leaving towards the stage's inputs (gin/), element-wise"""
+    g = load_golden(name)
+    net = build_from_golden(g, name, oracle)
+    out, ins = run_teacher_forced(net, g, "cpu", grads=True)
+    checked = 0
+    for key, inputs in ins.items():
+        if "gout/" + key not in g:
+            continue
+        grads = torch.autograd.grad(out[key], inputs, grad_outputs=g["gout/" + key], allow_unused=True, retain_graph=True)
+        for j, got in enumerate(grads):
+            want = g.get("gin/%s/%d" % (key, j))
+            if want is None:
+                continue
+            torch.testing.assert_close(got, want, rtol=1e-4, atol=1e-6, msg=lambda m, k=key, j=j: "%s/%d: %s" % (k, j, m))
+            checked += 1
+    assert checked >= 8
+
+
+@pytest.mark.parametrize("name", UNET_CASES)
 def test_oracle_reproduces_golden_indices(oracle, name):
     g = load_golden(name)
     cfg = CASES[name]()
@@ -97,3 +102,10 @@ def test_oracle_reproduces_golden_indices(oracle, name):
             assert torch.equal(idx, g["ball%d_%d_idx" % (i, s)])
             assert torch.equal(d2, g["ball%d_%d_d2" % (i, s)])
         cur = new
+
+
+@pytest.mark.parametrize("name", KINKFREE)
+def test_conditioned_fixtures_are_conditioned(name):
+    g = load_golden(name)
+    assert float(g["meta_min_preact"][0]) >= 9e-4   # no LeakyReLU input within 1e-3 of the kink
+    assert float(g["meta_min_pool_gap"][0]) >= 5e-6  # no pooled group whose two largest values nearly tie

@@ -222,16 +222,25 @@ def test_strided_and_int32_inputs_are_normalised(hip, oracle):
 
 
 # ------------------------------------------------------- goldens written by the reference's modules
+# BASELINE.json north_star: "fp32 features within 1e-5".  What is asserted, and why in this form:
+#   * every stage on the fixture's own inputs (teacher forcing), train-mode BatchNorm:      |GPU - golden| <= 1e-5 + 1e-5 |golden|
+#   * the whole network in eval mode (running statistics), stage outputs:                    same bound
+#   * the whole network in train mode, stage outputs, against the fp64 evaluation of the pass: |GPU - fp64| <= 2 |golden - fp64|
+#     (max norm per stage): the error a stack of train-mode BatchNorms amplifies is MEASURED against what the reference's
+#     own CPU pass loses, not argued
+#   * gradients: element-wise on the fixtures whose forward pass stays >= 1e-3 away from every LeakyReLU kink and
+#     clear of every arg-max switch (tests/golden/make_golden.py: move_off_the_kink); on the others a flipped mask makes an
+#     element-wise comparison of two correct fp32 implementations ill-posed, so only their L2 error is bounded.
 
-GOLDEN_CFG = None
+TIGHT = dict(rtol=1e-5, atol=1e-5)
 
 
 def _cases():
-    from test_golden_cpu import CASES
+    from golden_util import CASES
     return CASES
 
 
-@pytest.mark.parametrize("name", ["c1_example", "small_ssg", "small_msg"])
+@pytest.mark.parametrize("name", ["c1_example", "small_ssg", "small_msg", "c3_charlesmsg"])
 def test_kernel_goldens(hip, name):
     g = load_golden(name)
     cfg = _cases()[name]()
@@ -247,44 +256,189 @@ def test_kernel_goldens(hip, name):
         cur = new
 
 
+def _maxerr(a, b):
+    return float((a.double() - b.double()).abs().max())
+
+
+ALL_MODELS = ["c1_example", "small_ssg", "small_msg", "small_ssg_tanh", "small_ssg_slope1", "small_ssg_kinkfree",
+              "small_msg_kinkfree", "c3_charlesmsg"]
+WITH_VARIANTS = ["c1_example", "small_ssg", "small_msg", "small_ssg_kinkfree", "small_msg_kinkfree", "c3_charlesmsg"]
+
+
 @pytest.mark.parametrize("fused", [True, False])
-@pytest.mark.parametrize("name", ["c1_example", "small_ssg", "small_msg", "small_ssg_tanh", "small_ssg_slope1"])
-def test_model_goldens_on_gpu(hip, name, fused):
-    """BASELINE config 1 end to end: the mirror on HIP kernels vs the reference modules' recorded tensors.
-    fused=True: channel-last HIP kernels for the grouped-MLP aggregation; fused=False: the reference's
-    (B,C,np,ns) PyTorch graph around the HIP spatial kernels."""
-    from test_golden_cpu import ACTIVATION, build_from_golden, run_stages
+@pytest.mark.parametrize("name", ALL_MODELS)
+def test_model_goldens_teacher_forced(hip, name, fused):
+    """Every stage of the network (set abstraction x2, global module, feature propagation x3, head) on the HIP path,
+    fed the REFERENCE's tensors for that stage's inputs, train-mode BatchNorm: features within 1e-5.
+    fused=True: channel-last HIP kernels for the grouped-MLP aggregation; fused=False: the reference's (B,C,np,ns)
+    PyTorch graph around the HIP spatial kernels."""
+    from golden_util import build_from_golden, head_subsample, report, run_teacher_forced
     g = load_golden(name)
-    net = build_from_golden(g, _cases()[name](), None, device=DEV,  # kernels=None -> the HIP product path
-                            activation=ACTIVATION.get(name, lambda: None)(), fused=fused)
-    x_in = g["x"].to(DEV).requires_grad_(True)
-    out, rec = run_stages(net, g["pos"].to(DEV), x_in)
-    for k, v in rec.items():
-        # The kernel outputs feeding these tensors are exact (tests above); what differs from the CPU golden is
-        # the fp32 summation order of the 1x1-conv GEMMs (rocBLAS/MIOpen vs oneDNN, K up to 1280) amplified by
-        # train-mode BatchNorm, so the bound is relative to the tensor's scale rather than 1e-5 absolute.
-        scale = max(1.0, float(g[k].abs().max()))
-        torch.testing.assert_close(v.detach().cpu(), g[k], rtol=1e-4, atol=1e-4 * scale,
-                                   msg=lambda m, k=k: k + ": " + m)
-    bn = net.down_modules[0].mlps[0][0][1]
-    torch.testing.assert_close(bn.running_mean.cpu(), g["bn_after/first_running_mean"], rtol=1e-4, atol=1e-5)
-    torch.testing.assert_close(bn.running_var.cpu(), g["bn_after/first_running_var"], rtol=1e-4, atol=1e-5)
+    net = build_from_golden(g, name, None, device=DEV, fused=fused)  # kernels=None -> the HIP product path
+    out = run_teacher_forced(net, g, DEV)
+    worst = {}
+    for k, v in out.items():
+        got = head_subsample(g, k, v.detach()).cpu()
+        worst[k] = _maxerr(got, g[k])
+        torch.testing.assert_close(got, g[k], msg=lambda m, k=k: k + ": " + m, **TIGHT)
+    report("teacher_forced_max_abs_err", "%s/%s" % (name, "fused" if fused else "reference-graph"), worst)
+    bn = __import__("golden_util").stage_lists(net)[0][0].mlps[0][0][1]
+    torch.testing.assert_close(bn.running_mean.cpu(), g["bn_after/first_running_mean"], rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(bn.running_var.cpu(), g["bn_after/first_running_var"], rtol=1e-5, atol=1e-6)
     assert int(bn.num_batches_tracked) == 1
-    (out.x * g["cotangent"].to(DEV)).sum().backward()
+
+
+@pytest.mark.parametrize("fused", [True, False])
+@pytest.mark.parametrize("name", WITH_VARIANTS)
+def test_model_goldens_eval_mode(hip, name, fused):
+    """The whole network in eval mode (running statistics as the fixture's training pass left them), every stage
+    output within 1e-5 of the reference modules' -- no teacher forcing: errors may accumulate through the stack."""
+    from golden_util import build_from_golden, load_after_state, report, run_stages, variant
+    g = load_golden(name)
+    net = load_after_state(build_from_golden(g, name, None, device=DEV, fused=fused), g).eval()
+    with torch.no_grad():
+        rec = run_stages(net, g, DEV)
+    worst, checked = {}, 0
+    for k, v in rec.items():
+        if "eval/" + k not in g:
+            continue
+        ref, got = variant(g, "eval/", k, v.cpu())
+        worst[k] = _maxerr(got, ref)
+        torch.testing.assert_close(got, ref, msg=lambda m, k=k: k + ": " + m, **TIGHT)
+        checked += 1
+    assert checked >= 7
+    report("eval_mode_max_abs_err", "%s/%s" % (name, "fused" if fused else "reference-graph"), worst)
+
+
+@pytest.mark.parametrize("fused", [True, False])
+@pytest.mark.parametrize("name", WITH_VARIANTS)
+def test_model_goldens_train_mode_fp64_bound(hip, name, fused):
+    """The whole network in train mode, un-forced: per stage, the HIP path's distance to the fp64 evaluation of the
+    same pass is at most twice the distance of the reference's own fp32 CPU pass (the golden) to it."""
+    from golden_util import build_from_golden, report, run_stages, variant
+    g = load_golden(name)
+    net = build_from_golden(g, name, None, device=DEV, fused=fused)
+    rec = run_stages(net, g, DEV)
+    ratios = {}
+    for k, v in rec.items():
+        if "f64/" + k not in g:
+            continue
+        ref64, got = variant(g, "f64/", k, v.detach().cpu())
+        _, gold = variant(g, "f64/", k, _full_golden(g, k, v))
+        ref64 = torch.as_tensor(ref64)
+        e_gpu, e_cpu = _maxerr(got, ref64), _maxerr(gold, ref64)
+        ratios[k] = [e_gpu, e_cpu]
+        assert e_gpu <= 2.0 * e_cpu + 1e-7, "%s: |GPU-fp64| = %.3g vs |golden-fp64| = %.3g" % (k, e_gpu, e_cpu)
+    assert len(ratios) >= 7
+    report("train_mode_err_vs_fp64_[gpu,golden]", "%s/%s" % (name, "fused" if fused else "reference-graph"), ratios)
+
+
+def _full_golden(g, k, like):
+    """the train-mode golden on the full point set (fc0_x of the large fixture is stored on every 4th point: the f64
+    variant was subsampled from the full tensor, so re-expand is impossible -- compare on the common subset)"""
+    return g[k]
+
+
+@pytest.mark.parametrize("fused", [True, False])
+@pytest.mark.parametrize("name", ["small_ssg_kinkfree", "small_msg_kinkfree", "small_ssg_tanh", "small_ssg_slope1"])
+def test_model_gradients_elementwise(hip, name, fused):
+    """Whole-network backward on the fixtures that are clear of LeakyReLU kinks and arg-max switches: the gradient of
+    the input and of every stored parameter, element-wise."""
+    from golden_util import build_from_golden, cotangent, report, run_stages, stage_lists
+    g = load_golden(name)
+    net = build_from_golden(g, name, None, device=DEV, fused=fused)
+    x_in = g["x"].to(DEV).requires_grad_(True)
+    rec = run_stages(net, g, DEV, x_in=x_in)
+    (rec["out_x"] * cotangent(g).to(DEV)).sum().backward()
+    worst = {}
+
+    def check(tag, got, want):
+        scale = max(1.0, float(want.abs().max()))
+        worst[tag] = _maxerr(got, want) / scale
+        torch.testing.assert_close(got, want, rtol=1e-4, atol=2e-5 * scale, msg=lambda m: tag + ": " + m)
+
+    check("grad_x_in", x_in.grad.cpu(), g["grad_x_in"])
+    check("grad_first_conv", stage_lists(net)[0][0].mlps[0][0][0].weight.grad.cpu(), g["grad_first_conv"])
+    check("grad_last_fp_conv", stage_lists(net)[2][-1].nn[0][0].weight.grad.cpu(), g["grad_last_fp_conv"])
+    for k, p in net.named_parameters():
+        if "pgrad/" + k in g:
+            check("pgrad/" + k, p.grad.cpu(), g["pgrad/" + k])
+    report("gradient_max_err_over_scale", "%s/%s" % (name, "fused" if fused else "reference-graph"),
+           {"worst": max(worst.values()), "n": len(worst)})
+
+
+@pytest.mark.parametrize("fused", [True, False])
+@pytest.mark.parametrize("name", ["small_ssg_kinkfree", "small_msg_kinkfree"])
+def test_stage_gradients_teacher_forced(hip, name, fused):
+    """Per stage: the fixture's gradient of the stage output goes in, the gradients towards the stage's inputs come
+    out -- element-wise against what the reference's stage produced on the same tensors."""
+    from golden_util import build_from_golden, run_teacher_forced
+    g = load_golden(name)
+    net = build_from_golden(g, name, None, device=DEV, fused=fused)
+    out, ins = run_teacher_forced(net, g, DEV, grads=True)
+    checked = 0
+    for key, inputs in ins.items():
+        if "gout/" + key not in g:
+            continue
+        grads = torch.autograd.grad(out[key], inputs, grad_outputs=g["gout/" + key].to(DEV), allow_unused=True,
+                                    retain_graph=True)
+        for j, got in enumerate(grads):
+            want = g.get("gin/%s/%d" % (key, j))
+            if want is None:
+                continue
+            scale = max(1.0, float(want.abs().max()))
+            torch.testing.assert_close(got.cpu(), want, rtol=1e-4, atol=2e-5 * scale,
+                                       msg=lambda m, k=key, j=j: "%s/%d: %s" % (k, j, m))
+            checked += 1
+    assert checked >= 8
+
+
+@pytest.mark.parametrize("name", ["c1_example", "small_ssg", "small_msg", "c3_charlesmsg"])
+def test_model_gradients_l2_on_kinked_fixtures(hip, name):
+    """LeakyReLU fixtures with pre-activations down to 1e-8 of the kink (meta_min_preact): one mask flipped by a last-bit
+    GEMM difference moves, through train-mode BatchNorm backward, every gradient of its layer (measured: 1 flip in
+    50 400 activations -> ~1 %), so for these only the relative L2 error is bounded; the element-wise gradient checks
+    run on the conditioned twins of the same networks above."""
+    from golden_util import build_from_golden, cotangent, run_stages, stage_lists
+    g = load_golden(name)
+    net = build_from_golden(g, name, None, device=DEV)
+    x_in = g["x"].to(DEV).requires_grad_(True)
+    rec = run_stages(net, g, DEV, x_in=x_in)
+    target = rec["fc0_x"] if "fc0_x" in rec else rec["out_x"]
+    (target * cotangent(g).to(DEV)).sum().backward()
     ga, gb = x_in.grad.cpu(), g["grad_x_in"]
-    wa, wb = net.up_modules[-1].nn[0][0].weight.grad.cpu(), g["grad_last_fp_conv"]
-    if name in ACTIVATION:  # smooth activation: gradients are well conditioned, compare element-wise
-        torch.testing.assert_close(ga, gb, rtol=1e-3, atol=1e-4 * max(1.0, float(gb.abs().max())))
-        torch.testing.assert_close(wa, wb, rtol=1e-3, atol=1e-4 * max(1.0, float(wb.abs().max())))
-    else:
-        # LeakyReLU: one pre-activation within ~1e-5 of zero flips its 1 / 0.01 slope between the GPU and CPU
-        # GEMMs, and train-mode BatchNorm backward couples that single element to the whole batch (measured:
-        # 1 flip of 50400 -> ~1% everywhere).  The backward KERNELS are pinned exactly in the tests above, so
-        # here only the relative L2 error is bounded.
-        # (loose: the tiny-batch fixtures amplify a flip most; the kink-free fixtures small_ssg_slope1 /
-        # small_ssg_tanh carry the element-wise gradient check)
-        assert float((ga - gb).norm() / gb.norm()) < 0.25
-        assert float((wa - wb).norm() / wb.norm()) < 0.25
+    wa, wb = stage_lists(net)[2][-1].nn[0][0].weight.grad.cpu(), g["grad_last_fp_conv"]
+    assert float((ga - gb).norm() / gb.norm()) < 0.25
+    assert float((wa - wb).norm() / wb.norm()) < 0.25
+
+
+def test_c3_full_batch_properties(hip):
+    """BASELINE config 3 at its full size (pointnet2_charlesmsg, B=32, N=2048, 16 categories, 50 classes): properties
+    that need no CPU reference.  Eval-mode scores of a cloud do not depend on which other clouds share its batch -- the
+    property data-parallel sharding by cloud rests on -- and a second run is bit-identical."""
+    from torch_points3d_amd.dense import Data
+    from torch_points3d_amd.pointnet2 import PointNet2_D
+    B, N = 32, 2048
+    gen = torch.Generator().manual_seed(5)
+    pos = (torch.rand(B, N, 3, generator=gen) * 2 - 1).to(DEV)
+    x = torch.randn(B, N, 3, generator=gen).to(DEV)
+    cat = torch.randint(0, 16, (B, 1), generator=gen).repeat(1, N).to(DEV)
+    torch.manual_seed(1)
+    net = PointNet2_D(3, 50, num_categories=16).to(DEV)
+    net.train()
+    scores = net(Data(pos=pos, x=x), cat)  # one training pass: running statistics move off their initial values
+    assert scores.shape == (B * N, 50) and bool(torch.isfinite(scores).all())
+    loss = torch.nn.functional.cross_entropy(scores, torch.randint(0, 50, (B * N,), generator=gen).to(DEV))
+    loss.backward()
+    assert all(p.grad is not None and bool(torch.isfinite(p.grad).all()) for p in net.parameters())
+    net.eval()
+    with torch.no_grad():
+        full = net(Data(pos=pos, x=x), cat).view(B, N, 50)
+        again = net(Data(pos=pos, x=x), cat).view(B, N, 50)
+        assert torch.equal(full, again)
+        for lo, hi in ((0, 4), (4, 16), (16, 32)):
+            part = net(Data(pos=pos[lo:hi], x=x[lo:hi]), cat[lo:hi]).view(hi - lo, N, 50)
+            torch.testing.assert_close(part, full[lo:hi], rtol=1e-5, atol=1e-5)
 
 
 # ---------------------------------------------------- full BASELINE size: size-independent properties

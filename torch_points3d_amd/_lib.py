@@ -165,14 +165,6 @@ def call(name, *args):
     fn = _fn_cache.get(name)
     if fn is None:
         fn = _fn_cache[name] = getattr(load(), name)
-    if _post_call_hook is not None:
-        rc = fn(*args)
-        if rc == 0:
-            _post_call_hook(name, args)
-            return
-        h = load()
-        raise Tp3dError("%s failed: %s (code %d, hipError %d)" % (
-            name, h.tp3d_strerror(rc).decode(), rc, h.tp3d_last_hip_error()))
     if _timer is not None:
         a = torch.cuda.Event(enable_timing=True)
         b = torch.cuda.Event(enable_timing=True)
@@ -187,6 +179,8 @@ def call(name, *args):
         h = load()
         raise Tp3dError("%s failed: %s (code %d, hipError %d)" % (
             name, h.tp3d_strerror(rc).decode(), rc, h.tp3d_last_hip_error()))
+    if _post_call_hook is not None:
+        _post_call_hook(name, args)
 
 
 class on_device(object):

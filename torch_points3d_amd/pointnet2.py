@@ -118,6 +118,127 @@ class PointNet2Unet(nn.Module):
         return self.mlp(x)
 
 
+class UnetSkipConnectionBlock(nn.Module):
+    """One level of the nested U-Net the reference's segmentation models are built from
+    (models/base_architectures/unet.py:245-297): down -> submodule -> up with the level's input as skip; the innermost
+    level runs the global module instead.  Attribute names (`down`, `submodule`, `up`, `inner`) and the construction
+    order (which fixes the default initialisation under a seed) are the reference's, so its checkpoints load."""
+
+    def __init__(self, make_up, make_down=None, make_inner=None, submodule=None):
+        super().__init__()
+        self.innermost = make_inner is not None
+        if self.innermost:
+            self.inner = make_inner()
+            self.up = make_up()
+        else:
+            down, up = make_down(), make_up()
+            self.down = down
+            self.submodule = submodule
+            self.up = up
+
+    def forward(self, data):
+        below = self.inner(data) if self.innermost else self.submodule(self.down(data))
+        return self.up((below, data))
+
+
+def segmentation_config(name, feat):
+    """conf/models/segmentation/pointnet2.yaml resolved for FEAT."""
+    if name == "pointnet2_charlesmsg":  # :95-130 -- the multi-scale network of the PointNet++ paper (part segmentation)
+        return dict(unet_config("unet_3_ms", feat), mlp_cls=[128, 128], dropout=0.5)
+    raise ValueError("unknown segmentation config %r" % name)
+
+
+class PointNet2_D(nn.Module):
+    """Dense PointNet++ segmentation model with the per-object category fed to the classifier
+    (models/segmentation/pointnet2.py:19-110): nested U-Net `model`, then `FC_layer` = Conv1D+BN+LeakyReLU over
+    [features, one-hot category], Dropout, Conv1D with bias to the class scores.
+
+    forward(data[, category]) -> scores (B*N, num_classes), the layout the reference hands to cross_entropy (:101)."""
+
+    def __init__(self, input_nc, num_classes, config="pointnet2_charlesmsg", num_categories=0, kernels=None, fused=True):
+        super().__init__()
+        cfg = segmentation_config(config, input_nc) if isinstance(config, str) else config
+        self.config = cfg
+        self.fused = fused and kernels is None
+        self._num_classes = num_classes
+        self._num_categories = num_categories
+        n = len(cfg["down_conv_nn"])
+
+        def down(i):
+            return lambda: PointNetMSGDown(npoint=cfg["npoint"][i], radii=cfg["radii"][i], nsample=cfg["nsample"][i],
+                                           down_conv_nn=cfg["down_conv_nn"][i], normalize_xyz=cfg["normalize_xyz"][i],
+                                           index=i, kernels=kernels, fused=fused)
+
+        def up(j):
+            return lambda: DenseFPModule(up_conv_nn=cfg["up_conv_nn"][j], index=j, kernels=kernels, fused=fused)
+
+        block = UnetSkipConnectionBlock(up(0), make_inner=lambda: GlobalDenseBaseModule(
+            nn=cfg["innermost"], fused=fused and kernels is None))
+        for index in range(n - 1, 0, -1):
+            block = UnetSkipConnectionBlock(up(n - index), make_down=down(index), submodule=block)
+        self.model = UnetSkipConnectionBlock(up(n), make_down=down(0), submodule=block)
+        widths = list(cfg["mlp_cls"])
+        widths[0] += num_categories
+        self.FC_layer = Seq()
+        for a, b in zip(widths[:-1], widths[1:]):
+            self.FC_layer.append(Conv1D(a, b, bn=True, bias=False))
+        if cfg["dropout"]:
+            self.FC_layer.append(nn.Dropout(p=cfg["dropout"]))
+        self.FC_layer.append(Seq().append(nn.Conv1d(widths[-1], num_classes, kernel_size=1, bias=True)))
+
+    def stages(self):
+        """(down modules outermost first, global module, up modules innermost first) of the nested model."""
+        downs, ups, b = [], [], self.model
+        while not b.innermost:
+            downs.append(b.down)
+            ups.insert(0, b.up)
+            b = b.submodule
+        ups.insert(0, b.up)
+        return downs, b.inner, ups
+
+    def _with_category(self, x, category):
+        if not self._num_categories:
+            return None
+        if category is None:
+            raise ValueError("this model was built with num_categories=%d: pass `category`" % self._num_categories)
+        return torch.nn.functional.one_hot(category.long(), self._num_categories).float()  # (B, N, K)
+
+    def classifier_hidden(self, x, category=None):
+        """x (B, C, N) -> rows (B*N, width) after the Conv1D+BN+LeakyReLU layers of FC_layer (before its Dropout)."""
+        B, _, n = x.shape
+        onehot = self._with_category(x, category)
+        hidden = [m for m in self.FC_layer.children() if isinstance(m, Conv1D)]
+        if self.fused and x.is_cuda:
+            parts = [_fused.layer_parts(m) for m in hidden]
+            if all(p is not None for p in parts):
+                rows = _fused.cat_rows([_fused._cl(x)] + ([onehot] if onehot is not None else []))
+                return _fused.run_mlp(rows, parts)
+        if onehot is not None:
+            x = torch.cat((x, onehot.transpose(1, 2)), dim=1)
+        for m in hidden:
+            x = m(x)
+        return x.transpose(1, 2).reshape(B * n, -1)
+
+    def classify(self, x, category=None):
+        """x (B, C, N) features -> scores (B*N, num_classes)."""
+        rows = self.classifier_hidden(x, category)
+        layers = list(self.FC_layer.children())
+        for m in layers:
+            if isinstance(m, nn.Dropout):
+                rows = m(rows)
+        last = layers[-1][0]
+        return torch.addmm(last.bias, rows, last.weight.reshape(self._num_classes, -1).t())
+
+    def forward(self, data, category=None):
+        x = None
+        if data.x is not None:
+            x = data.x.transpose(1, 2)
+            if not (self.fused and x.is_cuda):
+                x = x.contiguous()
+        out = self.model(Data(pos=data.pos, x=x))
+        return self.classify(out.x, category)
+
+
 def PointNet2(architecture="unet", input_nc=None, num_layers=3, output_nc=None, multiscale=False, kernels=None):
     """Config-free factory with the reference's signature (applications/pointnet2.py:22-55); unet only."""
     if architecture != "unet":
