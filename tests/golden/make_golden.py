@@ -211,12 +211,19 @@ def _reference_head(net, data, record, category):
     return data
 
 
+def exact_checksum(v):
+    """Two int64 numbers that pin a tensor bit for bit and do not depend on the order a machine sums in: the sum of
+    the elements' bit patterns and a position-weighted sum of them (integer arithmetic, no overflow below 2^20
+    elements x 2^41)."""
+    b = v.detach().contiguous()
+    b = b.float().view(torch.int32) if b.is_floating_point() else b
+    b = b.reshape(-1).to(torch.int64)
+    w = torch.arange(b.numel(), dtype=torch.int64) % 1021 + 1
+    return np.array([int(b.sum()), int((b * w).sum())], dtype=np.int64)
+
+
 def state_checksums(sd):
-    out = {}
-    for k, v in sd.items():
-        v = v.double()
-        out[k] = np.array([float(v.sum()), float(v.abs().sum())])
-    return out
+    return {k: exact_checksum(v) for k, v in sd.items()}
 
 
 def kernel_level_records(cfg, pos):

@@ -55,9 +55,17 @@ def build_from_golden(g, name, kernels, device="cpu", fused=True):
     cks = {k[len("cksum/"):]: v for k, v in g.items() if k.startswith("cksum/")}
     assert set(cks) == set(sd), "state_dict keys differ from the reference modules'"
     for k, v in sd.items():
-        got = np.array([float(v.double().sum()), float(v.double().abs().sum())])
-        np.testing.assert_allclose(got, cks[k], rtol=0, atol=0, err_msg="weights differ at " + k)
+        assert np.array_equal(exact_checksum(v), np.asarray(cks[k])), "weights differ at " + k
     return net.to(device).train()
+
+
+def exact_checksum(v):
+    """as tests/golden/make_golden.py: order-independent integer checksums of the bit patterns"""
+    b = v.detach().contiguous()
+    b = b.float().view(torch.int32) if b.is_floating_point() else b
+    b = b.reshape(-1).to(torch.int64)
+    w = torch.arange(b.numel(), dtype=torch.int64) % 1021 + 1
+    return np.array([int(b.sum()), int((b * w).sum())], dtype=np.int64)
 
 
 def stage_lists(net):

@@ -48,14 +48,14 @@ def test_gemm_rows_plan_fits_its_statistics_buffer():
             tiles_n, row_blocks, items, blocks, chunks, per_wg = _plan("tp3d_gemm_rows_plan", 6, M, N)
             floats = h.tp3d_gemm_rows_stat_floats(M, N)
             assert chunks == h.tp3d_gemm_rows_stat_chunks(M, N)
-            assert chunks * 2 * N <= floats, (M, N)
+            assert chunks * 4 * N <= floats, (M, N)  # per chunk: sum d, sum d^2, shift, rows
             assert row_blocks * 128 >= M and items >= row_blocks * tiles_n and blocks <= 1024
             if per_wg:
-                # statistics row of workgroup w: (w // (8*tiles_n)) * 8 + (w & 7)
+                # statistics chunks of workgroup w: 2 * ((w // (8*tiles_n)) * 8 + (w & 7)) + wave row
                 assert blocks == 1024 and 1024 % (8 * tiles_n) == 0
-                assert max((w // (8 * tiles_n)) * 8 + (w & 7) for w in range(blocks)) == chunks - 1
+                assert max(2 * ((w // (8 * tiles_n)) * 8 + (w & 7)) + 1 for w in range(blocks)) == chunks - 1
             else:
-                assert chunks == row_blocks
+                assert chunks == 2 * row_blocks  # one per (128-row block, wave row)
 
 
 @pytest.mark.parametrize("pooled_ns", [0, 1, 2, 16, 24, 32, 64, 128, 512])

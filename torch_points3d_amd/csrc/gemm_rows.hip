@@ -32,7 +32,6 @@ __global__ __launch_bounds__(GR_BLOCK_T) void gemm_rows_kernel(const float *__re
 {
     __shared__ __attribute__((aligned(16))) float sA[GR_BM * GR_LD];
     __shared__ __attribute__((aligned(16))) float sB[GR_BN * GR_LD];
-    __shared__ float s_st[2][2][GR_BN];  // [sum|sumsq][wave row][column]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
@@ -76,6 +75,9 @@ __global__ __launch_bounds__(GR_BLOCK_T) void gemm_rows_kernel(const float *__re
 
     const int n0_first = n0;
     float run1[2] = {0.0f, 0.0f}, run2[2] = {0.0f, 0.0f};  // STATS == 2: this thread's share over all its items
+    float kshift[2] = {0.0f, 0.0f};
+    bool have_shift = false;
+    int run_rows = 0;
     f32x16 acc[2][2];
     while (item < items) {
 #pragma unroll
@@ -134,49 +136,48 @@ __global__ __launch_bounds__(GR_BLOCK_T) void gemm_rows_kernel(const float *__re
                     if (m < M && n < N) C[m * N + n] = acc[i][j][e];
                 }
             }
-        if (STATS == 2) {
-            // rows past M (and whole padding items) were staged as zeros, so they add nothing to either sum
+        if (STATS != 0) {
+            // Column statistics of this wave's 64 x 64 part of the tile as SHIFTED sums (d = v - K; K = the first value
+            // the wave saw in that column): free of the cancellation E[y^2] - E[y]^2 suffers when |mean| >> std.
+            // Rows past M were staged as zeros and are masked out.  STATS == 1: one chunk per (row block, wave row);
+            // STATS == 2: the sums run on over all items of the workgroup, one chunk per (workgroup, wave row).
+            const int64_t mrow0 = m0 + wr * 64;
+            const int valid = (int)min((int64_t)64, max((int64_t)0, M - mrow0));  // rows of this wave inside the matrix
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
+                if (STATS == 1 || !have_shift) kshift[j] = __shfl(acc[0][j][0], l31);  // row mrow0 of this column
                 float s1 = 0.0f, s2 = 0.0f;
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
                     for (int e = 0; e < 16; ++e) {
-                        const float v = acc[i][j][e];
-                        s1 += v;
-                        s2 += v * v;
+                        const int r = i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                        const float d = acc[i][j][e] - kshift[j];
+                        if (r < valid) {
+                            s1 += d;
+                            s2 += d * d;
+                        }
                     }
-                run1[j] += s1;
-                run2[j] += s2;
-            }
-        }
-        if (STATS == 1) {
-            // rows past M were staged as zeros, so they add nothing to either sum
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                float s1 = 0.0f, s2 = 0.0f;
-#pragma unroll
-                for (int i = 0; i < 2; ++i)
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) {
-                        const float v = acc[i][j][e];
-                        s1 += v;
-                        s2 += v * v;
+                if (STATS == 2) {
+                    run1[j] += s1;
+                    run2[j] += s2;
+                } else {
+                    s1 += __shfl_xor(s1, 32);  // the two half-waves hold different rows of the same column
+                    s2 += __shfl_xor(s2, 32);
+                    const int n = n0 + (wc * 2 + j) * 32 + l31;
+                    if (lh == 0 && n < N && m0 < M) {  // padding items (row block past M) own no statistics rows
+                        float *pr = partial + ((size_t)(rb * 2 + wr) * 4) * N + n;
+                        pr[0] = s1;
+                        pr[(size_t)N] = s2;
+                        pr[(size_t)2 * N] = kshift[j];
+                        pr[(size_t)3 * N] = (float)valid;
                     }
-                s1 += __shfl_xor(s1, 32);  // the two half-waves hold different rows of the same column
-                s2 += __shfl_xor(s2, 32);
-                if (lh == 0) {
-                    s_st[0][wr][(wc * 2 + j) * 32 + l31] = s1;
-                    s_st[1][wr][(wc * 2 + j) * 32 + l31] = s2;
                 }
             }
-            __syncthreads();
-            if (tid < GR_BN && n0 + tid < N && m0 < M) {  // padding items (row block past M) own no statistics row
-                partial[((size_t)rb * 2 + 0) * N + n0 + tid] = s_st[0][0][tid] + s_st[0][1][tid];
-                partial[((size_t)rb * 2 + 1) * N + n0 + tid] = s_st[1][0][tid] + s_st[1][1][tid];
+            if (STATS == 2) {
+                if (valid > 0) have_shift = true;  // (wave-uniform) a wave whose first items were padding keeps looking
+                run_rows += valid;
             }
-            // (the next write to s_st is separated from these reads by the K-loop barriers of the next item)
         }
         item = next_item;
         m0 = nm0;
@@ -184,21 +185,19 @@ __global__ __launch_bounds__(GR_BLOCK_T) void gemm_rows_kernel(const float *__re
         rb = nrb;
     }
     if (STATS == 2) {
-        // all K-loop barriers are behind: one exchange for the whole walk
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            float s1 = run1[j] + __shfl_xor(run1[j], 32), s2 = run2[j] + __shfl_xor(run2[j], 32);
-            if (lh == 0) {
-                s_st[0][wr][(wc * 2 + j) * 32 + l31] = s1;
-                s_st[1][wr][(wc * 2 + j) * 32 + l31] = s2;
-            }
-        }
-        __syncthreads();
         const int per = 8 * tiles_n;
         const int64_t slot = (int64_t)(blockIdx.x / per) * 8 + (blockIdx.x & 7);
-        if (tid < GR_BN && n0_first + tid < N) {
-            partial[((size_t)slot * 2 + 0) * N + n0_first + tid] = s_st[0][0][tid] + s_st[0][1][tid];
-            partial[((size_t)slot * 2 + 1) * N + n0_first + tid] = s_st[1][0][tid] + s_st[1][1][tid];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const float s1 = run1[j] + __shfl_xor(run1[j], 32), s2 = run2[j] + __shfl_xor(run2[j], 32);
+            const int n = n0_first + (wc * 2 + j) * 32 + l31;
+            if (lh == 0 && n < N) {
+                float *pr = partial + ((size_t)(slot * 2 + wr) * 4) * N + n;
+                pr[0] = s1;
+                pr[(size_t)N] = s2;
+                pr[(size_t)2 * N] = kshift[j];
+                pr[(size_t)3 * N] = (float)run_rows;
+            }
         }
     }
 }
@@ -224,7 +223,7 @@ RowsPlan rows_plan(int64_t M, int N)
     p.items = groups * 8 * p.tiles_n;  // items past the last row block stage zeros and store nothing
     p.blocks = p.items < GR_GRID ? p.items : GR_GRID;
     p.per_workgroup = p.blocks == GR_GRID && GR_GRID % (8 * p.tiles_n) == 0;
-    p.chunks = p.per_workgroup ? GR_GRID / p.tiles_n : p.row_blocks;
+    p.chunks = 2 * (p.per_workgroup ? GR_GRID / p.tiles_n : p.row_blocks);  // one per wave row of a workgroup tile
     return p;
 }
 }  // namespace
@@ -235,8 +234,8 @@ TP3D_EXPORT size_t tp3d_gemm_rows_stat_floats(int64_t M, int N)
 {
     if (M <= 0 || N <= 0) return 0;
     const RowsPlan p = rows_plan(M, N);
-    const int64_t rows = p.chunks > p.row_blocks ? p.chunks : p.row_blocks;
-    return (size_t)rows * 2 * (size_t)N;
+    const int64_t rows = p.chunks > 2 * p.row_blocks ? p.chunks : 2 * p.row_blocks;
+    return (size_t)rows * 4 * (size_t)N;  // per chunk: sum d, sum d^2, shift, rows
 }
 
 // number of statistics rows tp3d_gemm_rows_f32 writes for this shape = `chunks` of tp3d_bn_finalize_f32

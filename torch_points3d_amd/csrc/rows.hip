@@ -204,8 +204,10 @@ static inline StatTile stat_tile(int C, int V)
     return t;
 }
 
-// MODE 0: a += y, q += y*y                      (forward statistics)
-// MODE 1: a += dz, q += dz*yhat, dz = dA*act'   (backward reductions)
+// MODE 0: a += d, q += d*d with d = y - K, K = the chunk's first row of that column   (forward statistics; the
+//         shift keeps the sums free of the cancellation E[y^2] - E[y]^2 suffers when |mean| >> std);
+//         partial[chunk] = 4 rows of C: sum d, sum d^2, K, rows in the chunk  -> bn_finalize_kernel (Chan's merge)
+// MODE 1: a += dz, q += dz*yhat, dz = dA*act'   (backward reductions; partial[chunk] = 2 rows of C)
 template <int V, int MODE>
 __global__ __launch_bounds__(RW_BLOCK) void colreduce_partial_kernel(
     const float *__restrict__ Y, const float *__restrict__ dA, const float *__restrict__ scale,
@@ -223,6 +225,7 @@ __global__ __launch_bounds__(RW_BLOCK) void colreduce_partial_kernel(
     for (int v = 0; v < V; ++v) {
         a[v] = 0.0f;
         q[v] = 0.0f;
+        if (MODE == 0) mu[v] = (c + v < C && r0 < M) ? Y[r0 * C + c + v] : 0.0f;  // the shift K
         if (MODE == 1 && c + v < C) {
             sc[v] = scale[c + v];
             sh[v] = shift[c + v];
@@ -248,7 +251,7 @@ __global__ __launch_bounds__(RW_BLOCK) void colreduce_partial_kernel(
                 } else {
 #pragma unroll
                     for (int v = 0; v < V; ++v) {
-                        y[u][v] = MODE == 1 ? mu[v] : 0.0f;  // contributes exactly zero
+                        y[u][v] = mu[v];  // contributes exactly zero (MODE 0: y - K = 0; MODE 1: dA = 0)
                         d[u][v] = 0.0f;
                     }
                 }
@@ -258,8 +261,9 @@ __global__ __launch_bounds__(RW_BLOCK) void colreduce_partial_kernel(
 #pragma unroll
                 for (int v = 0; v < V; ++v) {
                     if (MODE == 0) {
-                        a[v] += y[u][v];
-                        q[v] += y[u][v] * y[u][v];
+                        const float dd = y[u][v] - mu[v];
+                        a[v] += dd;
+                        q[v] += dd * dd;
                     } else {
                         const float z = y[u][v] * sc[v] + sh[v];
                         const float dz = d[u][v] * (z > 0.0f ? 1.0f : slope);
@@ -284,8 +288,15 @@ __global__ __launch_bounds__(RW_BLOCK) void colreduce_partial_kernel(
                     sa += s1[(k * colthreads + ct) * V + v];
                     sq += s2[(k * colthreads + ct) * V + v];
                 }
-                partial[((size_t)blockIdx.y * 2 + 0) * C + c + v] = sa;
-                partial[((size_t)blockIdx.y * 2 + 1) * C + c + v] = sq;
+                if (MODE == 0) {
+                    partial[((size_t)blockIdx.y * 4 + 0) * C + c + v] = sa;
+                    partial[((size_t)blockIdx.y * 4 + 1) * C + c + v] = sq;
+                    partial[((size_t)blockIdx.y * 4 + 2) * C + c + v] = mu[v];
+                    partial[((size_t)blockIdx.y * 4 + 3) * C + c + v] = (float)(r1 - r0);
+                } else {
+                    partial[((size_t)blockIdx.y * 2 + 0) * C + c + v] = sa;
+                    partial[((size_t)blockIdx.y * 2 + 1) * C + c + v] = sq;
+                }
             }
         }
     }
@@ -315,7 +326,22 @@ __device__ __forceinline__ void sum_partials(const float *__restrict__ partial, 
     q = r2[0];
 }
 
-// finalize (training): mean, biased var -> scale = gamma*invstd, shift = beta - mean*scale; running stats update.
+// block-wide sum of one double per thread, fixed tree => reproducible
+__device__ __forceinline__ double block_sum(double v, double *red /* RW_BLOCK */)
+{
+    __syncthreads();
+    red[threadIdx.x] = v;
+    __syncthreads();
+    for (int off = RW_BLOCK / 2; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+        __syncthreads();
+    }
+    return red[0];
+}
+
+// finalize (training): the chunks' (sum d, sum d^2, shift K, rows n) are merged like Chan et al.'s parallel variance:
+//   mean_k = K + S/n,  M2_k = Q - S^2/n;   mean = sum n_k mean_k / M;   M2 = sum [M2_k + n_k (mean_k - mean)^2]
+// in double, fixed order.  mean, biased var -> scale = gamma*invstd, shift = beta - mean*scale; running stats update.
 // eval: scale/shift from the running statistics.  One workgroup per channel.
 __global__ __launch_bounds__(RW_BLOCK) void bn_finalize_kernel(
     const float *__restrict__ partial, int chunks, int64_t M, int C, float eps, float momentum,
@@ -323,13 +349,26 @@ __global__ __launch_bounds__(RW_BLOCK) void bn_finalize_kernel(
     float *__restrict__ running_var, int training, float *__restrict__ mean_out, float *__restrict__ invstd_out,
     float *__restrict__ scale_out, float *__restrict__ shift_out)
 {
+    __shared__ double red[RW_BLOCK];
     const int c = blockIdx.x;
     float mean, var;
     if (training) {
-        double a, q;
-        sum_partials(partial, chunks, C, c, a, q);
-        const double mu = a / (double)M;
-        double v = q / (double)M - mu * mu;
+        double wsum = 0.0;
+        for (int k = threadIdx.x; k < chunks; k += RW_BLOCK) {
+            const double n = (double)partial[((size_t)k * 4 + 3) * C + c];
+            if (n > 0.0) wsum += n * (double)partial[((size_t)k * 4 + 2) * C + c] + (double)partial[((size_t)k * 4 + 0) * C + c];
+        }
+        const double mu = block_sum(wsum, red) / (double)M;
+        double m2 = 0.0;
+        for (int k = threadIdx.x; k < chunks; k += RW_BLOCK) {
+            const double n = (double)partial[((size_t)k * 4 + 3) * C + c];
+            if (n > 0.0) {
+                const double S = (double)partial[((size_t)k * 4 + 0) * C + c], Q = (double)partial[((size_t)k * 4 + 1) * C + c];
+                const double dm = (double)partial[((size_t)k * 4 + 2) * C + c] + S / n - mu;
+                m2 += (Q - S * S / n) + n * dm * dm;
+            }
+        }
+        double v = block_sum(m2, red) / (double)M;
         if (v < 0.0) v = 0.0;
         mean = (float)mu;
         var = (float)v;
@@ -811,7 +850,7 @@ TP3D_EXPORT size_t tp3d_bn_workspace_floats(int64_t M, int C)
     // covers the reduction over M rows and over any M / ns pooled groups (which may fall in the small-matrix regime)
     int64_t chunks = M >= ST_SMALL_BELOW ? (M + ST_ROWS - 1) / ST_ROWS : (M + ST_ROWS_SMALL - 1) / ST_ROWS_SMALL;
     if (M >= ST_SMALL_BELOW && chunks < ST_SMALL_BELOW / ST_ROWS_SMALL) chunks = ST_SMALL_BELOW / ST_ROWS_SMALL;
-    return (size_t)chunks * 2 * (size_t)C;
+    return (size_t)chunks * 4 * (size_t)C;  // forward statistics keep 4 rows per chunk, the backward reductions 2
 }
 
 // plan[0..2] = rows per chunk, chunks, workspace floats written, for the reduction tp3d_bn_stats_f32 (pooled_ns = 0)
@@ -823,7 +862,7 @@ TP3D_EXPORT int tp3d_bn_plan(int64_t M, int C, int pooled_ns, int64_t *plan)
     const int crow = stat_rows(R);
     plan[0] = crow;
     plan[1] = (R + crow - 1) / crow;
-    plan[2] = plan[1] * 2 * C;
+    plan[2] = plan[1] * (pooled_ns == 0 ? 4 : 2) * C;
     return TP3D_OK;
 }
 
