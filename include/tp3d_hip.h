@@ -35,7 +35,7 @@ extern "C" {
 #define TP3D_E_UNSORTED (-3) /* reserved: batch vector not sorted (checked by the host wrapper) */
 #define TP3D_E_TOOBIG (-4)   /* size exceeds what the kernel's index arithmetic supports */
 
-#define TP3D_ABI_VERSION 18
+#define TP3D_ABI_VERSION 20
 
 int tp3d_abi_version(void);
 const char *tp3d_strerror(int code);
@@ -143,7 +143,9 @@ int tp3d_rows_scatter_bwd_f32(const float *grad_rows, const int64_t *idx, const 
                               int nbins, int ld, int col0, int C, float *grad_x_cl, void *workspace,
                               size_t workspace_bytes, void *stream);
 
-/* BatchNorm statistics of Y (M, C) and the folded affine  scale = gamma*invstd, shift = beta - mean*scale.
+/* BatchNorm statistics of Y (M, C): mean, invstd, scale = gamma*invstd and shift = beta; the normalised value is
+ * always formed as (y - mean)*scale + shift (a folded shift beta - mean*scale would cancel against y*scale in fp32
+ * when |mean| >> std).  Batch statistics are accumulated as shifted sums per row chunk and merged with Chan's formula.
  * training != 0: batch mean / biased variance (running stats updated in place with `momentum`, unbiased var);
  * training == 0: running statistics.  workspace: tp3d_bn_workspace_floats(M, C) floats. */
 size_t tp3d_bn_workspace_floats(int64_t M, int C);
@@ -151,12 +153,12 @@ int tp3d_bn_stats_f32(const float *Y, int64_t M, int C, float eps, float momentu
                       const float *beta, float *running_mean, float *running_var, int training, float *mean,
                       float *invstd, float *scale, float *shift, float *workspace, void *stream);
 
-/* out = LeakyReLU_slope(scale*Y + shift) over (M, C);  the pooled form also takes the max over each group of
+/* out = LeakyReLU_slope((Y - mean)*scale + shift) over (M, C);  the pooled form also takes the max over each group of
  * ns consecutive rows (first maximum wins) and records its row in argmax (G, C). */
-int tp3d_bn_act_f32(const float *Y, const float *scale, const float *shift, float slope, int64_t M, int C, float *out,
-                    void *stream);
-int tp3d_bn_act_maxpool_f32(const float *Y, const float *scale, const float *shift, float slope, int64_t G, int ns,
-                            int C, float *out, int *argmax, void *stream);
+int tp3d_bn_act_f32(const float *Y, const float *mean, const float *scale, const float *shift, float slope, int64_t M,
+                    int C, float *out, void *stream);
+int tp3d_bn_act_maxpool_f32(const float *Y, const float *mean, const float *scale, const float *shift, float slope,
+                            int64_t G, int ns, int C, float *out, int *argmax, void *stream);
 
 /* Backward of out = act(BN(Y)): dbeta, dgamma (C) and dY (M, C).  dA is (M, C), or -- with argmax != NULL --
  * the gradient (M/ns, C) of the pooled output.  workspace: tp3d_bn_workspace_floats(M, C) floats. */
@@ -217,6 +219,12 @@ int tp3d_kpconv_bwd_features_f32(const float *query, const float *support, const
                                  int Cin, int KP, float extent, int influence, int closest, float *d_features,
                                  void *inverse, size_t inverse_bytes, int inverse_ready, void *workspace,
                                  size_t workspace_bytes, void *stream);
+
+/* Geometric relation rows of Relation-Shape convolution (reference modules/RSConv/dense.py:86-101):
+ *   out[(b,j,s), 0:10] = [ |d|, new_pos[b,j] (3), p (3), d (3) ],  p = pos[b, idx[b,j,s]],  d = p - new_pos[b,j];
+ *   columns 10 .. ld-1 are zero.  pos (B,N,3), new_pos (B,np,3), idx (B,np,ns) -> out (B*np*ns, ld), ld >= 10. */
+int tp3d_relation_rows_f32(const float *pos, const float *new_pos, const int64_t *idx, int B, int N, int np, int ns,
+                           int ld, float *out, void *stream);
 
 /* inverse-distance weights of DenseFPModule (core/base_conv/dense.py:137-139): dist (rows,3) -> weight (rows,3) */
 int tp3d_idw_weights_f32(const float *dist, int64_t rows, float *weight, void *stream);

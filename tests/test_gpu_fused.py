@@ -218,6 +218,7 @@ def test_sharded_step_same_trajectory():
 def test_gemm_rows_matches_fp64_and_stats(M, N, K):
     """fp32 MFMA rows GEMM (forward / input-gradient contraction) + fused BatchNorm statistics epilogue"""
     from torch_points3d_amd import fused
+    K_ = K
     g = torch.Generator().manual_seed(M + N + K)
     A = torch.randn(M, K, generator=g).to(DEV)
     Bm = torch.randn(K, N, generator=g).to(DEV)
@@ -227,18 +228,26 @@ def test_gemm_rows_matches_fp64_and_stats(M, N, K):
     lib = float((torch.mm(A, Bm).double() - ref).abs().max())
     assert err <= max(2.0 * lib, 1e-5 * float(ref.abs().max())), (err, lib)
     from torch_points3d_amd import _lib
-    chunks = _lib.load().tp3d_gemm_rows_stat_chunks(M, N)  # one row per 128-row block, or per persistent workgroup
-    assert chunks == (M + 127) // 128 or chunks == 1024 // ((N + 127) // 128)
-    assert part.numel() >= chunks * 2 * N * 4
-    p = part[: chunks * 2 * N * 4].view(torch.float32).view(chunks, 2, N)
-    torch.testing.assert_close(p[:, 0].double().sum(0), ref.sum(0), rtol=1e-4, atol=1e-3 * float(ref.abs().max()))
-    torch.testing.assert_close(p[:, 1].double().sum(0), (ref * ref).sum(0), rtol=1e-4, atol=1e-2)
-    # the statistics rows end exactly at chunks*2*N floats: a guard band behind them must stay untouched
-    guard = torch.full((chunks * 2 * N + 8 * 2 * N,), 7.0, device=DEV)
+    # statistics chunks: one per (128-row block, wave row) or per (persistent workgroup, wave row); each holds four rows
+    # of N: sum d, sum d^2 (d = value - shift), the shift, and the number of matrix rows that went into it
+    chunks = _lib.load().tp3d_gemm_rows_stat_chunks(M, N)
+    assert chunks == 2 * ((M + 127) // 128) or chunks == 2 * (1024 // ((N + 127) // 128))
+    assert part.numel() >= chunks * 4 * N * 4
+    p = part[: chunks * 4 * N * 4].view(torch.float32).view(chunks, 4, N).double()
+    S, Q, K, n = p[:, 0], p[:, 1], p[:, 2], p[:, 3]
+    assert float(n[:, 0].sum()) == M and bool((n == n[:, :1]).all())
+    mean = (n * K + S).sum(0) / M
+    torch.testing.assert_close(mean, ref.mean(0), rtol=1e-5, atol=1e-5 * float(ref.abs().max()))
+    live = n > 0
+    mk = torch.where(live, K + S / n.clamp(min=1), torch.zeros_like(K))
+    m2 = (torch.where(live, Q - S * S / n.clamp(min=1), torch.zeros_like(Q)) + n * (mk - mean) ** 2).sum(0)
+    torch.testing.assert_close(m2 / M, ref.var(0, unbiased=False), rtol=2e-5, atol=1e-6)
+    # the statistics rows end exactly at chunks*4*N floats: a guard band behind them must stay untouched
+    guard = torch.full((chunks * 4 * N + 8 * 2 * N,), 7.0, device=DEV)
     C2 = torch.empty_like(C)
-    _lib.call("tp3d_gemm_rows_f32", A.data_ptr(), Bm.t().contiguous().data_ptr(), M, N, K, C2.data_ptr(), guard.data_ptr(),
+    _lib.call("tp3d_gemm_rows_f32", A.data_ptr(), Bm.t().contiguous().data_ptr(), M, N, K_, C2.data_ptr(), guard.data_ptr(),
               _lib.stream_ptr(A.device))
-    assert torch.equal(C2, C) and bool((guard[chunks * 2 * N:] == 7.0).all())
+    assert torch.equal(C2, C) and bool((guard[chunks * 4 * N:] == 7.0).all())
     # exact integer data: any operand / accumulator layout mix-up shows up as a wrong integer
     Ai = torch.randint(-3, 4, (M, K), generator=g).float().to(DEV)
     Bi = torch.randint(-3, 4, (K, N), generator=g).float().to(DEV)

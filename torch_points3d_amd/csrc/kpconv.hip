@@ -382,10 +382,14 @@ static int invert_neighbors(const int64_t *neighbors, int64_t slots, int64_t M, 
     int *start = reinterpret_cast<int *>(p + up((size_t)M * 4));
     int *cursor = reinterpret_cast<int *>(p + up((size_t)M * 4) + up((size_t)(M + 1) * 4));
     int *order = reinterpret_cast<int *>(p + up((size_t)M * 4) + up((size_t)(M + 1) * 4) + up((size_t)M * 4));
+    // second buffer of the run merge that sorts a bin of more than 1024 slots (a hub support point: many queries padding
+    // onto one index, duplicated points); without it such a bin fell back to one lane's insertion sort -- tens of seconds
+    int *merge_tmp = reinterpret_cast<int *>(p + up((size_t)M * 4) + up((size_t)(M + 1) * 4) + up((size_t)M * 4) +
+                                             up((size_t)slots * 4));
     *start_out = start;
     *order_out = order;
     if (ready) return TP3D_OK;  // the caller kept the table of an earlier call on the same neighbours
-    return invert_table(neighbors, slots, M, cnt, start, cursor, order, s);
+    return invert_table(neighbors, slots, M, cnt, start, cursor, order, s, 0, 0, merge_tmp);
 }
 
 // Strided shortcut of ResnetBBlock (reference modules/KPConv/blocks.py:206-210): max over each query's neighbours of
@@ -536,7 +540,7 @@ TP3D_EXPORT size_t tp3d_kpconv_bwd_workspace_bytes(int64_t M, int64_t slots)
 {
     if (M < 0 || slots < 0) return 0;
     auto up = [](size_t v) { return (v + 15) & ~(size_t)15; };
-    return up((size_t)M * 4) + up((size_t)(M + 1) * 4) + up((size_t)M * 4) + up((size_t)slots * 4);
+    return up((size_t)M * 4) + up((size_t)(M + 1) * 4) + up((size_t)M * 4) + 2 * up((size_t)slots * 4);  // + merge buffer
 }
 
 TP3D_EXPORT size_t tp3d_kpconv_grad_workspace_bytes(int64_t M, int64_t slots, int Cin)

@@ -265,7 +265,7 @@ __global__ __launch_bounds__(RW_BLOCK) void colreduce_partial_kernel(
                         a[v] += dd;
                         q[v] += dd * dd;
                     } else {
-                        const float z = y[u][v] * sc[v] + sh[v];
+                        const float z = (y[u][v] - mu[v]) * sc[v] + sh[v];
                         const float dz = d[u][v] * (z > 0.0f ? 1.0f : slope);
                         a[v] += dz;
                         q[v] += dz * ((y[u][v] - mu[v]) * is[v]);
@@ -341,7 +341,7 @@ __device__ __forceinline__ double block_sum(double v, double *red /* RW_BLOCK */
 
 // finalize (training): the chunks' (sum d, sum d^2, shift K, rows n) are merged like Chan et al.'s parallel variance:
 //   mean_k = K + S/n,  M2_k = Q - S^2/n;   mean = sum n_k mean_k / M;   M2 = sum [M2_k + n_k (mean_k - mean)^2]
-// in double, fixed order.  mean, biased var -> scale = gamma*invstd, shift = beta - mean*scale; running stats update.
+// in double, fixed order.  mean, biased var -> scale = gamma*invstd, shift_out = beta; running stats update.
 // eval: scale/shift from the running statistics.  One workgroup per channel.
 __global__ __launch_bounds__(RW_BLOCK) void bn_finalize_kernel(
     const float *__restrict__ partial, int chunks, int64_t M, int C, float eps, float momentum,
@@ -388,7 +388,8 @@ __global__ __launch_bounds__(RW_BLOCK) void bn_finalize_kernel(
     mean_out[c] = mean;
     invstd_out[c] = invstd;
     scale_out[c] = sc;
-    shift_out[c] = (beta ? beta[c] : 0.0f) - mean * sc;
+    shift_out[c] = beta ? beta[c] : 0.0f;  // the kernels apply (y - mean) * scale + beta: no folded shift, whose
+                                            // product mean * scale cancels against y * scale when |mean| >> std
 }
 
 // Grid-stride walk over a (rows, C) matrix in units of V floats that tracks the channel without a division per
@@ -409,9 +410,9 @@ struct ChanWalk {
 
 __device__ __forceinline__ float leaky(float z, float slope) { return z > 0.0f ? z : z * slope; }
 
-// A = act(scale*Y + shift), act = LeakyReLU(slope) (slope = 1 -> identity)
+// A = act((Y - mean)*scale + beta), act = LeakyReLU(slope) (slope = 1 -> identity)
 template <int V>
-__global__ __launch_bounds__(RW_BLOCK) void bn_act_kernel(const float *__restrict__ Y,
+__global__ __launch_bounds__(RW_BLOCK) void bn_act_kernel(const float *__restrict__ Y, const float *__restrict__ mean,
                                                            const float *__restrict__ scale,
                                                            const float *__restrict__ shift, float slope,
                                                            int64_t total, int C, float *__restrict__ out)
@@ -422,22 +423,24 @@ __global__ __launch_bounds__(RW_BLOCK) void bn_act_kernel(const float *__restric
     for (; e < total; e += stride, cw.next()) {
         if (V == 4) {
             const float4 y = *reinterpret_cast<const float4 *>(Y + e);
+            const float4 mu = *reinterpret_cast<const float4 *>(mean + cw.c);
             const float4 sc = *reinterpret_cast<const float4 *>(scale + cw.c);
             const float4 sh = *reinterpret_cast<const float4 *>(shift + cw.c);
             float4 o;
-            o.x = leaky(y.x * sc.x + sh.x, slope);
-            o.y = leaky(y.y * sc.y + sh.y, slope);
-            o.z = leaky(y.z * sc.z + sh.z, slope);
-            o.w = leaky(y.w * sc.w + sh.w, slope);
+            o.x = leaky((y.x - mu.x) * sc.x + sh.x, slope);
+            o.y = leaky((y.y - mu.y) * sc.y + sh.y, slope);
+            o.z = leaky((y.z - mu.z) * sc.z + sh.z, slope);
+            o.w = leaky((y.w - mu.w) * sc.w + sh.w, slope);
             *reinterpret_cast<float4 *>(out + e) = o;
         } else {
-            out[e] = leaky(Y[e] * scale[cw.c] + shift[cw.c], slope);
+            out[e] = leaky((Y[e] - mean[cw.c]) * scale[cw.c] + shift[cw.c], slope);
         }
     }
 }
 
 // fused BN-affine + LeakyReLU + max over the ns consecutive rows of a group (first max wins, like max_pool2d)
 __global__ __launch_bounds__(RW_BLOCK) void bn_act_maxpool_kernel(const float *__restrict__ Y,
+                                                                   const float *__restrict__ mean,
                                                                    const float *__restrict__ scale,
                                                                    const float *__restrict__ shift, float slope,
                                                                    int64_t G, int ns, int C,
@@ -447,7 +450,7 @@ __global__ __launch_bounds__(RW_BLOCK) void bn_act_maxpool_kernel(const float *_
     for (int64_t e = (int64_t)blockIdx.x * RW_BLOCK + threadIdx.x; e < total; e += (int64_t)gridDim.x * RW_BLOCK) {
         const int64_t g = e / C;
         const int c = (int)(e - g * C);
-        const float sc = scale[c], sh = shift[c];
+        const float mu = mean[c], sc = scale[c], sh = shift[c];
         const float *y = Y + (size_t)g * ns * C + c;
         float best = -INFINITY;
         int bs = 0;
@@ -458,7 +461,7 @@ __global__ __launch_bounds__(RW_BLOCK) void bn_act_maxpool_kernel(const float *_
             for (int u = 0; u < 8; ++u) v[u] = y[(size_t)(s + u) * C];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                const float z = v[u] * sc + sh;
+                const float z = (v[u] - mu) * sc + sh;
                 const float a = z > 0.0f ? z : z * slope;
                 if (a > best) {
                     best = a;
@@ -467,7 +470,7 @@ __global__ __launch_bounds__(RW_BLOCK) void bn_act_maxpool_kernel(const float *_
             }
         }
         for (; s < ns; ++s) {
-            const float z = y[(size_t)s * C] * sc + sh;
+            const float z = (y[(size_t)s * C] - mu) * sc + sh;
             const float a = z > 0.0f ? z : z * slope;
             if (a > best) {
                 best = a;
@@ -504,7 +507,7 @@ __global__ __launch_bounds__(RW_BLOCK) void bn_pool_bwd_partial_kernel(const flo
         for (int64_t g = g0 + tr; g < g1; g += 4) {
             const int s = arg[g * C + c];
             const float y = Y[((size_t)g * ns + s) * C + c];
-            const float z = y * sc + sh;
+            const float z = (y - mu) * sc + sh;
             const float dz = dP[g * C + c] * (z > 0.0f ? 1.0f : slope);
             a += dz;
             q += dz * ((y - mu) * is);
@@ -538,7 +541,7 @@ __global__ __launch_bounds__(RW_BLOCK) void bn_bwd_finalize_kernel(const float *
 __device__ __forceinline__ float bn_bwd_elem(float da, float y, float sc, float sh, float mu, float is, float db,
                                              float dg, float slope, float invM, int training)
 {
-    const float z = y * sc + sh;
+    const float z = (y - mu) * sc + sh;
     const float dz = da * (z > 0.0f ? 1.0f : slope);
     float v = dz;
     if (training) v = dz - db * invM - ((y - mu) * is) * (dg * invM);
@@ -578,7 +581,7 @@ __global__ __launch_bounds__(RW_BLOCK) void bn_act_bwd_apply_kernel(
             }
 #pragma unroll
             for (int v = 0; v < V; ++v) {
-                const float z = y[v] * sc[v] + sh[v];
+                const float z = (y[v] - mu[v]) * sc[v] + sh[v];
                 const float dz = d[v] * (z > 0.0f ? 1.0f : slope);
                 float t = dz;
                 if (training) t = dz - k1[v] - ((y[v] - mu[v]) * is[v]) * k2[v];
@@ -909,29 +912,29 @@ TP3D_EXPORT int tp3d_bn_finalize_f32(const float *partial, int chunks, int64_t M
     return check_launch();
 }
 
-TP3D_EXPORT int tp3d_bn_act_f32(const float *Y, const float *scale, const float *shift, float slope, int64_t M, int C,
-                                float *out, void *stream)
+TP3D_EXPORT int tp3d_bn_act_f32(const float *Y, const float *mean, const float *scale, const float *shift, float slope,
+                                int64_t M, int C, float *out, void *stream)
 {
     if (M < 0 || C <= 0) return TP3D_E_BADARG;
     if (M == 0) return TP3D_OK;
-    if (!Y || !scale || !shift || !out) return TP3D_E_BADARG;
+    if (!Y || !mean || !scale || !shift || !out) return TP3D_E_BADARG;
     const int64_t total = M * C;
     if ((C & 3) == 0)
-        hipLaunchKernelGGL(bn_act_kernel<4>, dim3(grid_for(total / 4)), dim3(RW_BLOCK), 0, (hipStream_t)stream, Y, scale,
-                           shift, slope, total, C, out);
+        hipLaunchKernelGGL(bn_act_kernel<4>, dim3(grid_for(total / 4)), dim3(RW_BLOCK), 0, (hipStream_t)stream, Y, mean,
+                           scale, shift, slope, total, C, out);
     else
-        hipLaunchKernelGGL(bn_act_kernel<1>, dim3(grid_for(total)), dim3(RW_BLOCK), 0, (hipStream_t)stream, Y, scale,
-                           shift, slope, total, C, out);
+        hipLaunchKernelGGL(bn_act_kernel<1>, dim3(grid_for(total)), dim3(RW_BLOCK), 0, (hipStream_t)stream, Y, mean,
+                           scale, shift, slope, total, C, out);
     return check_launch();
 }
 
-TP3D_EXPORT int tp3d_bn_act_maxpool_f32(const float *Y, const float *scale, const float *shift, float slope,
-                                        int64_t G, int ns, int C, float *out, int *argmax, void *stream)
+TP3D_EXPORT int tp3d_bn_act_maxpool_f32(const float *Y, const float *mean, const float *scale, const float *shift,
+                                        float slope, int64_t G, int ns, int C, float *out, int *argmax, void *stream)
 {
     if (G < 0 || ns <= 0 || C <= 0) return TP3D_E_BADARG;
     if (G == 0) return TP3D_OK;
-    if (!Y || !scale || !shift || !out || !argmax) return TP3D_E_BADARG;
-    hipLaunchKernelGGL(bn_act_maxpool_kernel, dim3(grid_for(G * C)), dim3(RW_BLOCK), 0, (hipStream_t)stream, Y, scale,
+    if (!Y || !mean || !scale || !shift || !out || !argmax) return TP3D_E_BADARG;
+    hipLaunchKernelGGL(bn_act_maxpool_kernel, dim3(grid_for(G * C)), dim3(RW_BLOCK), 0, (hipStream_t)stream, Y, mean, scale,
                        shift, slope, G, ns, C, out, argmax);
     return check_launch();
 }
@@ -994,6 +997,46 @@ TP3D_EXPORT int tp3d_interp_concat_fwd_f32(const float *feat_cl, const int64_t *
     else
         hipLaunchKernelGGL(interp_concat_fwd_kernel, dim3(grid_for(total)), dim3(RW_BLOCK), 0, (hipStream_t)stream,
                            feat_cl, idx, weight, skip_cl, m, n, C1, C2, ld, total, out);
+    return check_launch();
+}
+
+namespace tp3d {
+// Geometric relation vector of Relation-Shape convolution (reference modules/RSConv/dense.py:86-101), one row per
+// (centroid, neighbour) pair:  [ |d|, c_x c_y c_z, p_x p_y p_z, d_x d_y d_z, 0 .. ],  p = pos[b, idx], c = new_pos[b, j],
+// d = p - c, |d| = sqrt((dx*dx + dy*dy) + dz*dz).  One thread per row, ld = 12: three 16-byte stores.
+__global__ __launch_bounds__(RW_BLOCK) void relation_rows_kernel(const float *__restrict__ pos,
+                                                                  const float *__restrict__ new_pos,
+                                                                  const int64_t *__restrict__ idx, int N, int np, int ns,
+                                                                  int ld, int64_t rows, float *__restrict__ out)
+{
+    for (int64_t row = (int64_t)blockIdx.x * RW_BLOCK + threadIdx.x; row < rows; row += (int64_t)gridDim.x * RW_BLOCK) {
+        const int64_t bj = row / ns;
+        const int b = (int)(bj / np);
+        const int k = min(max((int)idx[row], 0), N - 1);
+        const float *p = pos + ((size_t)b * N + k) * 3, *c = new_pos + bj * 3;
+        const float px = p[0], py = p[1], pz = p[2], cx = c[0], cy = c[1], cz = c[2];
+        const float dx = px - cx, dy = py - cy, dz = pz - cz;
+        float v[12] = {sqrtf((dx * dx + dy * dy) + dz * dz), cx, cy, cz, px, py, pz, dx, dy, dz, 0.0f, 0.0f};
+        float *o = out + row * ld;
+        if (ld == 12 && ((uintptr_t)out & 15) == 0) {
+#pragma unroll
+            for (int q = 0; q < 3; ++q) reinterpret_cast<float4 *>(o)[q] = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+        } else {
+            for (int q = 0; q < ld; ++q) o[q] = q < 10 ? v[q] : 0.0f;
+        }
+    }
+}
+}  // namespace tp3d
+
+TP3D_EXPORT int tp3d_relation_rows_f32(const float *pos, const float *new_pos, const int64_t *idx, int B, int N, int np,
+                                       int ns, int ld, float *out, void *stream)
+{
+    if (B < 0 || N <= 0 || np < 0 || ns < 0 || ld < 10) return TP3D_E_BADARG;
+    const int64_t rows = (int64_t)B * np * ns;
+    if (rows == 0) return TP3D_OK;
+    if (!pos || !new_pos || !idx || !out) return TP3D_E_BADARG;
+    hipLaunchKernelGGL(relation_rows_kernel, dim3(grid_for(rows)), dim3(RW_BLOCK), 0, (hipStream_t)stream, pos, new_pos, idx,
+                       N, np, ns, ld, rows, out);
     return check_launch();
 }
 

@@ -118,7 +118,7 @@ def gemm_rows(A, Bt, want_stats=False):
 
 
 def _bn_stats(Y, M, C, gamma, beta, bn, training, dev, st, bias=None):
-    """(4, C) = mean, invstd, scale, shift of BatchNorm over the rows of Y.  In eval mode they depend only on the
+    """(4, C) = mean, invstd, scale = gamma * invstd, beta of BatchNorm over the rows of Y.  In eval mode they depend only on the
     module's parameters and running statistics, so they are computed once and reused until any of those changes."""
     key = None
     if not training:
@@ -134,8 +134,7 @@ def _bn_stats(Y, M, C, gamma, beta, bn, training, dev, st, bias=None):
               _lib.ptr(stats[2]), _lib.ptr(stats[3]), _lib.ptr(ws), st)
     if key is not None:
         if bias is not None:
-            stats[3].addcmul_(stats[2], bias.detach())  # shift += scale * bias: act(scale * (Y + b) + shift)
-            stats[0].sub_(bias.detach())                # yhat = (Y + b - running_mean) * invstd in the backward pass
+            stats[0].sub_(bias.detach())  # (Y + b - running_mean) * scale + beta == (Y - (running_mean - b)) * scale + beta
         bn._tp3d_eval_stats = (key, stats)
     return stats
 
@@ -189,12 +188,12 @@ class _LinearBNAct(torch.autograd.Function):
                 G = M // pool_ns
                 out = torch.empty((G, Cout), dtype=torch.float32, device=dev)
                 arg = torch.empty((G, Cout), dtype=torch.int32, device=dev)
-                _lib.call("tp3d_bn_act_maxpool_f32", _lib.ptr(Y), _lib.ptr(stats[2]), _lib.ptr(stats[3]), slope, G,
+                _lib.call("tp3d_bn_act_maxpool_f32", _lib.ptr(Y), _lib.ptr(stats[0]), _lib.ptr(stats[2]), _lib.ptr(stats[3]), slope, G,
                           pool_ns, Cout, _lib.ptr(out), _lib.ptr(arg), st)
             else:
                 arg = None
                 out = torch.empty((M, Cout), dtype=torch.float32, device=dev)
-                _lib.call("tp3d_bn_act_f32", _lib.ptr(Y), _lib.ptr(stats[2]), _lib.ptr(stats[3]), slope, M, Cout,
+                _lib.call("tp3d_bn_act_f32", _lib.ptr(Y), _lib.ptr(stats[0]), _lib.ptr(stats[2]), _lib.ptr(stats[3]), slope, M, Cout,
                           _lib.ptr(out), st)
         if training:
             bn.num_batches_tracked.add_(1)
@@ -235,29 +234,38 @@ class _LinearBNAct(torch.autograd.Function):
 
 class _BNAct(torch.autograd.Function):
     """out = LeakyReLU(BatchNorm(Y)) on rows (M, C): the BatchNorm + activation that follows a KPConv (SimpleBlock,
-    modules/KPConv/blocks.py:86-89) or any other row-major producer."""
+    modules/KPConv/blocks.py:86-89) or any other row-major producer; with pool_ns > 0 also the max over groups of
+    pool_ns consecutive rows (first maximum wins)."""
 
     @staticmethod
-    def forward(ctx, Y, gamma, beta, bn, slope):
+    def forward(ctx, Y, gamma, beta, bn, slope, pool_ns=0):
         dev = Y.device
         Y = Y.contiguous()
         M, C = Y.shape
         training = bn.training
-        out = torch.empty((M, C), dtype=torch.float32, device=dev)
         st = _lib.stream_ptr(dev)
+        arg = None
         with _lib.on_device(dev):
             stats = _bn_stats(Y, M, C, gamma, beta, bn, training, dev, st)  # mean, invstd, scale, shift
-            _lib.call("tp3d_bn_act_f32", _lib.ptr(Y), _lib.ptr(stats[2]), _lib.ptr(stats[3]), slope, M, C, _lib.ptr(out), st)
+            if pool_ns:
+                G = M // pool_ns
+                out = torch.empty((G, C), dtype=torch.float32, device=dev)
+                arg = torch.empty((G, C), dtype=torch.int32, device=dev)
+                _lib.call("tp3d_bn_act_maxpool_f32", _lib.ptr(Y), _lib.ptr(stats[0]), _lib.ptr(stats[2]), _lib.ptr(stats[3]), slope, G, pool_ns, C,
+                          _lib.ptr(out), _lib.ptr(arg), st)
+            else:
+                out = torch.empty((M, C), dtype=torch.float32, device=dev)
+                _lib.call("tp3d_bn_act_f32", _lib.ptr(Y), _lib.ptr(stats[0]), _lib.ptr(stats[2]), _lib.ptr(stats[3]), slope, M, C, _lib.ptr(out), st)
         if training:
             bn.num_batches_tracked.add_(1)
-        ctx.save_for_backward(Y, stats)
-        ctx.cfg = (slope, training)
+        ctx.save_for_backward(Y, stats, arg)
+        ctx.cfg = (slope, training, pool_ns)
         return out
 
     @staticmethod
     def backward(ctx, grad_out):
-        Y, stats = ctx.saved_tensors
-        slope, training = ctx.cfg
+        Y, stats, arg = ctx.saved_tensors
+        slope, training, pool_ns = ctx.cfg
         dev = grad_out.device
         grad_out = grad_out.contiguous()
         M, C = Y.shape
@@ -265,14 +273,27 @@ class _BNAct(torch.autograd.Function):
         dgb = torch.empty((2, C), dtype=torch.float32, device=dev)  # dbeta, dgamma
         ws = _lib.bn_workspace(M, C, dev)
         with _lib.on_device(dev):
-            _lib.call("tp3d_bn_act_bwd_f32", _lib.ptr(grad_out), None, _lib.ptr(Y), _lib.ptr(stats[2]), _lib.ptr(stats[3]),
-                      _lib.ptr(stats[0]), _lib.ptr(stats[1]), slope, M, 1, C, int(training), _lib.ptr(dgb[0]),
-                      _lib.ptr(dgb[1]), _lib.ptr(dY), _lib.ptr(ws), _lib.stream_ptr(dev))
-        return dY, dgb[1], dgb[0], None, None
+            _lib.call("tp3d_bn_act_bwd_f32", _lib.ptr(grad_out), _lib.ptr(arg), _lib.ptr(Y), _lib.ptr(stats[2]),
+                      _lib.ptr(stats[3]), _lib.ptr(stats[0]), _lib.ptr(stats[1]), slope, M, max(pool_ns, 1), C, int(training),
+                      _lib.ptr(dgb[0]), _lib.ptr(dgb[1]), _lib.ptr(dY), _lib.ptr(ws), _lib.stream_ptr(dev))
+        return dY, dgb[1], dgb[0], None, None, None
 
 
-def bn_act(Y, bn, slope):
-    return _BNAct.apply(Y, bn.weight, bn.bias, bn, slope)
+def bn_act(Y, bn, slope, pool_ns=0):
+    return _BNAct.apply(Y, bn.weight, bn.bias, bn, slope, pool_ns)
+
+
+def relation_rows(pos, new_pos, idx):
+    """(B*np*ns, 12) rows [ |d|, centroid xyz, neighbour xyz, d, 0, 0 ] of Relation-Shape convolution (no gradient:
+    positions are data)."""
+    dev = pos.device
+    B, N, _ = pos.shape
+    _, npnt, ns = idx.shape
+    out = torch.empty((B * npnt * ns, 12), dtype=torch.float32, device=dev)
+    with _lib.on_device(dev):
+        _lib.call("tp3d_relation_rows_f32", _lib.ptr(pos.contiguous()), _lib.ptr(new_pos.contiguous()),
+                  _lib.ptr(idx.contiguous()), B, N, npnt, ns, 12, _lib.ptr(out), _lib.stream_ptr(dev))
+    return out
 
 
 class _NbrMaxPool(torch.autograd.Function):
