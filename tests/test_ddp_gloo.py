@@ -130,3 +130,51 @@ def test_sharded_step_flat_allreduce(tmp_path):
     finally:
         torch.set_num_threads(nthreads)
     torch.testing.assert_close(res["grads"], (local[0] + local[1]) / 2, rtol=1e-5, atol=1e-6)
+
+
+def _unequal_seed_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from torch_points3d_amd.dp import ShardedStep
+    model = _make(seed=100 + rank)  # ranks build DIFFERENT initial weights ...
+    extra = torch.nn.Parameter(torch.ones(3))  # ... and one parameter the loss never reaches
+    model.register_parameter("unused_extra", extra)
+    with torch.no_grad():
+        for b in model.buffers():
+            if b.dtype.is_floating_point:
+                b.add_(float(rank))  # BatchNorm buffers differ as well
+    pos, x, y = _inputs()
+    sl = slice(rank * 2, rank * 2 + 2)
+    tr = ShardedStep(model, lambda ps: torch.optim.SGD(ps, lr=0.1),
+                     lambda: torch.nn.functional.cross_entropy(model(pos[sl], x[sl]), y[sl]), world_size=world,
+                     use_graph=False)
+    state = torch.cat([p.detach().reshape(-1) for p in model.parameters()] +
+                      [b.detach().reshape(-1).float() for b in model.buffers()])
+    gathered = [torch.zeros_like(state) for _ in range(world)]
+    dist.all_gather(gathered, state)
+    tr.step()  # must not raise on the unused parameter; its gradient is zero
+    weights = torch.cat([p.detach().reshape(-1) for p in model.parameters()])
+    after = [torch.zeros_like(weights) for _ in range(world)]
+    dist.all_gather(after, weights)
+    if rank == 0:
+        torch.save({"same_start": bool(torch.equal(gathered[0], gathered[1])),
+                    "same_after": bool(torch.equal(after[0], after[1])),
+                    "extra_unchanged": bool(torch.equal(model.unused_extra.detach(), torch.ones(3)))}, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_step_synchronises_replicas_and_tolerates_unused_parameters(tmp_path):
+    """ranks seeded differently must still start from rank 0's parameters and buffers (DDP broadcasts at construction;
+    averaging gradients of mismatched replicas trains none of them)"""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = str(tmp_path / "r0.pt")
+    mp.spawn(_unequal_seed_worker, args=(2, port, out), nprocs=2, join=True)
+    res = torch.load(out, weights_only=True)
+    assert res["same_start"], "replicas differ after ShardedStep construction"
+    assert res["same_after"], "replicas diverged after one step"
+    assert res["extra_unchanged"]

@@ -2,6 +2,7 @@
 
 There is no CPU fallback: if the library is missing or a call fails, the error is raised to the caller.
 """
+import collections
 import ctypes
 import os
 
@@ -206,17 +207,27 @@ class on_device(object):
         return False
 
 
-_ws_cache = {}
+_ws_cache = {}    # (device, stream, purpose) -> [buffer, handed out during a stream capture]
+_ws_retired = []  # buffers a captured graph may still point at: replaced, never freed
 
 
 def workspace(tag, nbytes, device):
     """Grow-only scratch buffer per (device, stream, purpose).  Kernels of one stream run in order and every entry
-    point consumes its workspace before returning control to the stream's next kernel, so reuse is safe."""
+    point consumes its workspace before returning control to the stream's next kernel, so reuse is safe.
+
+    A buffer handed out while the stream is being captured has its ADDRESS baked into the graph: it is never freed
+    afterwards (a larger request retires it to `_ws_retired` instead of dropping it), because torch's capture stream is
+    shared between graphs and a replay would otherwise write into memory the allocator has given to someone else."""
     key = (device.index, _raw_stream(device), tag)
-    buf = _ws_cache.get(key)
-    if buf is None or buf.numel() < nbytes:
-        buf = _ws_cache[key] = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
-    return buf
+    capturing = device.type == "cuda" and torch.cuda.is_current_stream_capturing()
+    slot = _ws_cache.get(key)
+    if slot is None or slot[0].numel() < nbytes:
+        if slot is not None and slot[1]:
+            _ws_retired.append(slot[0])
+        slot = _ws_cache[key] = [torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device), False]
+    if capturing:
+        slot[1] = True
+    return slot[0]
 
 
 def _raw_stream(device):
@@ -243,7 +254,19 @@ def ball_query_workspace(num_clouds, rows, max_cloud_points, device):
     return workspace("grid", nbytes, device), nbytes
 
 
-_inverse_cache = {}
+_inverse_cache = collections.OrderedDict()  # key -> [nbr, buffer, nbytes, event, stream, pinned]
+INVERSE_CACHE_ENTRIES = 48
+
+
+def _evict_inverse():
+    """drop least-recently-used tables beyond the limit; a table a captured graph reads (pinned) is never dropped"""
+    if len(_inverse_cache) < INVERSE_CACHE_ENTRIES:
+        return
+    for key in list(_inverse_cache):
+        if len(_inverse_cache) < INVERSE_CACHE_ENTRIES:
+            break
+        if not _inverse_cache[key][5]:
+            del _inverse_cache[key]
 
 
 def neighbour_inverse(nbr, M, device):
@@ -254,22 +277,25 @@ def neighbour_inverse(nbr, M, device):
     reads it).  The entry keeps `nbr` alive, so an equal address means the same storage and an equal version counter
     the same content.  ready == 0: the caller's kernel builds the table; it then calls inverse_built(token).
     A table built on another stream is waited for through its event; inside a stream capture the caller is expected
-    to have synchronised after warm-up (torch.cuda.graph does)."""
+    to have synchronised after warm-up (torch.cuda.graph does).  A table handed to a capture is PINNED: the graph
+    replays read its address, so it is exempt from eviction; the others are evicted least recently used first."""
     key = (nbr.data_ptr(), nbr._version, tuple(nbr.shape), int(M), device.index)
     hit = _inverse_cache.get(key)
     cur = _raw_stream(device)
     capturing = torch.cuda.is_current_stream_capturing()
     if hit is not None and hit[3] is not None:
-        if hit[4] != cur and not capturing:
+        _inverse_cache.move_to_end(key)
+        if capturing:
+            hit[5] = True
+        elif hit[4] != cur:
             torch.cuda.current_stream(device).wait_event(hit[3])
         return hit[1], hit[2], 1, None
     nbytes = load().tp3d_kpconv_bwd_workspace_bytes(int(M), nbr.numel())
     if capturing:  # never publish a table whose build is only a node of a graph being recorded
         return workspace("nbr_inverse", nbytes, device), nbytes, 0, None
     buf = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
-    if len(_inverse_cache) >= 48:
-        _inverse_cache.clear()
-    _inverse_cache[key] = [nbr, buf, nbytes, None, cur]
+    _evict_inverse()
+    _inverse_cache[key] = [nbr, buf, nbytes, None, cur, False]
     return buf, nbytes, 0, key
 
 

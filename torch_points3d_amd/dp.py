@@ -10,7 +10,8 @@ The two bracketed phases are pure device work on static tensors, so each is capt
 replayed (no per-launch host cost); the collective runs between them as a normal RCCL call on the same stream.
 The model has 1.38 M parameters (5.5 MB): a single all-reduce of ~50-100 us per ~12 ms step, so overlapping it
 with backward (what DDP's bucketing buys) is not worth giving up graph replay for.
-BatchNorm statistics stay per rank (the reference has no SyncBN).
+BatchNorm statistics stay per rank (the reference has no SyncBN).  At construction every rank receives rank 0's
+parameters and buffers, so replicas that were seeded differently still start identical.
 """
 import torch
 import torch.distributed as dist
@@ -59,20 +60,35 @@ class ShardedStep(object):
             if flatten_params:
                 p.data = self.flat_param.data[off:off + n].view_as(p)  # the model reads the optimizer's tensor
             p.grad = self.flat[off:off + n].view_as(p)  # (per-parameter optimizers read these views)
+        if world_size > 1:
+            self._sync_replicas()
         self.opt = make_optimizer([self.flat_param] if flatten_params else params)
         self.graph_fb = None
         self.graph_opt = None
         self.graphed = False
         self._want_graph = use_graph and dev.type == "cuda"
 
+    def _sync_replicas(self):
+        """Every rank starts from rank 0's parameters and buffers (what DistributedDataParallel does at construction):
+        averaging gradients of replicas that were initialised differently would train none of them."""
+        with torch.no_grad():
+            if self.flat_param is not None:
+                dist.broadcast(self.flat_param.data, src=0)
+            else:
+                for p in self.params:
+                    dist.broadcast(p.data, src=0)
+            for b in self.model.buffers():
+                dist.broadcast(b, src=0)
+
     # -- phases ------------------------------------------------------------------------------------------
     def _forward_backward(self):
         loss = self.loss_fn()
         # fresh gradient tensors (no per-parameter "+=" kernels), packed into the flat buffer by one concatenation
-        grads = torch.autograd.grad(loss, self.params)
+        grads = torch.autograd.grad(loss, self.params, allow_unused=True)
         pieces = []
-        for g, pad in zip(grads, self._pads):
-            pieces.append(g.reshape(-1))
+        for g, p, pad in zip(grads, self.params, self._pads):
+            # a parameter the loss does not reach gets a zero gradient (DDP: find_unused_parameters)
+            pieces.append(g.reshape(-1) if g is not None else torch.zeros(p.numel(), dtype=torch.float32, device=p.device))
             if pad.numel():
                 pieces.append(pad)
         torch.cat(pieces, out=self.flat)
