@@ -35,7 +35,7 @@ extern "C" {
 #define TP3D_E_UNSORTED (-3) /* reserved: batch vector not sorted (checked by the host wrapper) */
 #define TP3D_E_TOOBIG (-4)   /* size exceeds what the kernel's index arithmetic supports */
 
-#define TP3D_ABI_VERSION 20
+#define TP3D_ABI_VERSION 21
 
 int tp3d_abi_version(void);
 const char *tp3d_strerror(int code);
@@ -165,6 +165,12 @@ int tp3d_bn_act_maxpool_f32(const float *Y, const float *mean, const float *scal
 int tp3d_bn_act_bwd_f32(const float *dA, const int *argmax, const float *Y, const float *scale, const float *shift,
                         const float *mean, const float *invstd, float slope, int64_t M, int ns, int C, int training,
                         float *dbeta, float *dgamma, float *dY, float *workspace, void *stream);
+/* Only the reductions of that backward pass: dbeta, dgamma (C) and the two per-channel terms the fused GEMMs
+ * (tp3d_gemm_rows_bnbwd_f32, tp3d_gemm_tn_bn_f32) subtract while they form dY:  c1 = dbeta / M,  c2 = invstd * dgamma / M
+ * (both zero with training == 0).  Same arguments and workspace as tp3d_bn_act_bwd_f32, no dY. */
+int tp3d_bn_bwd_reduce_f32(const float *dA, const int *argmax, const float *Y, const float *scale, const float *shift,
+                           const float *mean, const float *invstd, float slope, int64_t M, int ns, int C, int training,
+                           float *dbeta, float *dgamma, float *c1, float *c2, float *workspace, void *stream);
 
 /* out[(b,i), :] = [ (w0*f0 + w1*f1) + w2*f2 , skip_cl[b,i,0:C2], 0.. ],  f_t = feat_cl[b, idx[b,i,t], 0:C1]
  * feat_cl (B,m,C1), idx/weight (B,n,3), skip_cl (B,n,C2) or NULL -> out (B*n, ld), ld >= C1+C2 (zero padded). */
@@ -172,15 +178,31 @@ int tp3d_interp_concat_fwd_f32(const float *feat_cl, const int64_t *idx, const f
                                int B, int m, int n, int C1, int C2, int ld, float *out, void *stream);
 
 /* Tall-skinny GEMM of a shared-MLP layer, fp32 MFMA:  C[M,N] = A[M,K] * Bt[N,K]^T  (row-major, K % 4 == 0).
- * Forward: A = rows, Bt = W exactly as nn.Conv2d stores it (Cout x Cin).  With stat_partial != NULL the epilogue also writes
- * partial column sums and sums of squares of C: stat_partial[chunk][2][N], chunk < tp3d_gemm_rows_stat_chunks(M, N)
- * (one row per 128-row block, or one per persistent workgroup when the launch fills the grid; the buffer holds
- * tp3d_gemm_rows_stat_floats(M, N) floats), which tp3d_bn_finalize_f32 turns into the BatchNorm statistics --
- * the separate statistics pass over C (tp3d_bn_stats_f32) is then not needed. */
+ * Forward: A = rows, Bt = W exactly as nn.Conv2d stores it (Cout x Cin).  With stat_partial != NULL the epilogue also
+ * writes shifted partial column sums of C: stat_partial[chunk][4][N] = sum d, sum d^2 (d = value - shift), shift, rows;
+ * chunk < tp3d_gemm_rows_stat_chunks(M, N); the buffer holds tp3d_gemm_rows_stat_floats(M, N) floats;
+ * tp3d_bn_finalize_f32 turns them into the BatchNorm statistics -- no separate statistics pass over C.
+ * Without statistics and with `workspace` (tp3d_gemm_rows_workspace_floats(M, N, K) floats, 0 = not needed) a long
+ * contraction with few output tiles is split over K-ranges into partial slabs summed in fixed order. */
 size_t tp3d_gemm_rows_stat_floats(int64_t M, int N);
 int tp3d_gemm_rows_stat_chunks(int64_t M, int N);
+size_t tp3d_gemm_rows_workspace_floats(int64_t M, int N, int K);
 int tp3d_gemm_rows_f32(const float *A, const float *Bt, int64_t M, int N, int K, float *C, float *stat_partial,
-                       void *stream);
+                       float *workspace, void *stream);
+/* The same contraction with the BatchNorm + activation of the PREVIOUS layer applied to the A operand while it is
+ * staged (core/common_modules/dense_modules.py:25-29: layer l+1 consumes LeakyReLU(BatchNorm(Y_l))): Y (M,K) is that
+ * layer's pre-BatchNorm output, mean / scale / beta (K) its statistics rows; the activated tensor is never written.
+ * K <= 1536. */
+int tp3d_gemm_rows_bnact_f32(const float *Y, const float *mean, const float *scale, const float *beta, float slope,
+                             const float *Bt, int64_t M, int N, int K, float *C, float *stat_partial, void *stream);
+/* Input-gradient GEMM of a layer with its BatchNorm + activation BACKWARD applied to the A operand while it is staged:
+ *   C[M,N] = dY[M,K] * Bt[N,K]^T,  dY = scale*(dZ - c1 - (Y - mean)*c2),  dZ = dA * act'((Y - mean)*scale + beta)
+ * Y (M,K) pre-BatchNorm output of the layer, dA (M,K) gradient of its activated output -- or, with argmax != NULL, the
+ * gradient (M/ns, K) of its max-pooled output and the winning rows; c1, c2 (K) from tp3d_bn_bwd_reduce_f32.
+ * Bt (N,K) = W^T of the layer (N = its input width).  dY is never written.  K <= 1536. */
+int tp3d_gemm_rows_bnbwd_f32(const float *Y, const float *dA, const int *argmax, int ns, const float *mean,
+                             const float *scale, const float *beta, const float *c1, const float *c2, float slope,
+                             const float *Bt, int64_t M, int N, int K, float *C, void *stream);
 int tp3d_bn_finalize_f32(const float *partial, int chunks, int64_t M, int C, float eps, float momentum,
                          const float *gamma, const float *beta, float *running_mean, float *running_var, float *mean,
                          float *invstd, float *scale, float *shift, void *stream);
@@ -191,6 +213,17 @@ int tp3d_bn_finalize_f32(const float *partial, int chunks, int64_t M, int C, flo
 size_t tp3d_gemm_tn_workspace_floats(int64_t M, int N, int K);
 int tp3d_gemm_tn_f32(const float *dY, const float *A, int64_t M, int N, int K, float *out, float *workspace,
                      void *stream);
+/* The same weight gradient with both operands formed while they are staged, so that neither the BatchNorm-backward
+ * result dY nor the activated layer input has to exist in HBM (autograd of dense_modules.py:25-29):
+ *   dY = scale_n*(dZ - c1_n - (Y - mean_n)*c2_n), dZ = dA * act'((Y - mean_n)*scale_n + beta_n)
+ *        Y (M,N) pre-BatchNorm output, dA (M,N) -- or (M/ns,N) with argmax (M/ns,N) != NULL for a max-pooled output;
+ *   A  = LeakyReLU_slope_k((A - mean_k)*scale_k + beta_k) when mean_k != NULL (A = the previous layer's pre-BatchNorm
+ *        output), else A as it is.
+ * N % 4 == 0, K % 4 == 0; workspace as for tp3d_gemm_tn_f32. */
+int tp3d_gemm_tn_bn_f32(const float *Y, const float *dA, const int *argmax, int ns, const float *mean_n,
+                        const float *scale_n, const float *beta_n, const float *c1_n, const float *c2_n, float slope_n,
+                        const float *A, const float *mean_k, const float *scale_k, const float *beta_k, float slope_k,
+                        int64_t M, int N, int K, float *out, float *workspace, void *stream);
 
 /* KPConv rigid convolution, stage 1 (reference modules/KPConv/convolution_ops.py:19-98):
  *   weighted[q, k, :] = sum_n h(|(support[nbr[q,n]] - query[q]) - k_points[k]|) * features[nbr[q,n], :]
@@ -326,8 +359,9 @@ int tp3d_nbr_maxpool_bwd_f32(const float *grad_out, const int32_t *argmax, const
 /* plan[8]: splits, rows per split, tile rows (N side), tile columns (K side), tiles, rows staged per step,
  * workspace floats written, first row of the last split */
 int tp3d_gemm_tn_plan(int64_t M, int N, int K, int64_t *plan);
-/* plan[6]: column tiles, row blocks, work items, workgroups, statistics rows written, 1 = one row per workgroup */
-int tp3d_gemm_rows_plan(int64_t M, int N, int64_t *plan);
+/* plan[9]: column tiles, row blocks, work items, workgroups, statistics chunks written, 1 = one chunk set per
+ * workgroup, wave rows per tile, K-ranges of a split launch (K = 0: not asked), tile columns */
+int tp3d_gemm_rows_plan(int64_t M, int N, int K, int64_t *plan);
 /* plan[3]: rows per chunk, chunks, workspace floats written by tp3d_bn_stats_f32 (pooled_ns = 0) or
  * tp3d_bn_act_bwd_f32 (pooled_ns = its ns; 1 for the dense form) */
 int tp3d_bn_plan(int64_t M, int C, int pooled_ns, int64_t *plan);

@@ -227,26 +227,31 @@ def test_gemm_rows_matches_fp64_and_stats(M, N, K):
     err = float((C.double() - ref).abs().max())
     lib = float((torch.mm(A, Bm).double() - ref).abs().max())
     assert err <= max(2.0 * lib, 1e-5 * float(ref.abs().max())), (err, lib)
+    # without statistics a long contraction with few tiles runs K-split (two-level summation): at least as accurate
+    Cs, _ = fused.gemm_rows(A, Bm.t().contiguous())
+    assert float((Cs.double() - ref).abs().max()) <= max(1.5 * err, 1e-6 * float(ref.abs().max()))
     from torch_points3d_amd import _lib
     # statistics chunks: one per (128-row block, wave row) or per (persistent workgroup, wave row); each holds four rows
     # of N: sum d, sum d^2 (d = value - shift), the shift, and the number of matrix rows that went into it
     chunks = _lib.load().tp3d_gemm_rows_stat_chunks(M, N)
-    assert chunks == 2 * ((M + 127) // 128) or chunks == 2 * (1024 // ((N + 127) // 128))
+    wave_rows = 4 if 0 < N % 128 <= 64 else 2  # 128 x 64 tiles (4 wave rows) for such widths, else 128 x 128 (2)
+    tiles_n = -(-N // (64 if wave_rows == 4 else 128))
+    assert chunks == wave_rows * ((M + 127) // 128) or chunks == wave_rows * (1024 // tiles_n)
     assert part.numel() >= chunks * 4 * N * 4
     p = part[: chunks * 4 * N * 4].view(torch.float32).view(chunks, 4, N).double()
-    S, Q, K, n = p[:, 0], p[:, 1], p[:, 2], p[:, 3]
+    S, Q, Ks, n = p[:, 0], p[:, 1], p[:, 2], p[:, 3]
     assert float(n[:, 0].sum()) == M and bool((n == n[:, :1]).all())
-    mean = (n * K + S).sum(0) / M
+    mean = (n * Ks + S).sum(0) / M
     torch.testing.assert_close(mean, ref.mean(0), rtol=1e-5, atol=1e-5 * float(ref.abs().max()))
     live = n > 0
-    mk = torch.where(live, K + S / n.clamp(min=1), torch.zeros_like(K))
+    mk = torch.where(live, Ks + S / n.clamp(min=1), torch.zeros_like(Ks))
     m2 = (torch.where(live, Q - S * S / n.clamp(min=1), torch.zeros_like(Q)) + n * (mk - mean) ** 2).sum(0)
     torch.testing.assert_close(m2 / M, ref.var(0, unbiased=False), rtol=2e-5, atol=1e-6)
     # the statistics rows end exactly at chunks*4*N floats: a guard band behind them must stay untouched
     guard = torch.full((chunks * 4 * N + 8 * 2 * N,), 7.0, device=DEV)
     C2 = torch.empty_like(C)
     _lib.call("tp3d_gemm_rows_f32", A.data_ptr(), Bm.t().contiguous().data_ptr(), M, N, K_, C2.data_ptr(), guard.data_ptr(),
-              _lib.stream_ptr(A.device))
+              None, _lib.stream_ptr(A.device))
     assert torch.equal(C2, C) and bool((guard[chunks * 4 * N:] == 7.0).all())
     # exact integer data: any operand / accumulator layout mix-up shows up as a wrong integer
     Ai = torch.randint(-3, 4, (M, K), generator=g).float().to(DEV)
@@ -293,3 +298,50 @@ def test_rows_mlp_with_linear_bias_matches_modules(train):
             continue
         scale = float(b.grad.abs().max()) + 1e-6
         torch.testing.assert_close(a.grad, b.grad, rtol=1e-3, atol=1e-4 * scale + 1e-5, msg=lambda m, k=k: k + ": " + m)
+
+
+@pytest.mark.parametrize("pool_ns", [0, 16])
+@pytest.mark.parametrize("widths", [[8, 64, 64, 128], [132, 128, 128, 256], [12, 32, 96, 196], [260, 64]])
+@pytest.mark.parametrize("train", [True, False])
+def test_mlp_chain_matches_layerwise_path(widths, pool_ns, train):
+    """The fused layer chain (BatchNorm / activation folded into the GEMM prologues, statistics in the epilogues,
+    dY and the activated inputs never written) against the layer-by-layer kernels it replaces: same outputs, same
+    gradients for the input rows and every parameter, same running statistics."""
+    import copy
+    from torch_points3d_amd import fused
+    from torch_points3d_amd.dense import MLP2D
+    torch.manual_seed(3)
+    mlp = MLP2D(widths).to(DEV)
+    with torch.no_grad():
+        for m in mlp.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.weight.uniform_(0.5, 1.5)
+                m.bias.normal_(0, 0.3)
+                m.running_mean.normal_()
+                m.running_var.uniform_(0.5, 2.0)
+    twin = copy.deepcopy(mlp)
+    mlp.train(train)
+    twin.train(train)
+    M = 4000 if pool_ns == 0 else 250 * pool_ns + 0
+    rows = torch.randn(M, widths[0], generator=torch.Generator().manual_seed(5)).to(DEV)
+    ra, rb = rows.clone().requires_grad_(True), rows.clone().requires_grad_(True)
+    cot = torch.randn((M // pool_ns) if pool_ns else M, widths[-1], generator=torch.Generator().manual_seed(6)).to(DEV)
+    old = fused.CHAIN_MIN_ROWS
+    try:
+        fused.CHAIN_MIN_ROWS = 0
+        assert fused._chain_ok(ra, fused.mlp_parts(mlp))
+        out = fused.run_mlp(ra, fused.mlp_parts(mlp), pool_ns)
+        fused.CHAIN_MIN_ROWS = 1 << 60
+        want = fused.run_mlp(rb, fused.mlp_parts(twin), pool_ns)
+    finally:
+        fused.CHAIN_MIN_ROWS = old
+    torch.testing.assert_close(out, want, rtol=1e-5, atol=1e-5)
+    out.backward(cot)
+    want.backward(cot)
+    # a LeakyReLU mask can flip on a last-bit forward difference between the two paths (different GEMM kernels for the
+    # narrow layers): bound the bulk tightly, allow isolated outliers through the L2 norm
+    assert float((ra.grad - rb.grad).norm() / rb.grad.norm()) < 1e-3
+    for (k, a), (_, b) in zip(mlp.named_parameters(), twin.named_parameters()):
+        assert float((a.grad - b.grad).norm() / (b.grad.norm() + 1e-12)) < 1e-3, k
+    for (k, a), (_, b) in zip(mlp.state_dict().items(), twin.state_dict().items()):
+        torch.testing.assert_close(a.float(), b.float(), rtol=1e-5, atol=1e-6, msg=lambda m, k=k: k + ": " + m)

@@ -45,17 +45,34 @@ def test_gemm_rows_plan_fits_its_statistics_buffer():
     h = _lib.load()
     for M in ROWS:
         for N in CHANNELS:
-            tiles_n, row_blocks, items, blocks, chunks, per_wg = _plan("tp3d_gemm_rows_plan", 6, M, N)
+            tiles_n, row_blocks, items, blocks, chunks, per_wg, wave_rows, _, bn = _plan("tp3d_gemm_rows_plan", 9, M, N, 0)
             floats = h.tp3d_gemm_rows_stat_floats(M, N)
             assert chunks == h.tp3d_gemm_rows_stat_chunks(M, N)
             assert chunks * 4 * N <= floats, (M, N)  # per chunk: sum d, sum d^2, shift, rows
+            assert bn in (64, 128) and wave_rows == (2 if bn == 128 else 4) and tiles_n * bn >= N > (tiles_n - 1) * bn
             assert row_blocks * 128 >= M and items >= row_blocks * tiles_n and blocks <= 1024
             if per_wg:
-                # statistics chunks of workgroup w: 2 * ((w // (8*tiles_n)) * 8 + (w & 7)) + wave row
+                # statistics chunks of workgroup w: wave_rows * ((w // (8*tiles_n)) * 8 + (w & 7)) + wave row
                 assert blocks == 1024 and 1024 % (8 * tiles_n) == 0
-                assert max(2 * ((w // (8 * tiles_n)) * 8 + (w & 7)) + 1 for w in range(blocks)) == chunks - 1
+                top = max(wave_rows * ((w // (8 * tiles_n)) * 8 + (w & 7)) + wave_rows - 1 for w in range(blocks))
+                assert top == chunks - 1
             else:
-                assert chunks == 2 * row_blocks  # one per (128-row block, wave row)
+                assert chunks == wave_rows * row_blocks  # one per (128-row block, wave row)
+
+
+def test_gemm_rows_k_split_fits_its_slabs():
+    h = _lib.load()
+    for M in ROWS:
+        for N, K in itertools.product(CHANNELS, [4, 32, 128, 256, 260, 384, 512, 516, 1024, 1280, 1536]):
+            if M * N > (1 << 28):
+                continue
+            ksplit = _plan("tp3d_gemm_rows_plan", 9, M, N, K)[7]
+            floats = h.tp3d_gemm_rows_workspace_floats(M, N, K)
+            assert (floats == 0) == (ksplit == 1), (M, N, K)
+            if ksplit > 1:
+                assert floats == ksplit * M * N and 2 <= ksplit <= 16
+                kchunk = -(-(-(-K // ksplit)) // 32) * 32
+                assert (ksplit - 1) * kchunk < K <= ksplit * kchunk  # every K-range starts inside the contraction
 
 
 @pytest.mark.parametrize("pooled_ns", [0, 1, 2, 16, 24, 32, 64, 128, 512])

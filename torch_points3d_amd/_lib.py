@@ -35,7 +35,11 @@ SIGNATURES = {
     "tp3d_interp_concat_fwd_f32": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _p],
     "tp3d_idw_weights_f32": [_p, _l, _p, _p],
     "tp3d_gemm_tn_f32": [_p, _p, _l, _i, _i, _p, _p, _p],
-    "tp3d_gemm_rows_f32": [_p, _p, _l, _i, _i, _p, _p, _p],
+    "tp3d_gemm_tn_bn_f32": [_p, _p, _p, _i, _p, _p, _p, _p, _p, _f, _p, _p, _p, _p, _f, _l, _i, _i, _p, _p, _p],
+    "tp3d_bn_bwd_reduce_f32": [_p, _p, _p, _p, _p, _p, _p, _f, _l, _i, _i, _i, _p, _p, _p, _p, _p, _p],
+    "tp3d_gemm_rows_f32": [_p, _p, _l, _i, _i, _p, _p, _p, _p],
+    "tp3d_gemm_rows_bnact_f32": [_p, _p, _p, _p, _f, _p, _l, _i, _i, _p, _p, _p],
+    "tp3d_gemm_rows_bnbwd_f32": [_p, _p, _p, _i, _p, _p, _p, _p, _p, _f, _p, _l, _i, _i, _p, _p],
     "tp3d_bn_finalize_f32": [_p, _i, _l, _i, _f, _f, _p, _p, _p, _p, _p, _p, _p, _p, _p],
     "tp3d_kpconv_bwd_features_f32": [_p, _p, _p, _p, _p, _l, _l, _i, _i, _i, _f, _i, _i, _p, _p, ctypes.c_size_t, _i, _p,
                                      ctypes.c_size_t, _p],
@@ -56,14 +60,14 @@ SIGNATURES = {
     "tp3d_relation_rows_f32": [_p, _p, _p, _i, _i, _i, _i, _i, _p, _p],
     # launch plans (host arithmetic; the last argument is a HOST int64 array)
     "tp3d_gemm_tn_plan": [_l, _i, _i, _p],
-    "tp3d_gemm_rows_plan": [_l, _i, _p],
+    "tp3d_gemm_rows_plan": [_l, _i, _i, _p],
     "tp3d_bn_plan": [_l, _i, _i, _p],
     "tp3d_scatter_plan": [_i, _i, _i, _i, _p],
 }
 MISC = ("tp3d_abi_version", "tp3d_strerror", "tp3d_last_hip_error", "tp3d_scatter_workspace_bytes",
         "tp3d_bn_workspace_floats", "tp3d_gemm_tn_workspace_floats", "tp3d_ball_query_workspace_bytes",
-        "tp3d_gemm_rows_stat_floats", "tp3d_gemm_rows_stat_chunks", "tp3d_kpconv_bwd_workspace_bytes", "tp3d_voxel_workspace_bytes", "tp3d_knn_workspace_bytes", "tp3d_kpconv_grad_workspace_bytes")
-ABI_VERSION = 20
+        "tp3d_gemm_rows_stat_floats", "tp3d_gemm_rows_stat_chunks", "tp3d_gemm_rows_workspace_floats", "tp3d_kpconv_bwd_workspace_bytes", "tp3d_voxel_workspace_bytes", "tp3d_knn_workspace_bytes", "tp3d_kpconv_grad_workspace_bytes")
+ABI_VERSION = 21
 
 _handle = None
 
@@ -107,6 +111,8 @@ def load():
     h.tp3d_gemm_rows_stat_floats.argtypes = [_l, _i]
     h.tp3d_gemm_rows_stat_chunks.restype = ctypes.c_int
     h.tp3d_gemm_rows_stat_chunks.argtypes = [_l, _i]
+    h.tp3d_gemm_rows_workspace_floats.restype = ctypes.c_size_t
+    h.tp3d_gemm_rows_workspace_floats.argtypes = [_l, _i, _i]
     h.tp3d_kpconv_grad_workspace_bytes.restype = ctypes.c_size_t
     h.tp3d_kpconv_grad_workspace_bytes.argtypes = [_l, _l, _i]
     h.tp3d_knn_workspace_bytes.restype = ctypes.c_size_t

@@ -1,18 +1,32 @@
-// Tall-skinny fp32 GEMM of the shared MLPs with the BatchNorm statistics fused into its epilogue:
-//     C[M,N] = A[M,K] * Bt[N,K]^T       M = B*npoint*nsample rows (up to ~1e6), N, K <= ~1300, K contiguous in both
-//     stats (optional): per column, sum and sum of squares of C in `chunks` partial rows -> tp3d_bn_finalize_f32
-//     (one row per 128-row block; launches that fill the persistent grid keep one running row per workgroup instead:
-//     1024 / tiles_n rows whatever M is, so the finalize pass stays small)
-// Forward pass:  Y = rows @ W^T   (Bt = W as stored: Cout x Cin)  + column statistics of Y (saves a full read of Y)
-// Reference semantics: Conv2d 1x1 (bias=False) followed by BatchNorm2d in training mode
+// Tall-skinny fp32 GEMM of the shared MLPs, with the neighbouring BatchNorm / activation passes folded into it:
+//     C[M,N] = op(A)[M,K] * Bt[N,K]^T       M = B*npoint*nsample rows (up to ~1e6), N, K <= ~1500, K contiguous in both
+//
+// op (the A-operand PROLOGUE, applied while a tile is staged into LDS -- the transformed matrix never exists in HBM):
+//     PRO_NONE    a = A[m,k]
+//     PRO_BNACT   a = LeakyReLU((Y[m,k] - mean[k]) * scale[k] + beta[k])        forward: A is the previous layer's
+//                                                                               pre-BatchNorm output Y
+//     PRO_BNBWD   a = scale[k] * (dz - c1[k] - (Y[m,k] - mean[k]) * c2[k]),     input-gradient GEMM: the BatchNorm +
+//                 dz = dA[m,k] * act'((Y[m,k] - mean[k]) * scale[k] + beta[k])  activation backward of the layer whose
+//     PRO_BNBWD_POOL  same with dA[m,k] = (argmax[g,k] == m - g*ns) ? dP[g,k] : 0, g = m / ns  (max-pooled output)
+//                                                                               gradient dY this GEMM contracts
+// EPILOGUE (STATS): per column, shifted sums of C in `chunks` partial rows -> tp3d_bn_finalize_f32
+//     (one chunk per (128-row block, wave row); launches that fill the persistent grid keep one running chunk per
+//     (workgroup, wave row) instead: wave_rows*1024/tiles_n chunks whatever M is, so the finalize pass stays small)
+// Reference semantics: Conv2d 1x1 (bias=False) -> BatchNorm2d (training) -> LeakyReLU, forward and autograd backward
 // (torch_points3d/core/common_modules/dense_modules.py:5-12,25-29).
 //
-// 4 waves per workgroup as 2x2, each wave 2x2 MFMA tiles of 32x32 (v_mfma_f32_32x32x2_f32, exact fp32): a 128 x 128
-// output tile per workgroup, K walked in steps of 32 through LDS, the global loads of step i+1 in flight during the
-// MFMAs of step i.  Both operands are staged as [row][k] with a 36-float pitch: float4 stores stay aligned and the
-// ds_read_b128 operand fetch (lane = row) is bank-conflict free (36*r mod 64 hits 16 disjoint 4-bank slots).
+// 4 waves per workgroup; two tile shapes: 128 x 128 (waves 2 x 2, each 2 x 2 MFMA tiles of 32 x 32) and 128 x 64 (waves
+// 4 x 1, each 1 x 2 tiles) for layers of 64 or fewer output columns (or whose width leaves such a remainder).
+// v_mfma_f32_32x32x2_f32, exact fp32.  K is walked in steps of 32 through LDS, the global loads of step i+1 in flight
+// during the MFMAs of step i; both operands are staged as [row][k] with a 36-float pitch: float4 stores stay aligned and
+// the ds_read_b128 operand fetch (lane = row) is bank-conflict free (36*r mod 64 hits 16 disjoint 4-bank slots).
 // Which physical k feeds which MFMA k-slot is free as long as A and B agree: in every group of 8 k's the lower
 // half-wave takes k0..k0+3 and the upper half-wave k0+4..k0+7, so one 16-byte LDS read feeds four MFMAs.
+// Long contractions with few output tiles (the 4096-row global / decoder layers, K up to 1536) are split over
+// gridDim.y K-ranges into partial slabs that a second kernel sums in fixed order: more workgroups, and a two-level
+// summation whose round-off is ~3x smaller than one sequential chain over K.
+#include <algorithm>
+
 #include "tp3d_common.h"
 
 namespace tp3d {
@@ -20,23 +34,60 @@ namespace tp3d {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int GR_BLOCK_T = 256;
-constexpr int GR_BM = 128, GR_BN = 128, GR_BK = 32;
+constexpr int GR_BM = 128, GR_BK = 32;
 constexpr int GR_LD = GR_BK + 4;  // 36-float pitch
+constexpr int GR_PRO_KMAX = 1536;  // widest contraction a prologue's per-channel constants are staged for
 
-// STATS: 0 none, 1 one statistics row per 128-row block, 2 one row per workgroup (needs gridDim.x % (8*tiles_n) == 0:
-// every item of a workgroup then lies in the same column tile)
-template <int STATS>
-__global__ __launch_bounds__(GR_BLOCK_T) void gemm_rows_kernel(const float *__restrict__ A, const float *__restrict__ Bt,
-                                                                int64_t M, int N, int K, int tiles_n, int64_t items,
-                                                                float *__restrict__ C, float *__restrict__ partial)
+enum { PRO_NONE = 0, PRO_BNACT = 1, PRO_BNBWD = 2, PRO_BNBWD_POOL = 3 };
+
+// what a prologue reads besides A (all per channel k of the contraction; layouts as tp3d_bn_* produce them)
+struct GemmPrologue {
+    const float *mean, *scale, *beta;  // BatchNorm statistics rows of the layer A belongs to
+    const float *c1, *c2;              // PRO_BNBWD*: dbeta / M and invstd * dgamma / M (zeros in eval mode)
+    const float *dA;                   // PRO_BNBWD: gradient wrt the activation (M, K); PRO_BNBWD_POOL: dP (M/ns, K)
+    const int *argmax;                 // PRO_BNBWD_POOL: (M/ns, K) winning row of each group
+    float slope;
+    int ns;
+};
+
+// WIDE: 128 x 128 tile, else 128 x 64.  STATS: 0 none, 1 one statistics chunk per (128-row block, wave row), 2 one per
+// (workgroup, wave row) (needs gridDim.x % (8*tiles_n) == 0: every item of a workgroup then lies in one column tile)
+template <bool WIDE, int PRO, int STATS>
+__global__ __launch_bounds__(GR_BLOCK_T, (WIDE && PRO != PRO_NONE) ? 2 : 1) void gemm_rows_kernel(const float *__restrict__ A, const float *__restrict__ Bt,
+                                                                int64_t M, int N, int K, int kchunk, int tiles_n,
+                                                                int64_t items, float *__restrict__ C,
+                                                                float *__restrict__ partial, GemmPrologue pro)
 {
+    constexpr int BN = WIDE ? 128 : 64;
+    constexpr int WR = WIDE ? 2 : 4;          // wave rows of the workgroup tile
+    constexpr int WM = WIDE ? 2 : 1;          // 32-row MFMA tiles per wave
+    constexpr int WN = 2;                     // 32-column MFMA tiles per wave
+    constexpr int PB = BN * (GR_BK / 4) / GR_BLOCK_T;  // float4 slots of the B tile per thread (4 or 2)
+    constexpr int NCONST = PRO == PRO_NONE ? 0 : (PRO == PRO_BNACT ? 3 : 5);
     __shared__ __attribute__((aligned(16))) float sA[GR_BM * GR_LD];
-    __shared__ __attribute__((aligned(16))) float sB[GR_BN * GR_LD];
+    __shared__ __attribute__((aligned(16))) float sB[BN * GR_LD];
+    __shared__ __attribute__((aligned(16))) float sK[NCONST > 0 ? NCONST * GR_PRO_KMAX : 4];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wr = wave >> 1, wc = wave & 1;
+    const int wr = WIDE ? wave >> 1 : wave, wc = WIDE ? wave & 1 : 0;
     const int l31 = lane & 31, lh = lane >> 5;
-    const int ksteps = (K + GR_BK - 1) / GR_BK;
+    const int kbeg = blockIdx.y * kchunk, kend = min(K, kbeg + kchunk);
+    const int ksteps = (kend - kbeg + GR_BK - 1) / GR_BK;
+    if (blockIdx.y > 0) C += (size_t)blockIdx.y * (size_t)M * N;  // K-split: one partial slab per K-range
+
+    if (PRO != PRO_NONE) {  // the contraction's per-channel constants, once per workgroup (zero past K)
+        for (int k = tid; k < GR_PRO_KMAX; k += GR_BLOCK_T) {
+            const bool in = k < K;
+            sK[0 * GR_PRO_KMAX + k] = in ? pro.mean[k] : 0.0f;
+            sK[1 * GR_PRO_KMAX + k] = in ? pro.scale[k] : 0.0f;
+            sK[2 * GR_PRO_KMAX + k] = in ? pro.beta[k] : 0.0f;
+            if (PRO >= PRO_BNBWD) {
+                sK[3 * GR_PRO_KMAX + k] = in ? pro.c1[k] : 0.0f;
+                sK[4 * GR_PRO_KMAX + k] = in ? pro.c2[k] : 0.0f;
+            }
+        }
+        __syncthreads();
+    }
 
     // Work items = (row block, column tile) in an XCD-aware order: the column tiles of one row block are 8 ids
     // apart, i.e. on the same XCD (shared L2 for A).  Workgroups are PERSISTENT: each walks items id, id + G, ...
@@ -47,23 +98,73 @@ __global__ __launch_bounds__(GR_BLOCK_T) void gemm_rows_kernel(const float *__re
         const int rem = (int)(item % (8 * tiles_n));
         rb = grp * 8 + (rem & 7);
         m0 = rb * GR_BM;
-        n0 = (rem >> 3) * GR_BN;
+        n0 = (rem >> 3) * BN;
     };
 
-    // staging registers: each tile is 128 rows x 32 k = 1024 float4 (4 per thread and operand)
-    float4 ra[4], rbv[4];
+    // staging registers: the A tile is 128 rows x 32 k = 1024 float4 (4 per thread), raw as loaded; the prologue is
+    // applied when they are written to LDS one K-step later (the loads have had a whole MFMA phase to land by then)
+    float4 ra[4], ra2[PRO >= PRO_BNBWD ? 4 : 1], rbv[PB];
+    int4 rarg[PRO == PRO_BNBWD_POOL ? 4 : 1];
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int k4 = (tid & 7) * 4;  // this thread's k offset inside a K-step (tid + i*256: the same for all four slots)
     auto fetch = [&](int64_t m0, int n0, int k0) {
+        const bool kin = k0 + k4 < kend;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int e = tid + i * GR_BLOCK_T;
-            const int row = e >> 3, k4 = (e & 7) * 4;  // 8 float4 per row
+            const int row = (tid >> 3) + i * 32;
             const int64_t m = m0 + row;
-            ra[i] = (m < M && k0 + k4 < K) ? *reinterpret_cast<const float4 *>(A + m * K + k0 + k4)
-                                           : make_float4(0.f, 0.f, 0.f, 0.f);
-            const int n = n0 + row;
-            rbv[i] = (n < N && k0 + k4 < K) ? *reinterpret_cast<const float4 *>(Bt + (size_t)n * K + k0 + k4)
-                                            : make_float4(0.f, 0.f, 0.f, 0.f);
+            const bool in = m < M && kin;
+            ra[i] = in ? *reinterpret_cast<const float4 *>(A + m * K + k0 + k4) : zero4;
+            if (PRO == PRO_BNBWD) ra2[i] = in ? *reinterpret_cast<const float4 *>(pro.dA + m * K + k0 + k4) : zero4;
+            if (PRO == PRO_BNBWD_POOL) {
+                const int64_t g = m / pro.ns;
+                ra2[i] = in ? *reinterpret_cast<const float4 *>(pro.dA + g * K + k0 + k4) : zero4;
+                rarg[i] = in ? *reinterpret_cast<const int4 *>(pro.argmax + g * K + k0 + k4) : make_int4(-1, -1, -1, -1);
+            }
         }
+#pragma unroll
+        for (int i = 0; i < PB; ++i) {
+            const int n = n0 + (tid >> 3) + i * 32;
+            rbv[i] = (n < N && kin) ? *reinterpret_cast<const float4 *>(Bt + (size_t)n * K + k0 + k4) : zero4;
+        }
+    };
+    // the prologue on one staged float4 (k = kk .. kk+3); out-of-range rows / k were loaded as zeros and MUST stay zero
+    auto transform = [&](int i, int64_t m0, int kk, bool in) -> float4 {
+        if (PRO == PRO_NONE) return ra[i];
+        if (!in) return zero4;
+        const float4 mu = *reinterpret_cast<const float4 *>(&sK[0 * GR_PRO_KMAX + kk]);
+        const float4 sc = *reinterpret_cast<const float4 *>(&sK[1 * GR_PRO_KMAX + kk]);
+        const float4 be = *reinterpret_cast<const float4 *>(&sK[2 * GR_PRO_KMAX + kk]);
+        const float y[4] = {ra[i].x, ra[i].y, ra[i].z, ra[i].w};
+        const float m_[4] = {mu.x, mu.y, mu.z, mu.w}, s_[4] = {sc.x, sc.y, sc.z, sc.w}, b_[4] = {be.x, be.y, be.z, be.w};
+        float o[4];
+        if (PRO == PRO_BNACT) {
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const float z = (y[v] - m_[v]) * s_[v] + b_[v];
+                o[v] = z > 0.0f ? z : z * pro.slope;
+            }
+        } else {
+            const float4 c1 = *reinterpret_cast<const float4 *>(&sK[3 * GR_PRO_KMAX + kk]);
+            const float4 c2 = *reinterpret_cast<const float4 *>(&sK[4 * GR_PRO_KMAX + kk]);
+            const float k1[4] = {c1.x, c1.y, c1.z, c1.w}, k2[4] = {c2.x, c2.y, c2.z, c2.w};
+            float d[4] = {ra2[i].x, ra2[i].y, ra2[i].z, ra2[i].w};
+            if (PRO == PRO_BNBWD_POOL) {
+                const int64_t m = m0 + (tid >> 3) + i * 32;
+                const int s = (int)(m - (m / pro.ns) * pro.ns);
+                const int a_[4] = {rarg[i].x, rarg[i].y, rarg[i].z, rarg[i].w};
+#pragma unroll
+                for (int v = 0; v < 4; ++v) d[v] = a_[v] == s ? d[v] : 0.0f;
+            }
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const float yc = y[v] - m_[v];
+                const float z = yc * s_[v] + b_[v];
+                const float dz = d[v] * (z > 0.0f ? 1.0f : pro.slope);
+                o[v] = s_[v] * ((dz - k1[v]) - yc * k2[v]);
+            }
+        }
+        return make_float4(o[0], o[1], o[2], o[3]);
     };
 
     int64_t item = blockIdx.x;
@@ -71,19 +172,19 @@ __global__ __launch_bounds__(GR_BLOCK_T) void gemm_rows_kernel(const float *__re
     int64_t m0, rb;
     int n0;
     decode(item, m0, n0, rb);
-    fetch(m0, n0, 0);
+    fetch(m0, n0, kbeg);
 
     const int n0_first = n0;
     float run1[2] = {0.0f, 0.0f}, run2[2] = {0.0f, 0.0f};  // STATS == 2: this thread's share over all its items
     float kshift[2] = {0.0f, 0.0f};
     bool have_shift = false;
     int run_rows = 0;
-    f32x16 acc[2][2];
+    f32x16 acc[WM][WN];
     while (item < items) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < WM; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < WN; ++j)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
         const int64_t next_item = item + gridDim.x;
@@ -92,29 +193,30 @@ __global__ __launch_bounds__(GR_BLOCK_T) void gemm_rows_kernel(const float *__re
         if (next_item < items) decode(next_item, nm0, nn0, nrb);
 
         for (int ks = 0; ks < ksteps; ++ks) {
+            const int kk = kbeg + ks * GR_BK + k4;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const int e = tid + i * GR_BLOCK_T;
-                const int o = (e >> 3) * GR_LD + (e & 7) * 4;
-                *reinterpret_cast<float4 *>(&sA[o]) = ra[i];
-                *reinterpret_cast<float4 *>(&sB[o]) = rbv[i];
+                const int row = (tid >> 3) + i * 32;
+                *reinterpret_cast<float4 *>(&sA[row * GR_LD + k4]) = transform(i, m0, kk, m0 + row < M && kk < kend);
             }
+#pragma unroll
+            for (int i = 0; i < PB; ++i) *reinterpret_cast<float4 *>(&sB[((tid >> 3) + i * 32) * GR_LD + k4]) = rbv[i];
             __syncthreads();
-            if (ks + 1 < ksteps) fetch(m0, n0, (ks + 1) * GR_BK);
-            else if (next_item < items) fetch(nm0, nn0, 0);  // next item's first K-step rides under this epilogue
+            if (ks + 1 < ksteps) fetch(m0, n0, kbeg + (ks + 1) * GR_BK);
+            else if (next_item < items) fetch(nm0, nn0, kbeg);  // next item's first K-step rides under this epilogue
 #pragma unroll
             for (int g = 0; g < GR_BK / 8; ++g) {
-                float4 a[2], b[2];
+                float4 a[WM], b[WN];
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
-                    a[i] = *reinterpret_cast<const float4 *>(&sA[((wr * 2 + i) * 32 + l31) * GR_LD + g * 8 + lh * 4]);
+                for (int i = 0; i < WM; ++i)
+                    a[i] = *reinterpret_cast<const float4 *>(&sA[((wr * WM + i) * 32 + l31) * GR_LD + g * 8 + lh * 4]);
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    b[j] = *reinterpret_cast<const float4 *>(&sB[((wc * 2 + j) * 32 + l31) * GR_LD + g * 8 + lh * 4]);
+                for (int j = 0; j < WN; ++j)
+                    b[j] = *reinterpret_cast<const float4 *>(&sB[((wc * WN + j) * 32 + l31) * GR_LD + g * 8 + lh * 4]);
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
+                for (int i = 0; i < WM; ++i)
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) {
+                    for (int j = 0; j < WN; ++j) {
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].x, b[j].x, acc[i][j], 0, 0, 0);
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].y, b[j].y, acc[i][j], 0, 0, 0);
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].z, b[j].z, acc[i][j], 0, 0, 0);
@@ -125,57 +227,59 @@ __global__ __launch_bounds__(GR_BLOCK_T) void gemm_rows_kernel(const float *__re
         }
 
         // ---- epilogue: D[row][col], col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+        constexpr int WROWS = WM * 32;  // rows of the tile one wave owns
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < WM; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int n = n0 + (wc * 2 + j) * 32 + l31;
+            for (int j = 0; j < WN; ++j) {
+                const int n = n0 + (wc * WN + j) * 32 + l31;
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
-                    const int64_t m = m0 + (wr * 2 + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                    const int64_t m = m0 + (wr * WM + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
                     if (m < M && n < N) C[m * N + n] = acc[i][j][e];
                 }
             }
         if (STATS != 0) {
-            // Column statistics of this wave's 64 x 64 part of the tile as SHIFTED sums (d = v - K; K = the first value
-            // the wave saw in that column): free of the cancellation E[y^2] - E[y]^2 suffers when |mean| >> std.
-            // Rows past M were staged as zeros and are masked out.  STATS == 1: one chunk per (row block, wave row);
+            // Column statistics of this wave's part of the tile as SHIFTED sums (d = v - K; K = the first value the
+            // wave saw in that column): free of the cancellation E[y^2] - E[y]^2 suffers when |mean| >> std.
+            // Rows past M were staged as zeros, i.e. each of the `pad` such rows of this wave added d = -K: taken out again
+            // below (only the last row block of a matrix has any).  STATS == 1: one chunk per (row block, wave row);
             // STATS == 2: the sums run on over all items of the workgroup, one chunk per (workgroup, wave row).
-            const int64_t mrow0 = m0 + wr * 64;
-            const int valid = (int)min((int64_t)64, max((int64_t)0, M - mrow0));  // rows of this wave inside the matrix
+            const int valid = (int)min((int64_t)WROWS, max((int64_t)0, M - (m0 + wr * WROWS)));  // wave-uniform
+            const float pad = (float)(WROWS - valid);
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                if (STATS == 1 || !have_shift) kshift[j] = __shfl(acc[0][j][0], l31);  // row mrow0 of this column
+            for (int j = 0; j < WN; ++j) {
+                if (STATS == 1 || !have_shift) kshift[j] = __shfl(acc[0][j][0], l31);  // first row of this wave's part
+                const float k = kshift[j];
                 float s1 = 0.0f, s2 = 0.0f;
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
+                for (int i = 0; i < WM; ++i)
 #pragma unroll
                     for (int e = 0; e < 16; ++e) {
-                        const int r = i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-                        const float d = acc[i][j][e] - kshift[j];
-                        if (r < valid) {
-                            s1 += d;
-                            s2 += d * d;
-                        }
+                        const float d = acc[i][j][e] - k;
+                        s1 += d;
+                        s2 += d * d;
                     }
+                s1 += __shfl_xor(s1, 32);  // the two half-waves hold different rows of the same column
+                s2 += __shfl_xor(s2, 32);
+                s1 += pad * k;
+                s2 -= pad * (k * k);
                 if (STATS == 2) {
-                    run1[j] += s1;
+                    run1[j] += s1;  // (both half-waves now hold the wave's sum; written once below)
                     run2[j] += s2;
                 } else {
-                    s1 += __shfl_xor(s1, 32);  // the two half-waves hold different rows of the same column
-                    s2 += __shfl_xor(s2, 32);
-                    const int n = n0 + (wc * 2 + j) * 32 + l31;
+                    const int n = n0 + (wc * WN + j) * 32 + l31;
                     if (lh == 0 && n < N && m0 < M) {  // padding items (row block past M) own no statistics rows
-                        float *pr = partial + ((size_t)(rb * 2 + wr) * 4) * N + n;
+                        float *pr = partial + ((size_t)(rb * WR + wr) * 4) * N + n;
                         pr[0] = s1;
                         pr[(size_t)N] = s2;
-                        pr[(size_t)2 * N] = kshift[j];
+                        pr[(size_t)2 * N] = k;
                         pr[(size_t)3 * N] = (float)valid;
                     }
                 }
             }
             if (STATS == 2) {
-                if (valid > 0) have_shift = true;  // (wave-uniform) a wave whose first items were padding keeps looking
+                if (valid > 0) have_shift = true;  // a wave whose first items were padding keeps looking for a shift
                 run_rows += valid;
             }
         }
@@ -188,17 +292,33 @@ __global__ __launch_bounds__(GR_BLOCK_T) void gemm_rows_kernel(const float *__re
         const int per = 8 * tiles_n;
         const int64_t slot = (int64_t)(blockIdx.x / per) * 8 + (blockIdx.x & 7);
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const float s1 = run1[j] + __shfl_xor(run1[j], 32), s2 = run2[j] + __shfl_xor(run2[j], 32);
-            const int n = n0_first + (wc * 2 + j) * 32 + l31;
+        for (int j = 0; j < WN; ++j) {
+            const int n = n0_first + (wc * WN + j) * 32 + l31;
             if (lh == 0 && n < N) {
-                float *pr = partial + ((size_t)(slot * 2 + wr) * 4) * N + n;
-                pr[0] = s1;
-                pr[(size_t)N] = s2;
+                float *pr = partial + ((size_t)(slot * WR + wr) * 4) * N + n;
+                pr[0] = run1[j];
+                pr[(size_t)N] = run2[j];
                 pr[(size_t)2 * N] = kshift[j];
                 pr[(size_t)3 * N] = (float)run_rows;
             }
         }
+    }
+}
+
+// out[e] = sum_s slab[s][e], s ascending (fixed order => reproducible); one float4 per thread
+__global__ __launch_bounds__(256) void gemm_rows_sum_slabs_kernel(const float *__restrict__ slabs, int S, int64_t MN4,
+                                                                   float *__restrict__ out)
+{
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < MN4; e += (int64_t)gridDim.x * 256) {
+        float4 t = reinterpret_cast<const float4 *>(slabs)[e];
+        for (int s = 1; s < S; ++s) {
+            const float4 v = reinterpret_cast<const float4 *>(slabs + (size_t)s * MN4 * 4)[e];
+            t.x += v.x;
+            t.y += v.y;
+            t.z += v.z;
+            t.w += v.w;
+        }
+        reinterpret_cast<float4 *>(out)[e] = t;
     }
 }
 
@@ -209,75 +329,162 @@ using namespace tp3d;
 namespace {
 constexpr int GR_GRID = 1024;  // persistent: 4 workgroups per CU, a multiple of 8
 struct RowsPlan {
-    int tiles_n;
+    bool wide;  // 128 x 128 tiles (else 128 x 64)
+    int tiles_n, wave_rows;
     int64_t row_blocks, items, blocks;
-    bool per_workgroup;  // statistics rows: one per workgroup instead of one per 128-row block
+    bool per_workgroup;  // statistics chunks: per (workgroup, wave row) instead of per (128-row block, wave row)
     int64_t chunks;
+    int ksplit, kchunk;  // K-ranges of a split launch (1 = no split)
 };
-RowsPlan rows_plan(int64_t M, int N)
+RowsPlan rows_plan(int64_t M, int N, int K = 0, bool allow_split = false)
 {
     RowsPlan p;
-    p.tiles_n = (N + GR_BN - 1) / GR_BN;
+    // narrow tiles when they cover N with less padding (N <= 64, or a remainder of at most 64 columns: 192, 320 ...)
+    const int rem = N % 128;
+    p.wide = !(rem > 0 && rem <= 64);
+    const int bn = p.wide ? 128 : 64;
+    p.wave_rows = p.wide ? 2 : 4;
+    p.tiles_n = (N + bn - 1) / bn;
     p.row_blocks = (M + GR_BM - 1) / GR_BM;
     const int64_t groups = (p.row_blocks + 7) / 8;
     p.items = groups * 8 * p.tiles_n;  // items past the last row block stage zeros and store nothing
     p.blocks = p.items < GR_GRID ? p.items : GR_GRID;
     p.per_workgroup = p.blocks == GR_GRID && GR_GRID % (8 * p.tiles_n) == 0;
-    p.chunks = 2 * (p.per_workgroup ? GR_GRID / p.tiles_n : p.row_blocks);  // one per wave row of a workgroup tile
+    p.chunks = p.wave_rows * (p.per_workgroup ? GR_GRID / p.tiles_n : p.row_blocks);
+    p.ksplit = 1;
+    p.kchunk = K > 0 ? (K + GR_BK - 1) / GR_BK * GR_BK : 0;
+    if (allow_split && K >= 256 && p.items <= 256) {
+        // few output tiles and a long contraction: K-ranges of >= 128 until ~1024 workgroups are in flight
+        const int want = (int)((GR_GRID + p.items - 1) / p.items);
+        const int by_k = K / 128;
+        int s = want < by_k ? want : by_k;
+        if (s > 16) s = 16;
+        if (s > 1) {
+            p.kchunk = ((K + s - 1) / s + GR_BK - 1) / GR_BK * GR_BK;
+            p.ksplit = (K + p.kchunk - 1) / p.kchunk;
+        }
+    }
     return p;
+}
+
+template <bool WIDE, int PRO>
+int launch_rows(const RowsPlan &p, const float *A, const float *Bt, int64_t M, int N, int K, float *C, float *stat_partial,
+                const GemmPrologue &pro, hipStream_t s)
+{
+    const dim3 grid((unsigned)p.blocks, (unsigned)p.ksplit), block(GR_BLOCK_T);
+    if (stat_partial && p.per_workgroup)
+        hipLaunchKernelGGL((gemm_rows_kernel<WIDE, PRO, 2>), grid, block, 0, s, A, Bt, M, N, K, p.kchunk, p.tiles_n, p.items,
+                           C, stat_partial, pro);
+    else if (stat_partial)
+        hipLaunchKernelGGL((gemm_rows_kernel<WIDE, PRO, 1>), grid, block, 0, s, A, Bt, M, N, K, p.kchunk, p.tiles_n, p.items,
+                           C, stat_partial, pro);
+    else
+        hipLaunchKernelGGL((gemm_rows_kernel<WIDE, PRO, 0>), grid, block, 0, s, A, Bt, M, N, K, p.kchunk, p.tiles_n, p.items,
+                           C, stat_partial, pro);
+    return check_launch();
+}
+
+template <int PRO>
+int launch_rows_any(const RowsPlan &p, const float *A, const float *Bt, int64_t M, int N, int K, float *C,
+                    float *stat_partial, const GemmPrologue &pro, hipStream_t s)
+{
+    return p.wide ? launch_rows<true, PRO>(p, A, Bt, M, N, K, C, stat_partial, pro, s)
+                  : launch_rows<false, PRO>(p, A, Bt, M, N, K, C, stat_partial, pro, s);
 }
 }  // namespace
 
-// size of the statistics buffer: one row per 128-row block, or per persistent workgroup -- whichever is more (the item
-// count is rounded up to groups of 8 row blocks, so 1017..1023 row blocks already fill the 1024-workgroup grid)
+// size of the statistics buffer: 4 rows of N floats per chunk (sum d, sum d^2, shift, rows); chunks = one per
+// (128-row block, wave row) or per (persistent workgroup, wave row) -- whichever the launch uses, both covered
 TP3D_EXPORT size_t tp3d_gemm_rows_stat_floats(int64_t M, int N)
 {
     if (M <= 0 || N <= 0) return 0;
     const RowsPlan p = rows_plan(M, N);
-    const int64_t rows = p.chunks > 2 * p.row_blocks ? p.chunks : 2 * p.row_blocks;
-    return (size_t)rows * 4 * (size_t)N;  // per chunk: sum d, sum d^2, shift, rows
+    const int64_t by_block = p.wave_rows * p.row_blocks;
+    const int64_t rows = p.chunks > by_block ? p.chunks : by_block;
+    return (size_t)rows * 4 * (size_t)N;
 }
 
-// number of statistics rows tp3d_gemm_rows_f32 writes for this shape = `chunks` of tp3d_bn_finalize_f32
+// number of statistics chunks tp3d_gemm_rows_f32 writes for this shape = `chunks` of tp3d_bn_finalize_f32
 TP3D_EXPORT int tp3d_gemm_rows_stat_chunks(int64_t M, int N)
 {
     if (M <= 0 || N <= 0) return 0;
     return (int)rows_plan(M, N).chunks;
 }
 
-// plan[0..5] = column tiles, row blocks, work items, workgroups launched, statistics rows written (= chunks),
-// 1 when they are one per workgroup (else one per 128-row block)
-TP3D_EXPORT int tp3d_gemm_rows_plan(int64_t M, int N, int64_t *plan)
+// floats of the K-split slabs tp3d_gemm_rows_f32 needs as `workspace` when it runs WITHOUT statistics (0: no split)
+TP3D_EXPORT size_t tp3d_gemm_rows_workspace_floats(int64_t M, int N, int K)
 {
-    if (M <= 0 || N <= 0 || !plan) return TP3D_E_BADARG;
-    const RowsPlan p = rows_plan(M, N);
+    if (M <= 0 || N <= 0 || K <= 0) return 0;
+    const RowsPlan p = rows_plan(M, N, K, true);
+    return p.ksplit > 1 ? (size_t)p.ksplit * (size_t)M * (size_t)N : 0;
+}
+
+// plan[0..8] = column tiles, row blocks, work items, workgroups, statistics chunks written, 1 when they are one per
+// workgroup (else per 128-row block), wave rows per tile, K-ranges of the split launch, columns of a tile
+TP3D_EXPORT int tp3d_gemm_rows_plan(int64_t M, int N, int K, int64_t *plan)
+{
+    if (M <= 0 || N <= 0 || K < 0 || !plan) return TP3D_E_BADARG;
+    const RowsPlan p = rows_plan(M, N, K, K > 0);
     plan[0] = p.tiles_n;
     plan[1] = p.row_blocks;
     plan[2] = p.items;
     plan[3] = p.blocks;
     plan[4] = p.chunks;
     plan[5] = p.per_workgroup ? 1 : 0;
+    plan[6] = p.wave_rows;
+    plan[7] = p.ksplit;
+    plan[8] = p.wide ? 128 : 64;
     return TP3D_OK;
 }
 
-TP3D_EXPORT int tp3d_gemm_rows_f32(const float *A, const float *Bt, int64_t M, int N, int K, float *C,
-                                   float *stat_partial, void *stream)
+TP3D_EXPORT int tp3d_gemm_rows_f32(const float *A, const float *Bt, int64_t M, int N, int K, float *C, float *stat_partial,
+                                   float *workspace, void *stream)
 {
     if (M < 0 || N <= 0 || K <= 0 || (K & 3)) return TP3D_E_BADARG;  // operand rows must be 16-byte aligned
     if (M == 0) return TP3D_OK;
     if (!A || !Bt || !C) return TP3D_E_BADARG;
-    const RowsPlan p = rows_plan(M, N);
-    const int tiles_n = p.tiles_n;
-    const int64_t items = p.items, blocks = p.blocks;
     hipStream_t s = (hipStream_t)stream;
-    if (stat_partial && p.per_workgroup)
-        hipLaunchKernelGGL(gemm_rows_kernel<2>, dim3((unsigned)blocks), dim3(GR_BLOCK_T), 0, s, A, Bt, M, N, K, tiles_n,
-                           items, C, stat_partial);
-    else if (stat_partial)
-        hipLaunchKernelGGL(gemm_rows_kernel<1>, dim3((unsigned)blocks), dim3(GR_BLOCK_T), 0, s, A, Bt, M, N, K, tiles_n,
-                           items, C, stat_partial);
-    else
-        hipLaunchKernelGGL(gemm_rows_kernel<0>, dim3((unsigned)blocks), dim3(GR_BLOCK_T), 0, s, A, Bt, M, N, K, tiles_n,
-                           items, C, stat_partial);
+    GemmPrologue none = {};
+    // K-split only without fused statistics (they need the finished column values) and with slabs to write to
+    const RowsPlan p = rows_plan(M, N, K, !stat_partial && workspace && ((M * (int64_t)N) & 3) == 0);
+    if (p.ksplit == 1) return launch_rows_any<PRO_NONE>(p, A, Bt, M, N, K, C, stat_partial, none, s);
+    if (int rc = launch_rows_any<PRO_NONE>(p, A, Bt, M, N, K, workspace, nullptr, none, s)) return rc;
+    const int64_t mn4 = M * (int64_t)N / 4;
+    hipLaunchKernelGGL(gemm_rows_sum_slabs_kernel, dim3((unsigned)std::min<int64_t>((mn4 + 255) / 256, 4096)), dim3(256), 0, s,
+                       workspace, p.ksplit, mn4, C);
     return check_launch();
+}
+
+// C = act(BN(Y)) * Bt^T: the forward GEMM of a layer whose input is the previous layer's pre-BatchNorm output Y (M, K)
+// with that layer's statistics rows mean / scale / beta (K each); the activated input is formed while staging.
+TP3D_EXPORT int tp3d_gemm_rows_bnact_f32(const float *Y, const float *mean, const float *scale, const float *beta,
+                                         float slope, const float *Bt, int64_t M, int N, int K, float *C,
+                                         float *stat_partial, void *stream)
+{
+    if (M < 0 || N <= 0 || K <= 0 || (K & 3) || K > GR_PRO_KMAX) return TP3D_E_BADARG;
+    if (M == 0) return TP3D_OK;
+    if (!Y || !mean || !scale || !beta || !Bt || !C) return TP3D_E_BADARG;
+    GemmPrologue pro = {};
+    pro.mean = mean, pro.scale = scale, pro.beta = beta, pro.slope = slope, pro.ns = 1;
+    return launch_rows_any<PRO_BNACT>(rows_plan(M, N, K), Y, Bt, M, N, K, C, stat_partial, pro, (hipStream_t)stream);
+}
+
+// Input-gradient GEMM with the BatchNorm + activation backward folded in:  C[M,N] = dY[M,K] * Bt[N,K]^T  where
+//   dY = scale * (dZ - c1 - (Y - mean) * c2),  dZ = dA * act'((Y - mean) * scale + beta)
+// is formed from Y (M, K) and dA while staging: dA is (M, K), or with argmax != NULL the gradient (M/ns, K) of the
+// max-pooled output with its winning rows.  c1 = dbeta / M, c2 = invstd * dgamma / M (tp3d_bn_bwd_reduce_f32; zeros
+// in eval mode).  Bt = W^T (N = the layer's input width, K = its output width).
+TP3D_EXPORT int tp3d_gemm_rows_bnbwd_f32(const float *Y, const float *dA, const int *argmax, int ns, const float *mean,
+                                         const float *scale, const float *beta, const float *c1, const float *c2,
+                                         float slope, const float *Bt, int64_t M, int N, int K, float *C, void *stream)
+{
+    if (M < 0 || N <= 0 || K <= 0 || (K & 3) || K > GR_PRO_KMAX || ns <= 0) return TP3D_E_BADARG;
+    if (M == 0) return TP3D_OK;
+    if (!Y || !dA || !mean || !scale || !beta || !c1 || !c2 || !Bt || !C || (argmax && M % ns)) return TP3D_E_BADARG;
+    GemmPrologue pro = {};
+    pro.mean = mean, pro.scale = scale, pro.beta = beta, pro.c1 = c1, pro.c2 = c2, pro.dA = dA, pro.argmax = argmax;
+    pro.slope = slope, pro.ns = ns;
+    const RowsPlan p = rows_plan(M, N, K);
+    return argmax ? launch_rows_any<PRO_BNBWD_POOL>(p, Y, Bt, M, N, K, C, nullptr, pro, (hipStream_t)stream)
+                  : launch_rows_any<PRO_BNBWD>(p, Y, Bt, M, N, K, C, nullptr, pro, (hipStream_t)stream);
 }

@@ -1,14 +1,20 @@
 // Weight-gradient contraction of the shared MLPs:  dW[n,k] = sum_r dY[r,n] * A[r,k]
-// dY (M, N) and A (M, K) row-major with M = B*npoint*nsample up to ~1e6 rows and N, K <= ~1300: a GEMM whose
+// dY (M, N) and A (M, K) row-major with M = B*npoint*nsample up to ~1e6 rows and N, K <= ~1500: a GEMM whose
 // OUTPUT is tiny and whose contraction dimension is huge.  Library GEMMs pick 32x32 macro-tiles without a
 // split over M for it (measured 0.5-1.5 ms per layer on MI355X); here the rows are split over the grid, every
 // workgroup streams its row range once through LDS and accumulates a (TN x TK) tile with fp32 MFMA
 // (v_mfma_f32_32x32x2_f32: exact fp32, 64 FLOP/clk/SIMD), and a second pass sums the splits in fixed order
 // (no atomics: bitwise reproducible).
 //
+// Both operands can be formed on the fly while they are staged (the FUSED instantiations), so that neither the
+// BatchNorm-backward result dY nor the activated layer input A has to exist in HBM:
+//     dY = scale_n * (dZ - c1_n - (Y - mean_n) * c2_n),  dZ = dA * act'((Y - mean_n) * scale_n + beta_n)
+//          from the layer's pre-BatchNorm output Y (M, N) and the gradient dA of its activated output (dense (M, N), or
+//          the gradient (M/ns, N) of its max-pooled output with the winning rows)
+//     A  = LeakyReLU((Yp - mean_k) * scale_k + beta_k)   from the previous layer's pre-BatchNorm output Yp (M, K)
+//
 // Reference semantics: the weight gradient of Conv2d 1x1 (bias=False) inside MLP2D
 // (torch_points3d/core/common_modules/dense_modules.py:5-12,25-29) -- computed by autograd in the reference.
-#include <cstdlib>
 #include <type_traits>
 
 #include "tp3d_common.h"
@@ -20,12 +26,26 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int TN_BLOCK = 256;  // 4 waves as 2 x 2
 constexpr int TN_BR_MAX = 64;  // most rows staged per step (narrow tiles stage more rows per barrier)
 
+// operand prologues of the FUSED instantiations (null pointers = plain operand)
+struct TnPrologue {
+    // dY operand: Y in `dY`, plus
+    const float *dA;      // gradient of the activated output: (M, N), or (M/ns, N) when argmax != null
+    const int *argmax;    // (M/ns, N) winning rows of the pooled groups, or null
+    const float *mean_n, *scale_n, *beta_n, *c1_n, *c2_n;
+    float slope_n;
+    int ns;
+    // A operand: Yp in `A`, plus
+    const float *mean_k, *scale_k, *beta_k;
+    float slope_k;
+};
+
 // Each wave owns WM x WN MFMA tiles of 32x32; the workgroup tile is (2*WM*32) x (2*WN*32).
-template <int WM, int WN, bool VECY, bool VECA>
+template <int WM, int WN, bool VECY, bool VECA, bool FUSED>
 __global__ __launch_bounds__(TN_BLOCK) void gemm_tn_partial_kernel(const float *__restrict__ dY,
                                                                     const float *__restrict__ A, int64_t M, int N,
                                                                     int K, int64_t rows_per_split, int tiles_k,
-                                                                    float *__restrict__ partial /*[S][N][K]*/)
+                                                                    float *__restrict__ partial /*[S][N][K]*/,
+                                                                    TnPrologue pro)
 {
     constexpr int TN = 2 * WM * 32, TK = 2 * WN * 32;
     // ~16-32 KiB staged per step whatever the tile shape (three-tile-wide shapes: 16 rows, so that every thread
@@ -34,6 +54,8 @@ __global__ __launch_bounds__(TN_BLOCK) void gemm_tn_partial_kernel(const float *
     constexpr int LDN = TN + 4, LDK = TK + 4;  // +4 floats: keeps float4 stores aligned, spreads rows over banks
     __shared__ __attribute__((aligned(16))) float sY[TN_BR * LDN];
     __shared__ __attribute__((aligned(16))) float sA[TN_BR * LDK];
+    __shared__ __attribute__((aligned(16))) float sCn[FUSED ? 5 * TN : 4];  // mean, scale, beta, c1, c2 of the tile's columns
+    __shared__ __attribute__((aligned(16))) float sCk[FUSED ? 3 * TK : 4];  // mean, scale, beta
 
     const int tile = blockIdx.x;
     const int n0 = (tile / tiles_k) * TN, k0 = (tile % tiles_k) * TK;
@@ -43,6 +65,26 @@ __global__ __launch_bounds__(TN_BLOCK) void gemm_tn_partial_kernel(const float *
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
     const int l31 = lane & 31, lh = lane >> 5;
+    const bool proY = FUSED && pro.dA != nullptr, proA = FUSED && pro.mean_k != nullptr;
+    const bool pooled = FUSED && pro.argmax != nullptr;
+
+    if (FUSED) {
+        for (int c = tid; c < TN; c += TN_BLOCK) {
+            const bool in = proY && n0 + c < N;
+            sCn[0 * TN + c] = in ? pro.mean_n[n0 + c] : 0.0f;
+            sCn[1 * TN + c] = in ? pro.scale_n[n0 + c] : 0.0f;
+            sCn[2 * TN + c] = in ? pro.beta_n[n0 + c] : 0.0f;
+            sCn[3 * TN + c] = in ? pro.c1_n[n0 + c] : 0.0f;
+            sCn[4 * TN + c] = in ? pro.c2_n[n0 + c] : 0.0f;
+        }
+        for (int c = tid; c < TK; c += TN_BLOCK) {
+            const bool in = proA && k0 + c < K;
+            sCk[0 * TK + c] = in ? pro.mean_k[k0 + c] : 0.0f;
+            sCk[1 * TK + c] = in ? pro.scale_k[k0 + c] : 0.0f;
+            sCk[2 * TK + c] = in ? pro.beta_k[k0 + c] : 0.0f;
+        }
+        __syncthreads();
+    }
 
     f32x16 acc[WM][WN];
 #pragma unroll
@@ -76,12 +118,25 @@ __global__ __launch_bounds__(TN_BLOCK) void gemm_tn_partial_kernel(const float *
     constexpr int PY = TN_BR * (TN / 4) / TN_BLOCK, PA = TN_BR * (TK / 4) / TN_BLOCK;  // float4 slots per thread
     static_assert(PY >= 1 && PA >= 1 && PY * TN_BLOCK == TN_BR * (TN / 4) && PA * TN_BLOCK == TN_BR * (TK / 4),
                   "staged tile must be a whole number of float4 slots per thread");
-    float4 ry[PY], ra[PA];
+    float4 ry[PY], ra[PA], rd[FUSED ? PY : 1];
+    int4 rg[FUSED ? PY : 1];
     auto fetch = [&](int64_t r0) {
 #pragma unroll
         for (int i = 0; i < PY; ++i) {
             const int e = tid + i * TN_BLOCK;
-            ry[i] = load4(dY, r0 + e / (TN / 4), n0 + (e % (TN / 4)) * 4, N, std::integral_constant<bool, VECY>());
+            const int64_t r = r0 + e / (TN / 4);
+            const int c = n0 + (e % (TN / 4)) * 4;
+            ry[i] = load4(dY, r, c, N, std::integral_constant<bool, VECY>());
+            if (FUSED && proY) {
+                if (pooled) {
+                    const int64_t g = r / pro.ns;
+                    rd[i] = load4(pro.dA, g, c, N, std::true_type());
+                    rg[i] = (r < r_end && c < N) ? *reinterpret_cast<const int4 *>(pro.argmax + g * N + c)
+                                                 : make_int4(-1, -1, -1, -1);
+                } else {
+                    rd[i] = load4(pro.dA, r, c, N, std::true_type());
+                }
+            }
         }
 #pragma unroll
         for (int i = 0; i < PA; ++i) {
@@ -89,17 +144,61 @@ __global__ __launch_bounds__(TN_BLOCK) void gemm_tn_partial_kernel(const float *
             ra[i] = load4(A, r0 + e / (TK / 4), k0 + (e % (TK / 4)) * 4, K, std::integral_constant<bool, VECA>());
         }
     };
+    // prologues, applied when the staged values go to LDS; rows past the range / columns past the edge stay zero
+    auto make_dy = [&](int i, int64_t r0) -> float4 {
+        if (!(FUSED && proY)) return ry[i];
+        const int e = tid + i * TN_BLOCK;
+        const int64_t r = r0 + e / (TN / 4);
+        const int cl = (e % (TN / 4)) * 4;  // column inside the tile
+        if (r >= r_end) return make_float4(0.f, 0.f, 0.f, 0.f);
+        const float y[4] = {ry[i].x, ry[i].y, ry[i].z, ry[i].w};
+        float d[4] = {rd[i].x, rd[i].y, rd[i].z, rd[i].w};
+        if (pooled) {
+            const int s = (int)(r - (r / pro.ns) * pro.ns);
+            const int a_[4] = {rg[i].x, rg[i].y, rg[i].z, rg[i].w};
+#pragma unroll
+            for (int v = 0; v < 4; ++v) d[v] = a_[v] == s ? d[v] : 0.0f;
+        }
+        float o[4];
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int c = cl + v;
+            const float sc = sCn[1 * TN + c];  // zero past N: the whole expression is then zero
+            const float yc = y[v] - sCn[0 * TN + c];
+            const float z = yc * sc + sCn[2 * TN + c];
+            const float dz = d[v] * (z > 0.0f ? 1.0f : pro.slope_n);
+            o[v] = sc * ((dz - sCn[3 * TN + c]) - yc * sCn[4 * TN + c]);
+        }
+        return make_float4(o[0], o[1], o[2], o[3]);
+    };
+    auto make_a = [&](int i, int64_t r0) -> float4 {
+        if (!(FUSED && proA)) return ra[i];
+        const int e = tid + i * TN_BLOCK;
+        const int64_t r = r0 + e / (TK / 4);
+        const int cl = (e % (TK / 4)) * 4;
+        if (r >= r_end) return make_float4(0.f, 0.f, 0.f, 0.f);
+        const float y[4] = {ra[i].x, ra[i].y, ra[i].z, ra[i].w};
+        float o[4];
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int c = cl + v;
+            const float z = (y[v] - sCk[0 * TK + c]) * sCk[1 * TK + c] + sCk[2 * TK + c];
+            o[v] = (k0 + c < K) ? (z > 0.0f ? z : z * pro.slope_k) : 0.0f;
+        }
+        return make_float4(o[0], o[1], o[2], o[3]);
+    };
+
     if (r_begin < r_end) fetch(r_begin);
     for (int64_t r0 = r_begin; r0 < r_end; r0 += TN_BR) {
 #pragma unroll
         for (int i = 0; i < PY; ++i) {
             const int e = tid + i * TN_BLOCK;
-            *reinterpret_cast<float4 *>(&sY[(e / (TN / 4)) * LDN + (e % (TN / 4)) * 4]) = ry[i];
+            *reinterpret_cast<float4 *>(&sY[(e / (TN / 4)) * LDN + (e % (TN / 4)) * 4]) = make_dy(i, r0);
         }
 #pragma unroll
         for (int i = 0; i < PA; ++i) {
             const int e = tid + i * TN_BLOCK;
-            *reinterpret_cast<float4 *>(&sA[(e / (TK / 4)) * LDK + (e % (TK / 4)) * 4]) = ra[i];
+            *reinterpret_cast<float4 *>(&sA[(e / (TK / 4)) * LDK + (e % (TK / 4)) * 4]) = make_a(i, r0);
         }
         __syncthreads();
         if (r0 + TN_BR < r_end) fetch(r0 + TN_BR);
@@ -180,21 +279,46 @@ static TnPlan plan_tn(int64_t M, int N, int K)
     const int min_rows = 256;
     int64_t max_by_rows = (M + min_rows - 1) / min_rows;
     int64_t s = want < max_by_rows ? want : max_by_rows;
-    static const bool fill_small = [] {  // off by default: see DESIGN.md (a full-suite run aborted with it on)
-        const char *e = getenv("TP3D_TN_FILL_SMALL");
-        return e && atoi(e) > 0;
-    }();
-    if (fill_small && s * tiles < 256) {  // few rows and few tiles: shorter splits (>= 64 rows) until every CU has work
-        int64_t s2 = (256 + tiles - 1) / tiles;
-        const int64_t by64 = (M + 63) / 64;
-        if (s2 > by64) s2 = by64;
-        if (s2 > s) s = s2;
-    }
     if (s < 1) s = 1;
     if (s > 512) s = 512;
     p.rows_per_split = ((M + s - 1) / s + TN_BR_MAX - 1) / TN_BR_MAX * TN_BR_MAX;
     p.splits = (int)((M + p.rows_per_split - 1) / p.rows_per_split);
     return p;
+}
+
+static int launch_tn(const float *dY, const float *A, int64_t M, int N, int K, float *out, float *workspace,
+                     const TnPrologue *pro, hipStream_t s)
+{
+    const TnPlan p = plan_tn(M, N, K);
+    if (p.splits > 65535) return TP3D_E_TOOBIG;
+    dim3 grid(p.tiles_n * p.tiles_k, p.splits);
+    const bool vy = (N & 3) == 0, va = (K & 3) == 0;
+    if (pro && !(vy && va)) return TP3D_E_BADARG;  // the fused operands need 16-byte aligned rows
+    const TnPrologue none = {};
+#define TP3D_TN_LAUNCH(WM_, WN_, VY_, VA_, FU_)                                                                     \
+    hipLaunchKernelGGL((gemm_tn_partial_kernel<WM_, WN_, VY_, VA_, FU_>), grid, dim3(TN_BLOCK), 0, s, dY, A, M, N, K,   \
+                       p.rows_per_split, p.tiles_k, workspace, pro ? *pro : none)
+#define TP3D_TN_ALIGN(WM_, WN_)                                                                                     \
+    do {                                                                                                            \
+        if (pro) TP3D_TN_LAUNCH(WM_, WN_, true, true, true);                                                        \
+        else if (vy && va) TP3D_TN_LAUNCH(WM_, WN_, true, true, false);                                             \
+        else if (vy) TP3D_TN_LAUNCH(WM_, WN_, true, false, false);                                                  \
+        else if (va) TP3D_TN_LAUNCH(WM_, WN_, false, true, false);                                                  \
+        else TP3D_TN_LAUNCH(WM_, WN_, false, false, false);                                                         \
+    } while (0)
+    if (p.wm == 2 && p.wn == 3) TP3D_TN_ALIGN(2, 3);
+    else if (p.wn == 3) TP3D_TN_ALIGN(1, 3);
+    else if (p.wm == 2 && p.wn == 2) TP3D_TN_ALIGN(2, 2);
+    else if (p.wm == 2) TP3D_TN_ALIGN(2, 1);
+    else if (p.wn == 2) TP3D_TN_ALIGN(1, 2);
+    else TP3D_TN_ALIGN(1, 1);
+#undef TP3D_TN_ALIGN
+#undef TP3D_TN_LAUNCH
+    if (int rc = check_launch()) return rc;
+    const int64_t NK = (int64_t)N * K;
+    hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3((unsigned)((NK + RD_E - 1) / RD_E)), dim3(RD_E * RD_S), 0, s, workspace,
+                       p.splits, NK, out);
+    return check_launch();
 }
 
 }  // namespace tp3d
@@ -232,31 +356,28 @@ TP3D_EXPORT int tp3d_gemm_tn_f32(const float *dY, const float *A, int64_t M, int
     hipStream_t s = (hipStream_t)stream;
     if (M == 0) return zero_async(out, (size_t)N * K * sizeof(float), s);
     if (!dY || !A || !workspace) return TP3D_E_BADARG;
-    const TnPlan p = plan_tn(M, N, K);
-    if (p.splits > 65535) return TP3D_E_TOOBIG;
-    dim3 grid(p.tiles_n * p.tiles_k, p.splits);
-    const bool vy = (N & 3) == 0, va = (K & 3) == 0;
-#define TP3D_TN_LAUNCH(WM_, WN_, VY_, VA_)                                                                          \
-    hipLaunchKernelGGL((gemm_tn_partial_kernel<WM_, WN_, VY_, VA_>), grid, dim3(TN_BLOCK), 0, s, dY, A, M, N, K,      \
-                       p.rows_per_split, p.tiles_k, workspace)
-#define TP3D_TN_ALIGN(WM_, WN_)                                                                                     \
-    do {                                                                                                            \
-        if (vy && va) TP3D_TN_LAUNCH(WM_, WN_, true, true);                                                         \
-        else if (vy) TP3D_TN_LAUNCH(WM_, WN_, true, false);                                                         \
-        else if (va) TP3D_TN_LAUNCH(WM_, WN_, false, true);                                                         \
-        else TP3D_TN_LAUNCH(WM_, WN_, false, false);                                                                \
-    } while (0)
-    if (p.wm == 2 && p.wn == 3) TP3D_TN_ALIGN(2, 3);
-    else if (p.wn == 3) TP3D_TN_ALIGN(1, 3);
-    else if (p.wm == 2 && p.wn == 2) TP3D_TN_ALIGN(2, 2);
-    else if (p.wm == 2) TP3D_TN_ALIGN(2, 1);
-    else if (p.wn == 2) TP3D_TN_ALIGN(1, 2);
-    else TP3D_TN_ALIGN(1, 1);
-#undef TP3D_TN_ALIGN
-#undef TP3D_TN_LAUNCH
-    if (int rc = check_launch()) return rc;
-    const int64_t NK = (int64_t)N * K;
-    hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3((unsigned)((NK + RD_E - 1) / RD_E)), dim3(RD_E * RD_S), 0, s, workspace,
-                       p.splits, NK, out);
-    return check_launch();
+    return launch_tn(dY, A, M, N, K, out, workspace, nullptr, s);
+}
+
+// The same contraction with both operands formed while they are staged (see the file header):
+//   Y (M,N), dA ((M,N), or (M/ns,N) with argmax), statistics rows of the layer (N each), c1 / c2 from
+//   tp3d_bn_bwd_reduce_f32;  A operand: either plain rows A (M,K) (mean_k == NULL) or the previous layer's pre-BatchNorm
+//   output with its statistics rows (K each).  N % 4 == 0 and K % 4 == 0.
+TP3D_EXPORT int tp3d_gemm_tn_bn_f32(const float *Y, const float *dA, const int *argmax, int ns, const float *mean_n,
+                                    const float *scale_n, const float *beta_n, const float *c1_n, const float *c2_n,
+                                    float slope_n, const float *A, const float *mean_k, const float *scale_k,
+                                    const float *beta_k, float slope_k, int64_t M, int N, int K, float *out,
+                                    float *workspace, void *stream)
+{
+    if (M < 0 || N <= 0 || K <= 0 || !out || ns <= 0) return TP3D_E_BADARG;
+    hipStream_t s = (hipStream_t)stream;
+    if (M == 0) return zero_async(out, (size_t)N * K * sizeof(float), s);
+    if (!Y || !dA || !A || !workspace || !mean_n || !scale_n || !beta_n || !c1_n || !c2_n) return TP3D_E_BADARG;
+    if (mean_k && (!scale_k || !beta_k)) return TP3D_E_BADARG;
+    if (argmax && M % ns) return TP3D_E_BADARG;
+    TnPrologue pro = {};
+    pro.dA = dA, pro.argmax = argmax, pro.mean_n = mean_n, pro.scale_n = scale_n, pro.beta_n = beta_n, pro.c1_n = c1_n;
+    pro.c2_n = c2_n, pro.slope_n = slope_n, pro.ns = ns;
+    pro.mean_k = mean_k, pro.scale_k = scale_k, pro.beta_k = beta_k, pro.slope_k = slope_k;
+    return launch_tn(Y, A, M, N, K, out, workspace, &pro, s);
 }

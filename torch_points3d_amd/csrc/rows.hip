@@ -524,16 +524,25 @@ __global__ __launch_bounds__(RW_BLOCK) void bn_pool_bwd_partial_kernel(const flo
     }
 }
 
-// sums the chunk partials: dbeta[c], dgamma[c]  (one workgroup per channel)
+// sums the chunk partials: dbeta[c], dgamma[c]  (one workgroup per channel); optionally also the two per-channel terms
+// the fused GEMM prologues subtract: c1 = dbeta / M, c2 = invstd * dgamma / M (zero when BatchNorm ran on running stats)
 __global__ __launch_bounds__(RW_BLOCK) void bn_bwd_finalize_kernel(const float *__restrict__ partial, int chunks,
                                                                     int C, float *__restrict__ dbeta,
-                                                                    float *__restrict__ dgamma)
+                                                                    float *__restrict__ dgamma,
+                                                                    const float *__restrict__ invstd, int64_t M,
+                                                                    int training, float *__restrict__ c1,
+                                                                    float *__restrict__ c2)
 {
     double a, q;
     sum_partials(partial, chunks, C, blockIdx.x, a, q);
     if (threadIdx.x == 0) {
         dbeta[blockIdx.x] = (float)a;
         dgamma[blockIdx.x] = (float)q;
+        if (c1) {
+            const float invM = 1.0f / (float)M;
+            c1[blockIdx.x] = training ? (float)a * invM : 0.0f;
+            c2[blockIdx.x] = training ? invstd[blockIdx.x] * ((float)q * invM) : 0.0f;
+        }
     }
 }
 
@@ -939,16 +948,12 @@ TP3D_EXPORT int tp3d_bn_act_maxpool_f32(const float *Y, const float *mean, const
     return check_launch();
 }
 
-TP3D_EXPORT int tp3d_bn_act_bwd_f32(const float *dA, const int *argmax, const float *Y, const float *scale,
-                                    const float *shift, const float *mean, const float *invstd, float slope,
-                                    int64_t M, int ns, int C, int training, float *dbeta, float *dgamma, float *dY,
-                                    float *workspace, void *stream)
+namespace tp3d {
+// pass 1 of the BatchNorm + activation backward: partial sums, then dbeta / dgamma (and c1 / c2 when asked for)
+static int bn_bwd_reduce(const float *dA, const int *argmax, const float *Y, const float *scale, const float *shift,
+                         const float *mean, const float *invstd, float slope, int64_t M, int ns, int C, int training,
+                         float *dbeta, float *dgamma, float *c1, float *c2, float *workspace, hipStream_t s)
 {
-    // dA: (M, C) dense when argmax == NULL, else the pooled gradient (M/ns, C) with its arg-max rows
-    if (M <= 0 || C <= 0 || ns <= 0 || (argmax && M % ns)) return TP3D_E_BADARG;
-    if (!dA || !Y || !scale || !shift || !mean || !invstd || !dbeta || !dgamma || !dY || !workspace)
-        return TP3D_E_BADARG;
-    hipStream_t s = (hipStream_t)stream;
     const int64_t R = argmax ? M / ns : M;  // rows of the reduction domain
     const int crow = stat_rows(R);
     const int chunks = (int)((R + crow - 1) / crow);
@@ -966,8 +971,38 @@ TP3D_EXPORT int tp3d_bn_act_bwd_f32(const float *dA, const int *argmax, const fl
                            shift, mean, invstd, slope, M, C, t.colthreads, crow, workspace);
     }
     if (int rc = check_launch()) return rc;
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(RW_BLOCK), 0, s, workspace, chunks, C, dbeta, dgamma);
-    if (int rc = check_launch()) return rc;
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(RW_BLOCK), 0, s, workspace, chunks, C, dbeta, dgamma, invstd, M,
+                       training, c1, c2);
+    return check_launch();
+}
+}  // namespace tp3d
+
+TP3D_EXPORT int tp3d_bn_bwd_reduce_f32(const float *dA, const int *argmax, const float *Y, const float *scale,
+                                       const float *shift, const float *mean, const float *invstd, float slope,
+                                       int64_t M, int ns, int C, int training, float *dbeta, float *dgamma, float *c1,
+                                       float *c2, float *workspace, void *stream)
+{
+    if (M <= 0 || C <= 0 || ns <= 0 || (argmax && M % ns)) return TP3D_E_BADARG;
+    if (!dA || !Y || !scale || !shift || !mean || !invstd || !dbeta || !dgamma || !c1 || !c2 || !workspace)
+        return TP3D_E_BADARG;
+    return bn_bwd_reduce(dA, argmax, Y, scale, shift, mean, invstd, slope, M, ns, C, training, dbeta, dgamma, c1, c2,
+                         workspace, (hipStream_t)stream);
+}
+
+TP3D_EXPORT int tp3d_bn_act_bwd_f32(const float *dA, const int *argmax, const float *Y, const float *scale,
+                                    const float *shift, const float *mean, const float *invstd, float slope,
+                                    int64_t M, int ns, int C, int training, float *dbeta, float *dgamma, float *dY,
+                                    float *workspace, void *stream)
+{
+    // dA: (M, C) dense when argmax == NULL, else the pooled gradient (M/ns, C) with its arg-max rows
+    if (M <= 0 || C <= 0 || ns <= 0 || (argmax && M % ns)) return TP3D_E_BADARG;
+    if (!dA || !Y || !scale || !shift || !mean || !invstd || !dbeta || !dgamma || !dY || !workspace)
+        return TP3D_E_BADARG;
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t R = argmax ? M / ns : M;  // rows of the reduction domain
+    if (int rc = bn_bwd_reduce(dA, argmax, Y, scale, shift, mean, invstd, slope, M, ns, C, training, dbeta, dgamma, nullptr,
+                               nullptr, workspace, s))
+        return rc;
     if (argmax) {
         int split = (int)((262144 + R * C - 1) / (R * C));  // ~4 waves per SIMD worth of lanes
         split = split < 1 ? 1 : (split > ns ? ns : split);

@@ -100,21 +100,44 @@ def _is_skinny(M, a, b):
 
 
 def gemm_rows(A, Bt, want_stats=False):
-    """A (M,K) @ Bt (N,K)^T -> (M,N) with the fp32 MFMA rows kernel (csrc/gemm_rows.hip); optionally also the
-    per-128-row-block column sums / sums of squares for BatchNorm.  K must be a multiple of 4."""
+    """A (M,K) @ Bt (N,K)^T -> (M,N) with the fp32 MFMA rows kernel (csrc/gemm_rows.hip); optionally also the shifted
+    partial column sums for BatchNorm (then returned as `part`).  K must be a multiple of 4.  Without statistics a
+    long contraction with few output tiles is split over K-ranges (two-level summation, more workgroups)."""
     dev = A.device
     M, K = A.shape
     N = Bt.shape[0]
     Bm = Bt.contiguous()
     C = torch.empty((M, N), dtype=torch.float32, device=dev)
-    part = None
+    part, slabs = None, None
+    h = _lib.load()
     if want_stats:
-        part = _lib.workspace("gemm_rows_stats", 4 * _lib.load().tp3d_gemm_rows_stat_floats(M, N), dev)
+        part = _lib.workspace("gemm_rows_stats", 4 * h.tp3d_gemm_rows_stat_floats(M, N), dev)
+    else:
+        n = h.tp3d_gemm_rows_workspace_floats(M, N, K)
+        if n:
+            slabs = _lib.workspace("gemm_rows_slabs", 4 * n, dev)
     with _lib.on_device(dev):
-        _lib.call("tp3d_gemm_rows_f32", _lib.ptr(A), _lib.ptr(Bm), M, N, K, _lib.ptr(C), _lib.ptr(part),
+        _lib.call("tp3d_gemm_rows_f32", _lib.ptr(A), _lib.ptr(Bm), M, N, K, _lib.ptr(C), _lib.ptr(part), _lib.ptr(slabs),
                   _lib.stream_ptr(dev))
     return C, part
 
+
+def _finalize_stats(part, M, C, gamma, beta, bn, dev, st):
+    """(4, C) = mean, invstd, scale, beta from the shifted partial sums a rows GEMM left in `part` (training mode)."""
+    stats = torch.empty((4, C), dtype=torch.float32, device=dev)
+    _lib.call("tp3d_bn_finalize_f32", _lib.ptr(part), _lib.load().tp3d_gemm_rows_stat_chunks(M, C), M, C, float(bn.eps),
+              float(bn.momentum), _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(bn.running_mean), _lib.ptr(bn.running_var),
+              _lib.ptr(stats[0]), _lib.ptr(stats[1]), _lib.ptr(stats[2]), _lib.ptr(stats[3]), st)
+    return stats
+
+
+ROWS_GEMM_MIN_COLS = 32   # narrower outputs (class scores, edge MLPs) stay on the library / skinny kernels
+CHAIN_MIN_ROWS = 32768    # the fused layer chain serves the large row matrices (grouped / per-point activations)
+
+
+def _long_k(M, N, K):
+    """few output tiles and a long contraction: served by the K-split launch (no fused statistics)"""
+    return _lib.load().tp3d_gemm_rows_workspace_floats(M, N, K) > 0
 
 
 def _bn_stats(Y, M, C, gamma, beta, bn, training, dev, st, bias=None):
@@ -157,31 +180,21 @@ class _LinearBNAct(torch.autograd.Function):
             W2 = torch.nn.functional.pad(W2, (0, Kp - Cin))
         training = bn.training
         st = _lib.stream_ptr(dev)
-        # measured on MI355X (tools/microbench.py gemm_rows): with the statistics fused, the rows kernel beats
-        # "library GEMM + separate statistics pass" when its 128-wide column tiles are full; for other widths
-        # (64, 132, the 10-class head) the library GEMM plus tp3d_bn_stats_f32 is faster
-        own_gemm = USE_ROWS_GEMM and training and Cout % 128 == 0 and Kp % 4 == 0
-        # few output tiles and a long contraction (the 4096-row global layer, 1280 -> 256: 64 tiles): the rows kernel has
-        # no split over K, so the library GEMM plus the separate statistics pass wins (93 -> 27 + 12 us)
-        if own_gemm and ((M + 127) // 128) * (Cout // 128) < 128 and Kp >= 512:
-            own_gemm = False
+        # the dense contraction on the fp32 MFMA rows kernel (128- or 64-column tiles); BatchNorm statistics come out of
+        # its epilogue, except for the long contractions with few output tiles (the 4096-row global / decoder layers),
+        # which run as a K-split launch followed by the separate statistics pass over their small output
+        own_gemm = USE_ROWS_GEMM and Cout >= ROWS_GEMM_MIN_COLS and Kp % 4 == 0
         if own_gemm:
-            # the dense contraction on the fp32 MFMA rows kernel; BatchNorm statistics come out of its epilogue
-            Y, part = gemm_rows(A, W2, want_stats=training)
+            Y, part = gemm_rows(A, W2, want_stats=training and not _long_k(M, Cout, Kp))
         elif _is_skinny(M, Kp, Cout):
             Y = gemm_skinny(A, W2)  # edge-wise MLPs of a few channels: a pure stream, one row per lane
             part = None
         else:
-            Y = torch.mm(A, W2.t())  # plain library GEMM (unaligned channel counts, e.g. the 10-class head)
+            Y = torch.mm(A, W2.t())  # plain library GEMM (a handful of output columns, e.g. the 10-class head)
             part = None
         with _lib.on_device(dev):
             if part is not None:
-                stats = torch.empty((4, Cout), dtype=torch.float32, device=dev)  # mean, invstd, scale, shift
-                _lib.call("tp3d_bn_finalize_f32", _lib.ptr(part), _lib.load().tp3d_gemm_rows_stat_chunks(M, Cout), M, Cout,
-                          float(bn.eps),
-                          float(bn.momentum), _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(bn.running_mean),
-                          _lib.ptr(bn.running_var), _lib.ptr(stats[0]), _lib.ptr(stats[1]), _lib.ptr(stats[2]),
-                          _lib.ptr(stats[3]), st)
+                stats = _finalize_stats(part, M, Cout, gamma, beta, bn, dev, st)  # mean, invstd, scale, beta
             else:
                 stats = _bn_stats(Y, M, Cout, gamma, beta, bn, training, dev, st, bias)
             if pool_ns:
@@ -219,17 +232,150 @@ class _LinearBNAct(torch.autograd.Function):
                       int(training), _lib.ptr(dgb[0]), _lib.ptr(dgb[1]), _lib.ptr(dY), _lib.ptr(ws),
                       _lib.stream_ptr(dev))
         dW = gemm_tn(dY, A)[:, :Cin].reshape(wshape) if ctx.needs_input_grad[1] else None
-        # input gradient: nothing to fuse into its epilogue, and the library GEMM is 10-25 % faster than the rows
-        # kernel on these shapes (same measurement), so it stays a plain library GEMM
         dA = None
         if ctx.needs_input_grad[0]:
-            dA = gemm_skinny(dY, W2.t()) if _is_skinny(M, W2.shape[1], Cout) else torch.mm(dY, W2)
+            if _is_skinny(M, W2.shape[1], Cout):
+                dA = gemm_skinny(dY, W2.t())
+            elif USE_ROWS_GEMM and W2.shape[1] >= ROWS_GEMM_MIN_COLS and Cout % 4 == 0:
+                dA = gemm_rows(dY, W2.t())[0]  # dA[M,Kp] = dY[M,N] (W^T)[Kp,N]^T on the same rows kernel
+            else:
+                dA = torch.mm(dY, W2)
         dbias = None
         if has_bias and ctx.needs_input_grad[7]:
             # batch statistics remove the bias from the output (gradient exactly zero); running statistics do not
             dbias = torch.zeros(Y.shape[1], dtype=torch.float32, device=dev) if training else dY.sum(0)
         return dA, dW, dgb[1], dgb[0], None, None, None, dbias
 
+
+
+class _MLPChain(torch.autograd.Function):
+    """A whole shared MLP -- [1x1 conv -> BatchNorm -> LeakyReLU] x L (+ max over groups of pool_ns rows) -- on a large
+    row matrix, with every BatchNorm / activation pass folded into the GEMM that consumes its result
+    (core/common_modules/dense_modules.py:25-29 forward, autograd backward):
+
+      forward   Y_0 = A_0 W_0^T;  Y_l = act(BN(Y_{l-1})) W_l^T  -- the activated tensor is formed in the GEMM's prologue
+                from Y_{l-1}, never written; BatchNorm statistics come out of each GEMM's epilogue
+      backward  per layer one reduction pass (dbeta, dgamma), then
+                dW_l     = dY_l^T act(BN(Y_{l-1}))   both operands formed on the fly (tp3d_gemm_tn_bn_f32)
+                dA_{l-1} = dY_l W_l                  dY_l formed on the fly       (tp3d_gemm_rows_bnbwd_f32)
+                with dY_l = BatchNorm+activation backward of (dA_l, Y_l)
+
+    Per hidden layer the activation-sized traffic drops from 4 passes to 2 forward and from 9 to 7 backward, and only
+    the pre-BatchNorm outputs Y_l are kept for the backward pass."""
+
+    @staticmethod
+    def forward(ctx, A0, pool_ns, layers, *params):
+        # layers: [(bn module, slope)], params: [weight_0, gamma_0, beta_0, weight_1, ...]
+        dev = A0.device
+        A0 = A0.contiguous()
+        M = A0.shape[0]
+        st = _lib.stream_ptr(dev)
+        L = len(layers)
+        Ys, stats, W2s, cins = [], [], [], []
+        training = layers[0][0].training
+        h = _lib.load()
+        with _lib.on_device(dev):
+            for l, (bn, slope) in enumerate(layers):
+                weight, gamma, beta = params[3 * l], params[3 * l + 1], params[3 * l + 2]
+                Cout = weight.shape[0]
+                W2 = weight.reshape(Cout, -1)
+                Kp = A0.shape[1] if l == 0 else Ys[-1].shape[1]
+                cins.append(W2.shape[1])
+                if W2.shape[1] != Kp:
+                    W2 = torch.nn.functional.pad(W2, (0, Kp - W2.shape[1]))
+                W2 = W2.contiguous()
+                Y = torch.empty((M, Cout), dtype=torch.float32, device=dev)
+                part = _lib.workspace("gemm_rows_stats", 4 * h.tp3d_gemm_rows_stat_floats(M, Cout), dev) if training else None
+                if l == 0:
+                    _lib.call("tp3d_gemm_rows_f32", _lib.ptr(A0), _lib.ptr(W2), M, Cout, Kp, _lib.ptr(Y), _lib.ptr(part), None, st)
+                else:
+                    ps = stats[-1]
+                    _lib.call("tp3d_gemm_rows_bnact_f32", _lib.ptr(Ys[-1]), _lib.ptr(ps[0]), _lib.ptr(ps[2]), _lib.ptr(ps[3]),
+                              layers[l - 1][1], _lib.ptr(W2), M, Cout, Kp, _lib.ptr(Y), _lib.ptr(part), st)
+                if training:
+                    stats.append(_finalize_stats(part, M, Cout, gamma, beta, bn, dev, st))
+                    bn.num_batches_tracked.add_(1)
+                else:
+                    stats.append(_bn_stats(Y, M, Cout, gamma, beta, bn, False, dev, st))
+                Ys.append(Y)
+                W2s.append(W2)
+            Y, ls, slope = Ys[-1], stats[-1], layers[-1][1]
+            C = Y.shape[1]
+            if pool_ns:
+                G = M // pool_ns
+                out = torch.empty((G, C), dtype=torch.float32, device=dev)
+                arg = torch.empty((G, C), dtype=torch.int32, device=dev)
+                _lib.call("tp3d_bn_act_maxpool_f32", _lib.ptr(Y), _lib.ptr(ls[0]), _lib.ptr(ls[2]), _lib.ptr(ls[3]), slope, G,
+                          pool_ns, C, _lib.ptr(out), _lib.ptr(arg), st)
+            else:
+                arg = None
+                out = torch.empty((M, C), dtype=torch.float32, device=dev)
+                _lib.call("tp3d_bn_act_f32", _lib.ptr(Y), _lib.ptr(ls[0]), _lib.ptr(ls[2]), _lib.ptr(ls[3]), slope, M, C,
+                          _lib.ptr(out), st)
+        ctx.save_for_backward(A0, arg, *Ys, *stats, *W2s)
+        ctx.cfg = (L, pool_ns, training, [s_ for _, s_ in layers], [tuple(params[3 * l].shape) for l in range(L)], cins)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        L, pool_ns, training, slopes, wshapes, cins = ctx.cfg
+        saved = ctx.saved_tensors
+        A0, arg = saved[0], saved[1]
+        Ys, stats, W2s = saved[2:2 + L], saved[2 + L:2 + 2 * L], saved[2 + 2 * L:2 + 3 * L]
+        dev = grad_out.device
+        st = _lib.stream_ptr(dev)
+        M = A0.shape[0]
+        dcur = grad_out.contiguous()
+        grads = [None] * (3 * L)
+        dA0 = None
+        with _lib.on_device(dev):
+            for l in range(L - 1, -1, -1):
+                Y, ls, W2, slope = Ys[l], stats[l], W2s[l], slopes[l]
+                C, Kp = W2.shape
+                pooled = bool(pool_ns) and l == L - 1
+                a_ptr, ns = (_lib.ptr(arg), pool_ns) if pooled else (None, 1)
+                red = torch.empty((4, C), dtype=torch.float32, device=dev)  # dbeta, dgamma, c1, c2
+                ws = _lib.bn_workspace(M, C, dev)
+                _lib.call("tp3d_bn_bwd_reduce_f32", _lib.ptr(dcur), a_ptr, _lib.ptr(Y), _lib.ptr(ls[2]), _lib.ptr(ls[3]),
+                          _lib.ptr(ls[0]), _lib.ptr(ls[1]), slope, M, ns, C, int(training), _lib.ptr(red[0]), _lib.ptr(red[1]),
+                          _lib.ptr(red[2]), _lib.ptr(red[3]), _lib.ptr(ws), st)
+                grads[3 * l + 1], grads[3 * l + 2] = red[1], red[0]
+                if ctx.needs_input_grad[3 + 3 * l]:
+                    dW = torch.empty((C, Kp), dtype=torch.float32, device=dev)
+                    tws = _lib.gemm_tn_workspace(M, C, Kp, dev)
+                    if l == 0:
+                        a_src, km, ks_, kb, kslope = A0, None, None, None, 1.0
+                    else:
+                        ps = stats[l - 1]
+                        a_src, km, ks_, kb, kslope = Ys[l - 1], _lib.ptr(ps[0]), _lib.ptr(ps[2]), _lib.ptr(ps[3]), slopes[l - 1]
+                    _lib.call("tp3d_gemm_tn_bn_f32", _lib.ptr(Y), _lib.ptr(dcur), a_ptr, ns, _lib.ptr(ls[0]), _lib.ptr(ls[2]),
+                              _lib.ptr(ls[3]), _lib.ptr(red[2]), _lib.ptr(red[3]), slope, _lib.ptr(a_src), km, ks_, kb, kslope,
+                              M, C, Kp, _lib.ptr(dW), _lib.ptr(tws), st)
+                    grads[3 * l] = dW[:, :cins[l]].reshape(wshapes[l])
+                if l > 0 or ctx.needs_input_grad[0]:
+                    Wt = W2.t().contiguous()  # (Kp, C): dA_{l-1}[M,Kp] = dY_l[M,C] (W^T)[Kp,C]^T
+                    dprev = torch.empty((M, Kp), dtype=torch.float32, device=dev)
+                    _lib.call("tp3d_gemm_rows_bnbwd_f32", _lib.ptr(Y), _lib.ptr(dcur), a_ptr, ns, _lib.ptr(ls[0]),
+                              _lib.ptr(ls[2]), _lib.ptr(ls[3]), _lib.ptr(red[2]), _lib.ptr(red[3]), slope, _lib.ptr(Wt), M, Kp, C,
+                              _lib.ptr(dprev), st)
+                    dcur = dprev
+                    if l == 0:
+                        dA0 = dprev
+        return (dA0, None, None) + tuple(grads)
+
+
+def _chain_ok(rows, parts):
+    """the fused layer chain serves MLPs on large row matrices whose widths suit the rows kernel's operands"""
+    if not USE_MLP_CHAIN or rows.shape[0] < CHAIN_MIN_ROWS or rows.shape[1] % 4:
+        return False
+    for conv, bn, slope in parts:
+        cout = conv.weight.shape[0]
+        if getattr(conv, "bias", None) is not None or cout % 4 or cout < ROWS_GEMM_MIN_COLS or cout > 1536:
+            return False
+    return True
+
+
+USE_MLP_CHAIN = True
 
 
 class _BNAct(torch.autograd.Function):
@@ -379,6 +525,11 @@ def rows_mlp(mlp, x):
 
 def run_mlp(rows, parts, pool_ns=0):
     """Shared MLP over rows; the last layer optionally max-pools groups of pool_ns consecutive rows."""
+    if _chain_ok(rows, parts):
+        flat = []
+        for conv, bn, slope in parts:
+            flat += [conv.weight, bn.weight, bn.bias]
+        return _MLPChain.apply(rows, pool_ns, [(bn, slope) for _, bn, slope in parts], *flat)
     for i, (conv, bn, slope) in enumerate(parts):
         rows = linear_bn_act(rows, conv, bn, slope, pool_ns if i == len(parts) - 1 else 0)
     return rows
