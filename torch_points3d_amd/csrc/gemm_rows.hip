@@ -93,7 +93,7 @@ __global__ __launch_bounds__(GR_BLOCK_T, (WIDE && PRO != PRO_NONE) ? 2 : 1) void
     // apart, i.e. on the same XCD (shared L2 for A).  Workgroups are PERSISTENT: each walks items id, id + G, ...
     // (G a multiple of 8) as one flat sequence of K-steps, so the loads of the next item's first K-step are already
     // in flight while this item's epilogue stores drain -- no exposed prologue/epilogue latency per tile.
-    auto decode = [&](int64_t item, int64_t &m0, int &n0, int64_t &rb) {
+    auto decode = [&](int64_t item, int64_t &m0, int &n0, int64_t &rb) __attribute__((always_inline)) {
         const int64_t grp = item / (8 * tiles_n);
         const int rem = (int)(item % (8 * tiles_n));
         rb = grp * 8 + (rem & 7);
@@ -103,11 +103,12 @@ __global__ __launch_bounds__(GR_BLOCK_T, (WIDE && PRO != PRO_NONE) ? 2 : 1) void
 
     // staging registers: the A tile is 128 rows x 32 k = 1024 float4 (4 per thread), raw as loaded; the prologue is
     // applied when they are written to LDS one K-step later (the loads have had a whole MFMA phase to land by then)
-    float4 ra[4], ra2[PRO >= PRO_BNBWD ? 4 : 1], rbv[PB];
-    int4 rarg[PRO == PRO_BNBWD_POOL ? 4 : 1];
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 ra[4] = {zero4, zero4, zero4, zero4}, ra2[4] = {zero4, zero4, zero4, zero4};
+    float4 rb0 = zero4, rb1 = zero4, rb2 = zero4, rb3 = zero4;  // B tile staging (named: an array of them ended up in scratch)
+    int4 rarg[4] = {make_int4(0, 0, 0, 0), make_int4(0, 0, 0, 0), make_int4(0, 0, 0, 0), make_int4(0, 0, 0, 0)};
     const int k4 = (tid & 7) * 4;  // this thread's k offset inside a K-step (tid + i*256: the same for all four slots)
-    auto fetch = [&](int64_t m0, int n0, int k0) {
+    auto fetch = [&](int64_t m0, int n0, int k0) __attribute__((always_inline)) {
         const bool kin = k0 + k4 < kend;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -122,49 +123,41 @@ __global__ __launch_bounds__(GR_BLOCK_T, (WIDE && PRO != PRO_NONE) ? 2 : 1) void
                 rarg[i] = in ? *reinterpret_cast<const int4 *>(pro.argmax + g * K + k0 + k4) : make_int4(-1, -1, -1, -1);
             }
         }
-#pragma unroll
-        for (int i = 0; i < PB; ++i) {
+        auto loadB = [&](int i) __attribute__((always_inline)) -> float4 {
             const int n = n0 + (tid >> 3) + i * 32;
-            rbv[i] = (n < N && kin) ? *reinterpret_cast<const float4 *>(Bt + (size_t)n * K + k0 + k4) : zero4;
+            return (n < N && kin) ? *reinterpret_cast<const float4 *>(Bt + (size_t)n * K + k0 + k4) : zero4;
+        };
+        rb0 = loadB(0);
+        rb1 = loadB(1);
+        if (PB > 2) {
+            rb2 = loadB(2);
+            rb3 = loadB(3);
         }
     };
     // the prologue on one staged float4 (k = kk .. kk+3); out-of-range rows / k were loaded as zeros and MUST stay zero
-    auto transform = [&](int i, int64_t m0, int kk, bool in) -> float4 {
-        if (PRO == PRO_NONE) return ra[i];
-        if (!in) return zero4;
+    auto bn_forward = [&](const float4 raw, int kk) __attribute__((always_inline)) -> float4 {
         const float4 mu = *reinterpret_cast<const float4 *>(&sK[0 * GR_PRO_KMAX + kk]);
         const float4 sc = *reinterpret_cast<const float4 *>(&sK[1 * GR_PRO_KMAX + kk]);
         const float4 be = *reinterpret_cast<const float4 *>(&sK[2 * GR_PRO_KMAX + kk]);
-        const float y[4] = {ra[i].x, ra[i].y, ra[i].z, ra[i].w};
-        const float m_[4] = {mu.x, mu.y, mu.z, mu.w}, s_[4] = {sc.x, sc.y, sc.z, sc.w}, b_[4] = {be.x, be.y, be.z, be.w};
-        float o[4];
-        if (PRO == PRO_BNACT) {
-#pragma unroll
-            for (int v = 0; v < 4; ++v) {
-                const float z = (y[v] - m_[v]) * s_[v] + b_[v];
-                o[v] = z > 0.0f ? z : z * pro.slope;
-            }
-        } else {
-            const float4 c1 = *reinterpret_cast<const float4 *>(&sK[3 * GR_PRO_KMAX + kk]);
-            const float4 c2 = *reinterpret_cast<const float4 *>(&sK[4 * GR_PRO_KMAX + kk]);
-            const float k1[4] = {c1.x, c1.y, c1.z, c1.w}, k2[4] = {c2.x, c2.y, c2.z, c2.w};
-            float d[4] = {ra2[i].x, ra2[i].y, ra2[i].z, ra2[i].w};
-            if (PRO == PRO_BNBWD_POOL) {
-                const int64_t m = m0 + (tid >> 3) + i * 32;
-                const int s = (int)(m - (m / pro.ns) * pro.ns);
-                const int a_[4] = {rarg[i].x, rarg[i].y, rarg[i].z, rarg[i].w};
-#pragma unroll
-                for (int v = 0; v < 4; ++v) d[v] = a_[v] == s ? d[v] : 0.0f;
-            }
-#pragma unroll
-            for (int v = 0; v < 4; ++v) {
-                const float yc = y[v] - m_[v];
-                const float z = yc * s_[v] + b_[v];
-                const float dz = d[v] * (z > 0.0f ? 1.0f : pro.slope);
-                o[v] = s_[v] * ((dz - k1[v]) - yc * k2[v]);
-            }
-        }
-        return make_float4(o[0], o[1], o[2], o[3]);
+        const float z0 = (raw.x - mu.x) * sc.x + be.x, z1 = (raw.y - mu.y) * sc.y + be.y;
+        const float z2 = (raw.z - mu.z) * sc.z + be.z, z3 = (raw.w - mu.w) * sc.w + be.w;
+        return make_float4(z0 > 0.0f ? z0 : z0 * pro.slope, z1 > 0.0f ? z1 : z1 * pro.slope,
+                           z2 > 0.0f ? z2 : z2 * pro.slope, z3 > 0.0f ? z3 : z3 * pro.slope);
+    };
+    auto bn_backward = [&](const float4 raw, const float4 d, int kk) __attribute__((always_inline)) -> float4 {
+        const float4 mu = *reinterpret_cast<const float4 *>(&sK[0 * GR_PRO_KMAX + kk]);
+        const float4 sc = *reinterpret_cast<const float4 *>(&sK[1 * GR_PRO_KMAX + kk]);
+        const float4 be = *reinterpret_cast<const float4 *>(&sK[2 * GR_PRO_KMAX + kk]);
+        const float4 c1 = *reinterpret_cast<const float4 *>(&sK[3 * GR_PRO_KMAX + kk]);
+        const float4 c2 = *reinterpret_cast<const float4 *>(&sK[4 * GR_PRO_KMAX + kk]);
+        auto one = [&](float y, float dd, float m, float s_, float b, float k1, float k2) __attribute__((always_inline)) -> float {
+            const float yc = y - m;
+            const float z = yc * s_ + b;
+            const float dz = dd * (z > 0.0f ? 1.0f : pro.slope);
+            return s_ * ((dz - k1) - yc * k2);
+        };
+        return make_float4(one(raw.x, d.x, mu.x, sc.x, be.x, c1.x, c2.x), one(raw.y, d.y, mu.y, sc.y, be.y, c1.y, c2.y),
+                           one(raw.z, d.z, mu.z, sc.z, be.z, c1.z, c2.z), one(raw.w, d.w, mu.w, sc.w, be.w, c1.w, c2.w));
     };
 
     int64_t item = blockIdx.x;
@@ -197,10 +190,30 @@ __global__ __launch_bounds__(GR_BLOCK_T, (WIDE && PRO != PRO_NONE) ? 2 : 1) void
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int row = (tid >> 3) + i * 32;
-                *reinterpret_cast<float4 *>(&sA[row * GR_LD + k4]) = transform(i, m0, kk, m0 + row < M && kk < kend);
+                float4 t = ra[i];
+                if constexpr (PRO != PRO_NONE) {
+                    if (m0 + row < M && kk < kend) {
+                        if constexpr (PRO == PRO_BNACT) t = bn_forward(ra[i], kk);
+                        if constexpr (PRO == PRO_BNBWD) t = bn_backward(ra[i], ra2[i], kk);
+                        if constexpr (PRO == PRO_BNBWD_POOL) {
+                            const int64_t m = m0 + row;
+                            const int sl = (int)(m - (m / pro.ns) * pro.ns);
+                            const float4 d = make_float4(rarg[i].x == sl ? ra2[i].x : 0.0f, rarg[i].y == sl ? ra2[i].y : 0.0f,
+                                                         rarg[i].z == sl ? ra2[i].z : 0.0f, rarg[i].w == sl ? ra2[i].w : 0.0f);
+                            t = bn_backward(ra[i], d, kk);
+                        }
+                    } else {
+                        t = zero4;
+                    }
+                }
+                *reinterpret_cast<float4 *>(&sA[row * GR_LD + k4]) = t;
             }
-#pragma unroll
-            for (int i = 0; i < PB; ++i) *reinterpret_cast<float4 *>(&sB[((tid >> 3) + i * 32) * GR_LD + k4]) = rbv[i];
+            *reinterpret_cast<float4 *>(&sB[((tid >> 3) + 0 * 32) * GR_LD + k4]) = rb0;
+            *reinterpret_cast<float4 *>(&sB[((tid >> 3) + 1 * 32) * GR_LD + k4]) = rb1;
+            if (PB > 2) {
+                *reinterpret_cast<float4 *>(&sB[((tid >> 3) + 2 * 32) * GR_LD + k4]) = rb2;
+                *reinterpret_cast<float4 *>(&sB[((tid >> 3) + 3 * 32) * GR_LD + k4]) = rb3;
+            }
             __syncthreads();
             if (ks + 1 < ksteps) fetch(m0, n0, kbeg + (ks + 1) * GR_BK);
             else if (next_item < items) fetch(nm0, nn0, kbeg);  // next item's first K-step rides under this epilogue
@@ -305,6 +318,188 @@ __global__ __launch_bounds__(GR_BLOCK_T, (WIDE && PRO != PRO_NONE) ? 2 : 1) void
     }
 }
 
+// The plain 128 x 128 kernel (no prologue, no K-split): the forward GEMM of the wide layers, kept as its own
+// instantiation because it is the one that has to fit two waves per SIMD (182 VGPRs + 64 accumulators, no scratch).
+// STATS: 0 none, 1 one statistics chunk per (128-row block, wave row), 2 one per (workgroup, wave row) (needs
+// gridDim.x % (8*tiles_n) == 0: every item of a workgroup then lies in the same column tile)
+template <int STATS>
+__global__ __launch_bounds__(GR_BLOCK_T) void gemm_rows_wide_kernel(const float *__restrict__ A, const float *__restrict__ Bt,
+                                                                int64_t M, int N, int K, int tiles_n, int64_t items,
+                                                                float *__restrict__ C, float *__restrict__ partial)
+{
+    __shared__ __attribute__((aligned(16))) float sA[GR_BM * GR_LD];
+    __shared__ __attribute__((aligned(16))) float sB[128 * GR_LD];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int ksteps = (K + GR_BK - 1) / GR_BK;
+
+    // Work items = (row block, column tile) in an XCD-aware order: the column tiles of one row block are 8 ids
+    // apart, i.e. on the same XCD (shared L2 for A).  Workgroups are PERSISTENT: each walks items id, id + G, ...
+    // (G a multiple of 8) as one flat sequence of K-steps, so the loads of the next item's first K-step are already
+    // in flight while this item's epilogue stores drain -- no exposed prologue/epilogue latency per tile.
+    auto decode = [&](int64_t item, int64_t &m0, int &n0, int64_t &rb) {
+        const int64_t grp = item / (8 * tiles_n);
+        const int rem = (int)(item % (8 * tiles_n));
+        rb = grp * 8 + (rem & 7);
+        m0 = rb * GR_BM;
+        n0 = (rem >> 3) * 128;
+    };
+
+    // staging registers: each tile is 128 rows x 32 k = 1024 float4 (4 per thread and operand)
+    float4 ra[4], rbv[4];
+    auto fetch = [&](int64_t m0, int n0, int k0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int e = tid + i * GR_BLOCK_T;
+            const int row = e >> 3, k4 = (e & 7) * 4;  // 8 float4 per row
+            const int64_t m = m0 + row;
+            ra[i] = (m < M && k0 + k4 < K) ? *reinterpret_cast<const float4 *>(A + m * K + k0 + k4)
+                                           : make_float4(0.f, 0.f, 0.f, 0.f);
+            const int n = n0 + row;
+            rbv[i] = (n < N && k0 + k4 < K) ? *reinterpret_cast<const float4 *>(Bt + (size_t)n * K + k0 + k4)
+                                            : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+
+    int64_t item = blockIdx.x;
+    if (item >= items) return;
+    int64_t m0, rb;
+    int n0;
+    decode(item, m0, n0, rb);
+    fetch(m0, n0, 0);
+
+    const int n0_first = n0;
+    float run1[2] = {0.0f, 0.0f}, run2[2] = {0.0f, 0.0f};  // STATS == 2: this thread's share over all its items
+    float kshift[2] = {0.0f, 0.0f};
+    bool have_shift = false;
+    int run_rows = 0;
+    f32x16 acc[2][2];
+    while (item < items) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+        const int64_t next_item = item + gridDim.x;
+        int64_t nm0 = 0, nrb = 0;
+        int nn0 = 0;
+        if (next_item < items) decode(next_item, nm0, nn0, nrb);
+
+        for (int ks = 0; ks < ksteps; ++ks) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int e = tid + i * GR_BLOCK_T;
+                const int o = (e >> 3) * GR_LD + (e & 7) * 4;
+                *reinterpret_cast<float4 *>(&sA[o]) = ra[i];
+                *reinterpret_cast<float4 *>(&sB[o]) = rbv[i];
+            }
+            __syncthreads();
+            if (ks + 1 < ksteps) fetch(m0, n0, (ks + 1) * GR_BK);
+            else if (next_item < items) fetch(nm0, nn0, 0);  // next item's first K-step rides under this epilogue
+#pragma unroll
+            for (int g = 0; g < GR_BK / 8; ++g) {
+                float4 a[2], b[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+                    a[i] = *reinterpret_cast<const float4 *>(&sA[((wr * 2 + i) * 32 + l31) * GR_LD + g * 8 + lh * 4]);
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    b[j] = *reinterpret_cast<const float4 *>(&sB[((wc * 2 + j) * 32 + l31) * GR_LD + g * 8 + lh * 4]);
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].x, b[j].x, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].y, b[j].y, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].z, b[j].z, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, b[j].w, acc[i][j], 0, 0, 0);
+                    }
+            }
+            __syncthreads();
+        }
+
+        // ---- epilogue: D[row][col], col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int n = n0 + (wc * 2 + j) * 32 + l31;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int64_t m = m0 + (wr * 2 + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                    if (m < M && n < N) C[m * N + n] = acc[i][j][e];
+                }
+            }
+        if (STATS != 0) {
+            // Column statistics of this wave's 64 x 64 part of the tile as SHIFTED sums (d = v - K; K = the first value
+            // the wave saw in that column): free of the cancellation E[y^2] - E[y]^2 suffers when |mean| >> std.
+            // Rows past M were staged as zeros, i.e. each of the `pad` such rows of this wave added d = -K: taken out again
+            // below (only the last row block of a matrix has any).  STATS == 1: one chunk per (row block, wave row);
+            // STATS == 2: the sums run on over all items of the workgroup, one chunk per (workgroup, wave row).
+            const int valid = (int)min((int64_t)64, max((int64_t)0, M - (m0 + wr * 64)));  // wave-uniform
+            const float pad = (float)(64 - valid);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                if (STATS == 1 || !have_shift) kshift[j] = __shfl(acc[0][j][0], l31);  // first row of this wave's part
+                const float k = kshift[j];
+                float s1 = 0.0f, s2 = 0.0f;
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const float d = acc[i][j][e] - k;
+                        s1 += d;
+                        s2 += d * d;
+                    }
+                s1 += __shfl_xor(s1, 32);  // the two half-waves hold different rows of the same column
+                s2 += __shfl_xor(s2, 32);
+                s1 += pad * k;
+                s2 -= pad * (k * k);
+                if (STATS == 2) {
+                    run1[j] += s1;  // (both half-waves now hold the wave's sum; written once below)
+                    run2[j] += s2;
+                } else {
+                    const int n = n0 + (wc * 2 + j) * 32 + l31;
+                    if (lh == 0 && n < N && m0 < M) {  // padding items (row block past M) own no statistics rows
+                        float *pr = partial + ((size_t)(rb * 2 + wr) * 4) * N + n;
+                        pr[0] = s1;
+                        pr[(size_t)N] = s2;
+                        pr[(size_t)2 * N] = k;
+                        pr[(size_t)3 * N] = (float)valid;
+                    }
+                }
+            }
+            if (STATS == 2) {
+                if (valid > 0) have_shift = true;  // a wave whose first items were padding keeps looking for a shift
+                run_rows += valid;
+            }
+        }
+        item = next_item;
+        m0 = nm0;
+        n0 = nn0;
+        rb = nrb;
+    }
+    if (STATS == 2) {
+        const int per = 8 * tiles_n;
+        const int64_t slot = (int64_t)(blockIdx.x / per) * 8 + (blockIdx.x & 7);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int n = n0_first + (wc * 2 + j) * 32 + l31;
+            if (lh == 0 && n < N) {
+                float *pr = partial + ((size_t)(slot * 2 + wr) * 4) * N + n;
+                pr[0] = run1[j];
+                pr[(size_t)N] = run2[j];
+                pr[(size_t)2 * N] = kshift[j];
+                pr[(size_t)3 * N] = (float)run_rows;
+            }
+        }
+    }
+}
+
+
 // out[e] = sum_s slab[s][e], s ascending (fixed order => reproducible); one float4 per thread
 __global__ __launch_bounds__(256) void gemm_rows_sum_slabs_kernel(const float *__restrict__ slabs, int S, int64_t MN4,
                                                                    float *__restrict__ out)
@@ -353,9 +548,10 @@ RowsPlan rows_plan(int64_t M, int N, int K = 0, bool allow_split = false)
     p.chunks = p.wave_rows * (p.per_workgroup ? GR_GRID / p.tiles_n : p.row_blocks);
     p.ksplit = 1;
     p.kchunk = K > 0 ? (K + GR_BK - 1) / GR_BK * GR_BK : 0;
-    if (allow_split && K >= 256 && p.items <= 256) {
-        // few output tiles and a long contraction: K-ranges of >= 128 until ~1024 workgroups are in flight
-        const int want = (int)((GR_GRID + p.items - 1) / p.items);
+    if (allow_split && K >= 1024 && p.items <= 128) {
+        // few output tiles and a very long contraction (the 1280 / 1536-channel decoder layers): K-ranges of >= 128
+        // (every range writes an M x N slab that the summing pass reads back, so no more ranges than needed)
+        const int want = (int)((512 + p.items - 1) / p.items);
         const int by_k = K / 128;
         int s = want < by_k ? want : by_k;
         if (s > 16) s = 16;
@@ -372,6 +568,15 @@ int launch_rows(const RowsPlan &p, const float *A, const float *Bt, int64_t M, i
                 const GemmPrologue &pro, hipStream_t s)
 {
     const dim3 grid((unsigned)p.blocks, (unsigned)p.ksplit), block(GR_BLOCK_T);
+    if (WIDE && PRO == PRO_NONE && p.ksplit == 1) {  // the dedicated plain 128 x 128 kernel
+        if (stat_partial && p.per_workgroup)
+            hipLaunchKernelGGL(gemm_rows_wide_kernel<2>, grid, block, 0, s, A, Bt, M, N, K, p.tiles_n, p.items, C, stat_partial);
+        else if (stat_partial)
+            hipLaunchKernelGGL(gemm_rows_wide_kernel<1>, grid, block, 0, s, A, Bt, M, N, K, p.tiles_n, p.items, C, stat_partial);
+        else
+            hipLaunchKernelGGL(gemm_rows_wide_kernel<0>, grid, block, 0, s, A, Bt, M, N, K, p.tiles_n, p.items, C, stat_partial);
+        return check_launch();
+    }
     if (stat_partial && p.per_workgroup)
         hipLaunchKernelGGL((gemm_rows_kernel<WIDE, PRO, 2>), grid, block, 0, s, A, Bt, M, N, K, p.kchunk, p.tiles_n, p.items,
                            C, stat_partial, pro);

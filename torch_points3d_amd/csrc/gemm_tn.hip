@@ -97,7 +97,7 @@ __global__ __launch_bounds__(TN_BLOCK) void gemm_tn_partial_kernel(const float *
     // VECY / VECA: that operand's rows are 16-byte aligned (ld % 4 == 0) -> float4 loads, else 4 scalar loads
 
     // four consecutive floats of row r starting at column c (zero past the row range / matrix edge)
-    auto load4 = [&](const float *base, int64_t r, int c, int ld, auto aligned_tag) -> float4 {
+    auto load4 = [&](const float *base, int64_t r, int c, int ld, auto aligned_tag) __attribute__((always_inline)) -> float4 {
         constexpr bool aligned = decltype(aligned_tag)::value;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (r < r_end) {
@@ -120,7 +120,7 @@ __global__ __launch_bounds__(TN_BLOCK) void gemm_tn_partial_kernel(const float *
                   "staged tile must be a whole number of float4 slots per thread");
     float4 ry[PY], ra[PA], rd[FUSED ? PY : 1];
     int4 rg[FUSED ? PY : 1];
-    auto fetch = [&](int64_t r0) {
+    auto fetch = [&](int64_t r0) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < PY; ++i) {
             const int e = tid + i * TN_BLOCK;
@@ -145,7 +145,7 @@ __global__ __launch_bounds__(TN_BLOCK) void gemm_tn_partial_kernel(const float *
         }
     };
     // prologues, applied when the staged values go to LDS; rows past the range / columns past the edge stay zero
-    auto make_dy = [&](int i, int64_t r0) -> float4 {
+    auto make_dy = [&](int i, int64_t r0) __attribute__((always_inline)) -> float4 {
         if (!(FUSED && proY)) return ry[i];
         const int e = tid + i * TN_BLOCK;
         const int64_t r = r0 + e / (TN / 4);
@@ -171,7 +171,7 @@ __global__ __launch_bounds__(TN_BLOCK) void gemm_tn_partial_kernel(const float *
         }
         return make_float4(o[0], o[1], o[2], o[3]);
     };
-    auto make_a = [&](int i, int64_t r0) -> float4 {
+    auto make_a = [&](int i, int64_t r0) __attribute__((always_inline)) -> float4 {
         if (!(FUSED && proA)) return ra[i];
         const int e = tid + i * TN_BLOCK;
         const int64_t r = r0 + e / (TK / 4);

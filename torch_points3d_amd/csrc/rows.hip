@@ -326,51 +326,54 @@ __device__ __forceinline__ void sum_partials(const float *__restrict__ partial, 
     q = r2[0];
 }
 
-// block-wide sum of one double per thread, fixed tree => reproducible
-__device__ __forceinline__ double block_sum(double v, double *red /* RW_BLOCK */)
-{
-    __syncthreads();
-    red[threadIdx.x] = v;
-    __syncthreads();
-    for (int off = RW_BLOCK / 2; off > 0; off >>= 1) {
-        if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
-        __syncthreads();
-    }
-    return red[0];
-}
-
-// finalize (training): the chunks' (sum d, sum d^2, shift K, rows n) are merged like Chan et al.'s parallel variance:
-//   mean_k = K + S/n,  M2_k = Q - S^2/n;   mean = sum n_k mean_k / M;   M2 = sum [M2_k + n_k (mean_k - mean)^2]
-// in double, fixed order.  mean, biased var -> scale = gamma*invstd, shift_out = beta; running stats update.
-// eval: scale/shift from the running statistics.  One workgroup per channel.
+// finalize (training): the chunks' (sum d, sum d^2, shift K, rows n) are merged like Chan et al.'s parallel variance.
+// A chunk is (n, mean = K + S/n, M2 = Q - S^2/n); two sets merge as
+//   n = na + nb,  mean = ma + (mb - ma) nb / n,  M2 = M2a + M2b + (mb - ma)^2 na nb / n
+// in double: every thread folds its chunks in ascending order, then a fixed tree over the workgroup (reproducible,
+// ONE pass over the partials).  mean, biased var -> scale = gamma*invstd, shift_out = beta; running stats update.
+// eval: scale from the running statistics.  One workgroup per channel.
 __global__ __launch_bounds__(RW_BLOCK) void bn_finalize_kernel(
     const float *__restrict__ partial, int chunks, int64_t M, int C, float eps, float momentum,
     const float *__restrict__ gamma, const float *__restrict__ beta, float *__restrict__ running_mean,
     float *__restrict__ running_var, int training, float *__restrict__ mean_out, float *__restrict__ invstd_out,
     float *__restrict__ scale_out, float *__restrict__ shift_out)
 {
-    __shared__ double red[RW_BLOCK];
+    __shared__ double rn[RW_BLOCK], rm[RW_BLOCK], r2[RW_BLOCK];
     const int c = blockIdx.x;
     float mean, var;
     if (training) {
-        double wsum = 0.0;
+        double n = 0.0, mu = 0.0, m2 = 0.0;
         for (int k = threadIdx.x; k < chunks; k += RW_BLOCK) {
-            const double n = (double)partial[((size_t)k * 4 + 3) * C + c];
-            if (n > 0.0) wsum += n * (double)partial[((size_t)k * 4 + 2) * C + c] + (double)partial[((size_t)k * 4 + 0) * C + c];
-        }
-        const double mu = block_sum(wsum, red) / (double)M;
-        double m2 = 0.0;
-        for (int k = threadIdx.x; k < chunks; k += RW_BLOCK) {
-            const double n = (double)partial[((size_t)k * 4 + 3) * C + c];
-            if (n > 0.0) {
+            const double nb = (double)partial[((size_t)k * 4 + 3) * C + c];
+            if (nb > 0.0) {
                 const double S = (double)partial[((size_t)k * 4 + 0) * C + c], Q = (double)partial[((size_t)k * 4 + 1) * C + c];
-                const double dm = (double)partial[((size_t)k * 4 + 2) * C + c] + S / n - mu;
-                m2 += (Q - S * S / n) + n * dm * dm;
+                const double mb = (double)partial[((size_t)k * 4 + 2) * C + c] + S / nb, m2b = Q - S * S / nb;
+                const double tot = n + nb, dm = mb - mu;
+                mu += dm * (nb / tot);
+                m2 += m2b + dm * dm * (n * nb / tot);
+                n = tot;
             }
         }
-        double v = block_sum(m2, red) / (double)M;
+        rn[threadIdx.x] = n;
+        rm[threadIdx.x] = mu;
+        r2[threadIdx.x] = m2;
+        __syncthreads();
+        for (int off = RW_BLOCK / 2; off > 0; off >>= 1) {
+            if ((int)threadIdx.x < off) {
+                const double na = rn[threadIdx.x], nb = rn[threadIdx.x + off];
+                const double tot = na + nb;
+                if (nb > 0.0) {
+                    const double dm = rm[threadIdx.x + off] - rm[threadIdx.x];
+                    rm[threadIdx.x] += dm * (nb / tot);
+                    r2[threadIdx.x] += r2[threadIdx.x + off] + dm * dm * (na * nb / tot);
+                    rn[threadIdx.x] = tot;
+                }
+            }
+            __syncthreads();
+        }
+        double v = r2[0] / (double)M;
         if (v < 0.0) v = 0.0;
-        mean = (float)mu;
+        mean = (float)rm[0];
         var = (float)v;
         if (running_mean && threadIdx.x == 0) {
             const double unb = M > 1 ? v * ((double)M / (double)(M - 1)) : v;
@@ -384,10 +387,9 @@ __global__ __launch_bounds__(RW_BLOCK) void bn_finalize_kernel(
     if (threadIdx.x != 0) return;
     const float invstd = 1.0f / sqrtf(var + eps);
     const float g = gamma ? gamma[c] : 1.0f;
-    const float sc = g * invstd;
     mean_out[c] = mean;
     invstd_out[c] = invstd;
-    scale_out[c] = sc;
+    scale_out[c] = g * invstd;
     shift_out[c] = beta ? beta[c] : 0.0f;  // the kernels apply (y - mean) * scale + beta: no folded shift, whose
                                             // product mean * scale cancels against y * scale when |mean| >> std
 }

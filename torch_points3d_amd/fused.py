@@ -132,7 +132,16 @@ def _finalize_stats(part, M, C, gamma, beta, bn, dev, st):
 
 
 ROWS_GEMM_MIN_COLS = 32   # narrower outputs (class scores, edge MLPs) stay on the library / skinny kernels
+ROWS_GEMM_NARROW = True   # widths served by the 128 x 64 tiles (N % 128 in 1..64) on the rows kernel (else library GEMM)
+ROWS_GEMM_DX = False      # input-gradient contractions on the rows kernel; measured 0.22 ms/step slower than the
+                          # library GEMM on the BASELINE step (tools/exp_r02.sh), so off
 CHAIN_MIN_ROWS = 32768    # the fused layer chain serves the large row matrices (grouped / per-point activations)
+
+
+def _rows_gemm_serves(cout):
+    if not USE_ROWS_GEMM or cout < ROWS_GEMM_MIN_COLS:
+        return False
+    return ROWS_GEMM_NARROW or not (0 < cout % 128 <= 64)
 
 
 def _long_k(M, N, K):
@@ -183,7 +192,12 @@ class _LinearBNAct(torch.autograd.Function):
         # the dense contraction on the fp32 MFMA rows kernel (128- or 64-column tiles); BatchNorm statistics come out of
         # its epilogue, except for the long contractions with few output tiles (the 4096-row global / decoder layers),
         # which run as a K-split launch followed by the separate statistics pass over their small output
-        own_gemm = USE_ROWS_GEMM and Cout >= ROWS_GEMM_MIN_COLS and Kp % 4 == 0
+        own_gemm = _rows_gemm_serves(Cout) and Kp % 4 == 0
+        # few output tiles and a contraction of 512..1023 channels: the rows kernel has nothing to hide its K walk
+        # behind and a K-split would move more slab bytes than it saves -- library GEMM + separate statistics pass
+        # (93 -> 27 + 12 us on the 4096-row global layer); longer contractions go K-split for their summation order
+        if own_gemm and ((M + 127) // 128) * ((Cout + 127) // 128) < 128 and 512 <= Kp < 1024:
+            own_gemm = False
         if own_gemm:
             Y, part = gemm_rows(A, W2, want_stats=training and not _long_k(M, Cout, Kp))
         elif _is_skinny(M, Kp, Cout):
@@ -236,7 +250,7 @@ class _LinearBNAct(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             if _is_skinny(M, W2.shape[1], Cout):
                 dA = gemm_skinny(dY, W2.t())
-            elif USE_ROWS_GEMM and W2.shape[1] >= ROWS_GEMM_MIN_COLS and Cout % 4 == 0:
+            elif ROWS_GEMM_DX and _rows_gemm_serves(W2.shape[1]) and Cout % 4 == 0:
                 dA = gemm_rows(dY, W2.t())[0]  # dA[M,Kp] = dY[M,N] (W^T)[Kp,N]^T on the same rows kernel
             else:
                 dA = torch.mm(dY, W2)
@@ -375,7 +389,8 @@ def _chain_ok(rows, parts):
     return True
 
 
-USE_MLP_CHAIN = True
+USE_MLP_CHAIN = False  # measured (tools/exp_r02.sh): 12.0 vs 10.3 ms/step -- the prologue arithmetic and the second operand
+                       # stream push the fused GEMMs to one wave per SIMD; kept for the experiments DESIGN.md records
 
 
 class _BNAct(torch.autograd.Function):
