@@ -121,18 +121,33 @@ def algorithmic_bytes(name, a):
         return B * (m * C1 * 4 + n * 36 + n * C2 * 4 + n * ld * 4)
     if name == "tp3d_idw_weights_f32":  # rows
         return a[0] * 24
-    if name in ("tp3d_gemm_tn_f32", "tp3d_gemm_rows_f32"):  # M, N, K
+    if name in ("tp3d_gemm_tn_f32", "tp3d_gemm_rows_f32", "tp3d_gemm_rows_bnact_f32"):  # M, N, K
         M, N, K = a[:3]
         return (M * (N + K) + N * K) * 4
+    if name == "tp3d_gemm_rows_bnbwd_f32":  # ns, M, N, K: Y and dA (dense, or pooled M/ns rows + argmax) in, C out
+        ns, M, N, K = a[:4]
+        return (M * K + (M // ns) * K * (1 if ns == 1 else 2) + M * N + N * K) * 4
+    if name == "tp3d_gemm_tn_bn_f32":  # ns, M, N, K: Y, dA, A in; (N, K) out
+        ns, M, N, K = a[:4]
+        return (M * N + (M // ns) * N * (1 if ns == 1 else 2) + M * K + N * K) * 4
+    if name == "tp3d_bn_bwd_reduce_f32":  # M, ns, C, training: Y + dA read (pooled: the arg-max rows only)
+        M, ns, C = a[:3]
+        return 2 * M * C * 4 if ns == 1 else (M // ns) * C * 12
     if name == "tp3d_bn_finalize_f32":  # chunks, M, C
         chunks, M, C = a[:3]
-        return chunks * 2 * C * 4
+        return chunks * 4 * C * 4
+    if name == "tp3d_relation_rows_f32":  # B, N, np, ns, ld
+        B, N, npnt, ns, ld = a[:5]
+        return B * (N * 12 + npnt * 12 + npnt * ns * (8 + ld * 4))
     return 0
 
 
 def algorithmic_flops(name, a):
-    if name in ("tp3d_gemm_tn_f32", "tp3d_gemm_rows_f32"):  # M, N, K
+    if name in ("tp3d_gemm_tn_f32", "tp3d_gemm_rows_f32", "tp3d_gemm_rows_bnact_f32"):  # M, N, K
         M, N, K = a[:3]
+        return 2 * M * N * K
+    if name in ("tp3d_gemm_rows_bnbwd_f32", "tp3d_gemm_tn_bn_f32"):  # ns, M, N, K
+        ns, M, N, K = a[:4]
         return 2 * M * N * K
     return 0
 
@@ -193,6 +208,85 @@ def cpu_baseline(sample_b, iters):
     }
 
 
+def time_forward(model, pos, x, steps, warmup, use_graph):
+    """seconds for `steps` forward passes (train-mode BatchNorm, no autograd), replayed from one HIP graph if possible"""
+    with torch.no_grad():
+        for _ in range(max(warmup, 1)):
+            model(pos, x)
+        torch.cuda.synchronize()
+        graphed = False
+        if use_graph:
+            try:
+                side = torch.cuda.Stream()
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    model(pos, x)
+                torch.cuda.current_stream().wait_stream(side)
+                torch.cuda.synchronize()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                    model(pos, x)
+                graphed = True
+            except Exception as exc:  # noqa: BLE001 -- capture is an optimisation; eager launches measure the same kernels
+                log("graph capture unavailable (%s: %s); eager launches" % (type(exc).__name__, exc))
+                torch.cuda.synchronize()
+        step = g.replay if graphed else (lambda: model(pos, x))
+        step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0, graphed
+
+
+def cpu_forward_baseline(sample_b, iters):
+    from oracle import tpk_ref
+    cores = cpu_share()
+    torch.set_num_threads(cores)
+    tpk_ref.set_num_threads(cores)
+    cmodel = build_model(tpk_ref, "cpu")
+    cpos, cx, _ = make_inputs(sample_b, N_POINTS, 1234, "cpu")
+    with torch.no_grad():
+        cmodel(cpos, cx)
+        t1 = time.perf_counter()
+        for _ in range(max(iters, 1)):
+            cmodel(cpos, cx)
+        cdt = time.perf_counter() - t1
+    return {"value": sample_b * max(iters, 1) / cdt, "unit": "point-clouds/s", "cores": cores, "kind": "port",
+            "sample": "%d forward passes of the same PointNet++ SSG on %d clouds of N=%d after 1 warm-up; PyTorch-CPU "
+                      "conv/BN + oracle/tpk_ref_cpu.c kernels (OpenMP over clouds/queries)" % (max(iters, 1), sample_b, N_POINTS),
+            "seconds": cdt}
+
+
+def north_star_kernels(summ):
+    """BASELINE.json's north-star kernels with their algorithmic-bytes rate against the HBM peak (SURVEY 8d formulas)
+    and, where a committed rocprofv3 --pmc pass holds them, VALU / occupancy counters (profiles/r02_pmc_spatial.json)."""
+    wanted = ("tp3d_fps_f32", "tp3d_ball_query_dense_f32", "tp3d_three_nn_f32", "tp3d_group_concat_fwd_f32",
+              "tp3d_interp_concat_fwd_f32")
+    pmc = {}
+    ppath = os.path.join(ROOT, "profiles", "r02_pmc_spatial.json")
+    if os.path.exists(ppath):
+        try:
+            pmc = json.load(open(ppath))
+        except (OSError, ValueError):
+            pmc = {}
+    out = []
+    for (name, a), (launches, total_ms) in sorted(summ.items(), key=lambda kv: -kv[1][1]):
+        if name not in wanted:
+            continue
+        nbytes = algorithmic_bytes(name, a)
+        avg_ms = total_ms / launches
+        gbs = nbytes / 1e9 / (avg_ms / 1e3)
+        row = {"entry": name, "sizes": list(a)[:5], "avg_ms": round(avg_ms, 4), "algorithmic_MB": round(nbytes / 1e6, 3),
+               "GBps": round(gbs, 1), "frac_of_hbm_peak": round(gbs / HBM_PEAK_GBS, 5)}
+        if name in pmc.get("kernels", {}):
+            row["counters"] = pmc["kernels"][name]
+            row["counters_source"] = pmc.get("source")
+        out.append(row)
+    return out
+
+
 def run_forward(args):
     """BASELINE configs[1] as written: PointNet++ SSG FORWARD, B=32, N=16384, one MI355X (train-mode BatchNorm, as in the
     reference's example, which never calls .eval()).  A step = one forward pass of the whole network including FPS,
@@ -208,34 +302,8 @@ def run_forward(args):
     torch.cuda.set_device(device)
     model = build_model(None, device)
     pos, x, _ = make_inputs(B_PER_GPU, N_POINTS, 1234, device)
+    dt, graphed = time_forward(model, pos, x, args.steps, args.warmup, not args.no_graph)
     with torch.no_grad():
-        for _ in range(max(args.warmup, 1)):
-            out = model(pos, x)
-        torch.cuda.synchronize()
-        graphed = False
-        if not args.no_graph:
-            try:
-                side = torch.cuda.Stream()
-                side.wait_stream(torch.cuda.current_stream())
-                with torch.cuda.stream(side):
-                    model(pos, x)
-                torch.cuda.current_stream().wait_stream(side)
-                torch.cuda.synchronize()
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, capture_error_mode="thread_local"):
-                    out = model(pos, x)
-                graphed = True
-            except Exception as exc:  # noqa: BLE001 -- capture is an optimisation; eager launches measure the same kernels
-                log("graph capture unavailable (%s: %s); eager launches" % (type(exc).__name__, exc))
-                torch.cuda.synchronize()
-        step = g.replay if graphed else (lambda: model(pos, x))
-        step()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            step()
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
         # per-entry HIP-event timing in an eager pass outside the timed region
         timer = _lib.KernelTimer()
         _lib.set_timer(timer)
@@ -480,6 +548,11 @@ def main():
                          "the oracle kernels as baseline.  knn: BASELINE configs[4] leg, random subsample + exact 16-NN on "
                          "a 10^6-point scene, brute-force oracle on a query sample as baseline.  (All three single GPU; "
                          "extra lines, not the headline)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: B=32 clouds per GPU (the metric's batch per device); strong: a global batch of 32 clouds "
+                         "split over the ranks (32/16/8/4 per GPU at 1/2/4/8 GPUs, SURVEY 8e)")
+    ap.add_argument("--no-geometry-prefetch", action="store_true",
+                    help="compute sampling / searches inside the training pass instead of one step ahead on a second stream")
     ap.add_argument("--set", action="append", default=[], metavar="NAME=VALUE",
                     help="experiment switch: set an attribute of torch_points3d_amd.fused (e.g. USE_MLP_CHAIN=0) before the "
                          "run; recorded in the JSON line")
@@ -528,16 +601,27 @@ def main():
             dist.init_process_group(backend=args.backend)
 
     from torch_points3d_amd import _lib
-    from torch_points3d_amd.dp import ShardedStep
+    from torch_points3d_amd.dense import Data
+    from torch_points3d_amd.dp import PipelinedStep, ShardedStep
     _lib.load()  # fail loudly if the HIP extension is missing
 
-    # identical initial weights on every rank (same seed); whole clouds per rank; BatchNorm stays per rank
+    # whole clouds per rank; BatchNorm stays per rank; ShardedStep broadcasts rank 0's initial state
+    if args.scaling == "strong" and B_PER_GPU % world:
+        raise SystemExit("--scaling strong needs a rank count that divides %d" % B_PER_GPU)
+    b_rank = B_PER_GPU // world if args.scaling == "strong" else B_PER_GPU
     model = build_model(None, device)
-    pos, x, y = make_inputs(B_PER_GPU, N_POINTS, 1234 + rank, device)
+    pos, x, y = make_inputs(b_rank, N_POINTS, 1234 + rank, device)
     use_graph = not args.no_graph
-    trainer = ShardedStep(model, lambda params: torch.optim.Adam(params, lr=1e-3, capturable=use_graph),
-                          lambda: F.cross_entropy(model(pos, x), y), world_size=world, use_graph=use_graph, log=log,
-                          reduce_always=multi)
+    make_opt = lambda params: torch.optim.Adam(params, lr=1e-3, capturable=use_graph)  # noqa: E731
+    if args.no_geometry_prefetch:
+        trainer = ShardedStep(model, make_opt, lambda: F.cross_entropy(model(pos, x), y), world_size=world,
+                              use_graph=use_graph, log=log, reduce_always=multi)
+    else:
+        # sampling / radius searches / 3-NN tables of step i+1 run on a second stream during step i (dp.PipelinedStep)
+        net = model.net
+        trainer = PipelinedStep(model, make_opt, lambda slot: net.precompute_geometry(pos),
+                                lambda geo: F.cross_entropy(net(Data(pos=pos, x=x), geometry=geo).x, y),
+                                world_size=world, use_graph=use_graph, log=log, reduce_always=multi)
     log("model built; warm-up")
     graphed = trainer.warmup_and_capture(args.warmup)
     torch.cuda.synchronize()
@@ -574,10 +658,21 @@ def main():
     log("timed region done: %.2f ms/step (host enqueue %.2f ms/step)" % (dt / args.steps * 1e3,
                                                                           t_enqueued / args.steps * 1e3))
 
+    coll_ms = None
     if multi:
         t = torch.tensor([dt], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        # the step's only collective, timed on its own (device events around K all-reduce + divide rounds)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        dist.barrier()
+        e0.record()
+        for _ in range(args.steps):
+            trainer._reduce()
+        e1.record()
+        torch.cuda.synchronize()
+        coll_ms = round(e0.elapsed_time(e1) / args.steps, 4)
 
     if rank == 0:
         summ = timer.summary()
@@ -604,11 +699,16 @@ def main():
             dom = max(per_entry, key=lambda n: per_entry[n]["ms"])
             e = per_entry[dom]
             avg_ms = e["ms"] / e["launches"]
-            traffic = None
+            # HBM bytes per launch of the dominant kernel come from separate rocprofv3 --pmc passes (the profiler cannot
+            # run inside this process): the committed summary names the round and command it was taken with
+            traffic, traffic_source = None, None
             tpath = os.path.join(ROOT, "profiles", "traffic.json")
             if os.path.exists(tpath):
                 try:
-                    traffic = json.load(open(tpath)).get(dom)
+                    tj = json.load(open(tpath))
+                    traffic = tj.get(dom)
+                    traffic_source = tj.get("_source", "profiles/traffic.json (earlier rocprofv3 --pmc FETCH_SIZE / "
+                                                       "WRITE_SIZE passes, not this run)")
                 except (OSError, ValueError):
                     traffic = None
             if e["flops"]:  # a dense contraction: priced against the fp32 MFMA peak
@@ -624,6 +724,8 @@ def main():
                             "algorithmic_bytes_per_launch": int(e["bytes"] / e["launches"])}
             roofline.update({"avg_launch_ms": round(avg_ms, 4), "launches": e["launches"],
                              "ms_per_step": round(e["ms"] / args.steps, 4)})
+            if traffic is not None:
+                roofline["traffic_source"] = traffic_source
         entries = [{"entry": n, "ms_per_step": round(v["ms"] / args.steps, 4), "launches_per_step":
                     v["launches"] // args.steps,
                     "GBps": round(v["bytes"] / 1e9 / (v["ms"] / 1e3), 1) if v["ms"] > 0 else None,
@@ -632,7 +734,18 @@ def main():
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline(args.cpu_sample_clouds, args.cpu_sample_iters)
-        value = world * B_PER_GPU * args.steps / dt
+        # the north star's ">= 30x the CPU path" is defined on the SSG FORWARD pass: measured in the same run, after the
+        # headline region (BASELINE configs[1] as written; train-mode BatchNorm as the reference's example)
+        forward_only = None
+        if world == 1:
+            fdt, fgraphed = time_forward(model, pos, x, args.steps, 2, use_graph)
+            forward_only = {"ms_per_step": round(fdt / args.steps * 1e3, 3), "value": round(b_rank * args.steps / fdt, 2),
+                            "unit": "point-clouds/s", "launch": "hip-graph replay" if fgraphed else "eager"}
+            if not args.no_cpu_baseline:
+                fcpu = cpu_forward_baseline(args.cpu_sample_clouds, max(args.cpu_sample_iters // 2, 2))
+                forward_only["cpu_baseline"] = fcpu
+                forward_only["gpu_over_cpu"] = round(forward_only["value"] / fcpu["value"], 1)
+        value = world * b_rank * args.steps / dt
         grouping = "MSG" if MODEL_CONFIG.endswith("_ms") else "SSG"
         line = {
             "metric": "point-clouds/sec fwd+bwd PointNet++%s B=32 N=16384" % grouping,
@@ -643,22 +756,29 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3),
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": "PointNet++ %s (%s) train step fwd+bwd+Adam, B=32 per GPU, N=16384, "
+            "config": {"workload": "PointNet++ %s (%s) train step fwd+bwd+Adam, B=%d per GPU, N=16384, "
                                    "FEAT=3, 10 classes, pos~U[-1,1]^3 (BASELINE configs[%d])"
-                                   % (grouping, MODEL_CONFIG, 2 if grouping == "MSG" else 1),
-                       "launch": "hip-graph replay" if graphed else "eager",
-                       "global_batch": world * B_PER_GPU, "points": N_POINTS,
+                                   % (grouping, MODEL_CONFIG, b_rank, 2 if grouping == "MSG" else 1),
+                       "launch": ("hip-graph replay" if graphed else "eager") + (
+                           "" if args.no_geometry_prefetch else
+                           "; sampling + searches of step i+1 on a second stream during step i (every step does both)"),
+                       "global_batch": world * b_rank, "points": N_POINTS,
                        "parallelism": "dp%d (whole clouds per rank, one flat gradient all-reduce over RCCL "
                                       "per step)" % world},
             "roofline": roofline,
             "cpu_baseline": cpu,
+            "forward_only": forward_only,
+            "north_star_kernels": north_star_kernels(summ),
             "entry_points": entries,
             "kernels": kernels,
         }
+        if multi:
+            line["collective"] = {"what": "one flat fp32 gradient all-reduce (sum) + divide per step over RCCL",
+                                  "bytes": int(trainer.flat.numel() * 4), "ms_per_step": coll_ms}
         if args.set:
             line["experiment_switches"] = args.set
         if cpu:

@@ -212,6 +212,45 @@ def test_sharded_step_same_trajectory():
         torch.testing.assert_close(v.float(), after_graph[k].float(), rtol=1e-6, atol=1e-7, msg=lambda m, k=k: k + m)
 
 
+def test_pipelined_step_same_trajectory_as_sharded_step():
+    """geometry of step i+1 on a second stream during step i (dp.PipelinedStep, HIP graphs) follows exactly the
+    trajectory of the plain stepper: same parameters and BatchNorm buffers after several steps, and the precomputed
+    geometry is bit-identical to what the forward pass computes itself"""
+    import torch.nn.functional as F
+    from torch_points3d_amd.dense import Data
+    from torch_points3d_amd.dp import PipelinedStep, ShardedStep
+    from torch_points3d_amd.pointnet2 import PointNet2Unet
+
+    g = torch.Generator().manual_seed(6)
+    pos = (torch.rand(2, 4096, 3, generator=g) * 2 - 1).to(DEV)
+    x = torch.randn(2, 4096, 3, generator=g).to(DEV)
+    y = torch.randint(0, 7, (2, 4096), generator=g).to(DEV)
+
+    def make():
+        torch.manual_seed(0)
+        return PointNet2Unet(3, output_nc=7, config="unet_3_ss").to(DEV).train()
+
+    a, b = make(), make()
+    geo = b.precompute_geometry(pos)
+    assert torch.equal(geo.down[0].idx, a.down_modules[0].sampler(pos).long())
+    with torch.no_grad():
+        assert torch.equal(a(Data(pos=pos, x=x)).x, b(Data(pos=pos, x=x), geometry=geo).x)
+    a, b = make(), make()
+    ta = ShardedStep(a, lambda ps: torch.optim.SGD(ps, lr=0.05), lambda: F.cross_entropy(a(Data(pos=pos, x=x)).x, y),
+                     world_size=1, use_graph=False)
+    tb = PipelinedStep(b, lambda ps: torch.optim.SGD(ps, lr=0.05), lambda slot: b.precompute_geometry(pos),
+                       lambda geo_: F.cross_entropy(b(Data(pos=pos, x=x), geometry=geo_).x, y), world_size=1, use_graph=True)
+    assert tb.warmup_and_capture(2)
+    for _ in range(2 + 2):  # the eager warm-up steps of the pipelined stepper (2) and its side-stream warm-up (2 passes)
+        ta.step()
+    for _ in range(5):  # crosses both geometry slots several times
+        ta.step()
+        tb.step()
+    torch.cuda.synchronize()
+    for (k, v), (_, w) in zip(a.state_dict().items(), b.state_dict().items()):
+        torch.testing.assert_close(v.float(), w.float(), rtol=1e-5, atol=1e-6, msg=lambda m, k=k: k + m)
+
+
 @pytest.mark.parametrize("M,N,K", [(1000, 64, 8), (4096, 128, 132), (70000, 128, 128), (33, 8, 4), (20000, 256, 260),
                                    (5000, 1024, 512), (262144, 128, 64), (129, 132, 68), (4096, 256, 1280),
                                    (140000, 256, 64), (50000, 384, 32), (130100, 128, 8)])

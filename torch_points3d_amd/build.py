@@ -93,5 +93,24 @@ def _reap(running):
     return cmd if proc.wait() != 0 else None
 
 
+CPU_SRC = os.path.join(PKG_DIR, "csrc_cpu", "points_cpu.c")
+CPU_LIB_PATH = os.path.join(PKG_DIR, "libtp3d_cpu.so")
+
+
+def build_cpu_library(force=False):
+    """gcc-compile the host-side searches (include/tp3d_cpu.h) into torch_points3d_amd/libtp3d_cpu.so.  No HIP, no
+    OpenMP: the library must be loadable and usable inside forked DataLoader workers."""
+    deps = [CPU_SRC, os.path.join(ROOT, "include", "tp3d_cpu.h")]
+    if not force and os.path.exists(CPU_LIB_PATH) and all(os.path.getmtime(d) <= os.path.getmtime(CPU_LIB_PATH) for d in deps):
+        return CPU_LIB_PATH
+    cc = shutil.which("gcc") or shutil.which("cc")
+    if cc is None:
+        raise RuntimeError("no C compiler found: libtp3d_cpu.so cannot be built")
+    subprocess.check_call([cc, "-O3", "-ffp-contract=off", "-fPIC", "-shared", "-Wall", "-I" + os.path.join(ROOT, "include"),
+                           CPU_SRC, "-o", CPU_LIB_PATH, "-lpthread", "-lm"])
+    return CPU_LIB_PATH
+
+
 if __name__ == "__main__":
     print(build_library(force=True, verbose=True))
+    print(build_cpu_library(force=True))

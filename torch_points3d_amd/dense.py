@@ -164,14 +164,28 @@ class BaseDenseConvolutionDown(nn.Module):
     def conv(self, x, pos, new_pos, radius_idx, scale_idx):
         raise NotImplementedError
 
-    def forward(self, data, sample_idx=None, **kwargs):
+    def precompute(self, pos):
+        """The geometry of this level for the cloud `pos` (B,N,3): everything forward() derives from positions alone --
+        sampled indices, sampled positions, one neighbour table per scale.  Pass the result as forward(precomputed=)."""
+        with torch.no_grad():
+            idx = self.sampler(pos).long()
+            new_pos = pos.gather(1, idx.unsqueeze(-1).repeat(1, 1, pos.shape[-1]))
+            tables = [self.neighbour_finder(pos, new_pos, scale_idx=s) for s in range(self.neighbour_finder.num_scales)]
+        return Data(idx=idx, new_pos=new_pos, radius_idx=tables)
+
+    def forward(self, data, sample_idx=None, precomputed=None, **kwargs):
         x, pos = data.x, data.pos
-        idx = sample_idx if sample_idx is not None else self.sampler(pos)
-        idx = idx.unsqueeze(-1).repeat(1, 1, pos.shape[-1]).long()
-        new_pos = pos.gather(1, idx)
+        if precomputed is not None:
+            idx = precomputed.idx.unsqueeze(-1)
+            new_pos = precomputed.new_pos
+        else:
+            idx = sample_idx if sample_idx is not None else self.sampler(pos)
+            idx = idx.unsqueeze(-1).repeat(1, 1, pos.shape[-1]).long()
+            new_pos = pos.gather(1, idx)
         ms_x = []
         for scale_idx in range(self.neighbour_finder.num_scales):
-            radius_idx = self.neighbour_finder(pos, new_pos, scale_idx=scale_idx)
+            radius_idx = (precomputed.radius_idx[scale_idx] if precomputed is not None
+                          else self.neighbour_finder(pos, new_pos, scale_idx=scale_idx))
             ms_x.append(self.conv(x, pos, new_pos, radius_idx, scale_idx))
         if all(_is_channel_last(t) for t in ms_x):
             # fused path: scales are (B, C_i, np) VIEWS of channel-last storage; concatenate the storage itself
@@ -250,12 +264,12 @@ class BaseDenseConvolutionUp(nn.Module):
     def conv(self, pos, pos_skip, x):
         raise NotImplementedError
 
-    def forward(self, data, **kwargs):
+    def forward(self, data, precomputed=None, **kwargs):
         data, data_skip = data
-        fused_out = self._forward_fused(data, data_skip) if hasattr(self, "_forward_fused") else None
+        fused_out = self._forward_fused(data, data_skip, precomputed) if hasattr(self, "_forward_fused") else None
         if fused_out is not None:
             return Data(x=fused_out, pos=data_skip.pos)
-        new_features = self.conv(data.pos, data_skip.pos, data.x)
+        new_features = self.conv(data.pos, data_skip.pos, data.x, precomputed)
         if data_skip.x is not None:
             new_features = torch.cat([new_features, data_skip.x], dim=1)
         new_features = new_features.unsqueeze(-1)
@@ -273,7 +287,21 @@ class DenseFPModule(BaseDenseConvolutionUp):
         self.fused = fused
         self.nn = MLP2D(up_conv_nn, bn=bn, activation=activation, bias=False)
 
-    def _forward_fused(self, data, data_skip):
+    def precompute(self, pos, pos_skip):
+        """3-NN interpolation table of this stage: (idx (B,n,3), inverse-distance weights (B,n,3)); None below the
+        global module (pos is None there)."""
+        if pos is None:
+            return None
+        with torch.no_grad():
+            dist, idx = self._tp.three_nn(pos_skip, pos)
+            if self._tp is _hip_kernels and dist.is_cuda:
+                weight = _fused.idw_weights(dist)
+            else:
+                dist_recip = 1.0 / (dist + 1e-8)
+                weight = dist_recip / torch.sum(dist_recip, dim=2, keepdim=True)
+        return Data(idx=idx, weight=weight)
+
+    def _forward_fused(self, data, data_skip, precomputed=None):
         """interpolate + skip concat + MLP on (rows, C): HIP kernels around library GEMMs; None -> reference graph."""
         if not (self.fused and _use_fused(self._tp, data.x, data_skip.pos, data_skip.x)):
             return None
@@ -286,16 +314,20 @@ class DenseFPModule(BaseDenseConvolutionUp):
         if pos is None:  # below the global module: one feature column broadcast to every skip point
             rows = x.transpose(1, 2).expand(B, n, x.shape[1])
             rows = _fused.cat_rows([rows] + ([skip_cl] if skip_cl is not None else []))
+        elif precomputed is not None:
+            rows = _fused.interp_concat(_fused._cl(x), precomputed.idx, precomputed.weight, skip_cl)
         else:
             dist, idx = self._tp.three_nn(pos_skip, pos)
             rows = _fused.interp_concat(_fused._cl(x), idx, _fused.idw_weights(dist), skip_cl)
         out = _fused.run_mlp(rows, parts)
         return out.view(B, n, -1).transpose(1, 2)
 
-    def conv(self, pos, pos_skip, x):
+    def conv(self, pos, pos_skip, x, precomputed=None):
         assert pos_skip.shape[2] == 3
         if pos is None:  # below the global module: broadcast the single feature column
             return x.expand(*(x.size()[0:2] + (pos_skip.size(1),)))
+        if precomputed is not None:
+            return self._tp.three_interpolate(x, precomputed.idx, precomputed.weight)
         dist, idx = self._tp.three_nn(pos_skip, pos)
         dist_recip = 1.0 / (dist + 1e-8)
         weight = dist_recip / torch.sum(dist_recip, dim=2, keepdim=True)

@@ -145,3 +145,125 @@ class ShardedStep(object):
 
     def eager_step(self):
         self._eager_step()
+
+
+class PipelinedStep(ShardedStep):
+    """ShardedStep with the geometry of the NEXT batch computed on a second stream while the current batch trains.
+
+    Everything a dense PointNet++ derives from the positions alone -- farthest point sampling, radius searches, 3-NN
+    tables (`model.precompute_geometry`) -- is ~1 ms of mostly serial work that occupies a fraction of the chip (FPS runs
+    one workgroup per cloud: 32 of 256 CUs); the feature path does not need it before the step starts.  The reference
+    has the same split for its partial-dense networks (MultiScaleTransform: geometry precomputed by the data loader,
+    core/data_transform/transforms.py:579-654); here it is a second HIP stream instead of CPU workers.
+
+        main stream :  ... | fwd+bwd(i) using G[i%2] | all-reduce | Adam | fwd+bwd(i+1) using G[(i+1)%2] | ...
+        side stream :  ... | geometry(i+1) -> G[(i+1)%2]           |      | geometry(i+2) -> G[i%2]       | ...
+
+    geometry_fn(slot) -> geometry of the batch that will train next (written to fresh tensors; the stepper keeps two
+    slots alive); loss_fn(geometry) -> scalar loss of the current batch.  Every step still does all of its work -- one
+    geometry pass and one training pass -- only their order across the two streams differs."""
+
+    def __init__(self, model, make_optimizer, geometry_fn, loss_fn, **kw):
+        self._geometry_fn = geometry_fn
+        self._loss_with = loss_fn
+        self._slots = [None, None]
+        self._cur = 0
+        super().__init__(model, make_optimizer, lambda: self._loss_with(self._slots[self._cur]), **kw)
+        dev = self.params[0].device
+        self._side = torch.cuda.Stream(device=dev) if dev.type == "cuda" else None
+        self._geo_done = [None, None]   # events: geometry slot written (recorded on the side stream)
+        self._slot_free = [None, None]  # events: training pass that read the slot finished (main stream)
+        self.graph_geo = [None, None]
+        self.graph_fbs = [None, None]
+
+    # -- eager form (also the warm-up) -------------------------------------------------------------------
+    def _eager_step(self):
+        nxt = self._cur ^ 1
+        if self._slots[self._cur] is None:  # very first step: nothing was prefetched
+            self._slots[self._cur] = self._geometry_fn(self._cur)
+        if self._side is not None:
+            self._side.wait_stream(torch.cuda.current_stream())  # slot `nxt` was last read by the previous step
+            with torch.cuda.stream(self._side):
+                self._slots[nxt] = self._geometry_fn(nxt)
+        else:
+            self._slots[nxt] = self._geometry_fn(nxt)
+        self._forward_backward()
+        self._reduce()
+        self.opt.step()
+        if self._side is not None:
+            torch.cuda.current_stream().wait_stream(self._side)
+        self._cur = nxt
+
+    # -- capture -----------------------------------------------------------------------------------------
+    def warmup_and_capture(self, warmup_steps=3):
+        for _ in range(max(warmup_steps, 2)):
+            self._eager_step()
+        if not self._want_graph:
+            return False
+        try:
+            torch.cuda.synchronize()
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):  # allocator / lazy-init warm-up on a non-default stream
+                for slot in (0, 1):
+                    self._slots[slot] = self._geometry_fn(slot)
+                    self._cur = slot
+                    self._forward_backward()
+                    self.opt.step()
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            for slot in (0, 1):  # geometry graphs first: their outputs are the training graphs' static inputs
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                    self._slots[slot] = self._geometry_fn(slot)
+                self.graph_geo[slot] = g
+            for slot in (0, 1):
+                self._cur = slot
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                    self._forward_backward()
+                self.graph_fbs[slot] = g
+            g2 = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g2, capture_error_mode="thread_local"):
+                self.opt.step()
+            self.graph_opt = g2
+            torch.cuda.synchronize()
+            # prime the pipeline: geometry of the first batch, on the side stream like all later ones
+            self._cur = 0
+            with torch.cuda.stream(self._side):
+                self.graph_geo[0].replay()
+                self._geo_done[0] = torch.cuda.Event()
+                self._geo_done[0].record(self._side)
+            torch.cuda.synchronize()
+            self.graphed = True
+            self.log("train step captured: 2 geometry graphs (side stream), 2 forward+backward graphs, optimizer graph")
+        except Exception as exc:  # stay on the eager path rather than lose the run
+            self.log("graph capture unavailable (%s: %s); eager launches" % (type(exc).__name__, exc))
+            torch.cuda.synchronize()
+            self.graphed = False
+        return self.graphed
+
+    def step(self):
+        if not self.graphed:
+            return self._eager_step()
+        cur, nxt = self._cur, self._cur ^ 1
+        main = torch.cuda.current_stream()
+        # geometry of the next batch: may start as soon as the training pass that last read slot `nxt` is done
+        if self._slot_free[nxt] is not None:
+            self._side.wait_event(self._slot_free[nxt])
+        with torch.cuda.stream(self._side):
+            self.graph_geo[nxt].replay()
+            ev = torch.cuda.Event()
+            ev.record(self._side)
+            self._geo_done[nxt] = ev
+        main.wait_event(self._geo_done[cur])
+        self.graph_fbs[cur].replay()
+        done = torch.cuda.Event()
+        done.record(main)
+        self._slot_free[cur] = done
+        self._reduce()
+        self.graph_opt.replay()
+        self._cur = nxt
+
+    def eager_step(self):
+        self._eager_step()

@@ -77,7 +77,27 @@ class PointNet2Unet(nn.Module):
     def output_nc(self):
         return self._output_nc
 
-    def forward(self, data):
+    def precompute_geometry(self, pos):
+        """Everything the forward pass derives from the positions alone -- per set-abstraction level the sampled indices
+        / positions / neighbour tables, per feature-propagation stage the 3-NN interpolation table -- computed once for
+        `pos` (B,N,3).  Pass it as forward(data, geometry=): the pass then contains no sampling and no search, so the
+        geometry of the NEXT batch can be computed on a second stream while this batch trains (dp.PipelinedStep), the
+        dense-format counterpart of the reference's MultiScaleTransform precompute
+        (core/data_transform/transforms.py:579-654)."""
+        levels, cur, positions = [], pos, [pos]
+        for down in self.down_modules:
+            g = down.precompute(cur)
+            levels.append(g)
+            cur = g.new_pos
+            positions.append(cur)
+        ups, below = [], None  # `below` = position set of the stage's input (None under the global module)
+        for up in self.up_modules:
+            skip_pos = positions.pop()
+            ups.append(up.precompute(below, skip_pos))
+            below = skip_pos
+        return Data(down=levels, up=ups)
+
+    def forward(self, data, geometry=None):
         """data.pos (B,N,3), data.x (B,N,C) or None -> Data(pos (B,N,3), x (B,output_nc,N))."""
         assert data.pos.dim() == 3
         x = None
@@ -89,19 +109,17 @@ class PointNet2Unet(nn.Module):
                 x = x.contiguous()
         cur = Data(pos=data.pos, x=x)
         stack_down = [cur]
-        for i in range(len(self.down_modules) - 1):
-            cur = self.down_modules[i](cur)
+        for i in range(len(self.down_modules)):
+            cur = self.down_modules[i](cur, precomputed=None if geometry is None else geometry.down[i])
             stack_down.append(cur)
-        cur = self.down_modules[-1](cur)
-        stack_down.append(cur)
         cur = self.inner_modules[0](cur)
         sampling_ids = {}
         for d in stack_down:
             for k, v in d.__dict__.items():
                 if k.startswith("sampling_id"):
                     sampling_ids[k] = v
-        for up in self.up_modules:
-            cur = up((cur, stack_down.pop()))
+        for i, up in enumerate(self.up_modules):
+            cur = up((cur, stack_down.pop()), precomputed=None if geometry is None else geometry.up[i])
         for k, v in sampling_ids.items():
             setattr(cur, k, v)
         if self.has_mlp_head:
