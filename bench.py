@@ -39,9 +39,9 @@ class SegStep(nn.Module):
         super().__init__()
         self.net = net
 
-    def forward(self, pos, x):
+    def forward(self, pos, x, geometry=None):
         from torch_points3d_amd.dense import Data
-        return self.net(Data(pos=pos, x=x)).x  # (B, classes, N)
+        return self.net(Data(pos=pos, x=x), geometry=geometry).x  # (B, classes, N)
 
 
 def make_inputs(B, N, seed, device):
@@ -60,9 +60,30 @@ def MODEL_CONFIG_set(name):
     MODEL_CONFIG = name
 
 
+class PartSegStep(nn.Module):
+    """BASELINE configs[2]: PointNet2_D (models/segmentation/pointnet2.py) -- per-cloud object category one-hot fed to
+    the classifier; tensor-in / tensor-out like SegStep (scores as (B, classes, N))."""
+
+    def __init__(self, net, num_categories):
+        super().__init__()
+        self.net = net
+        self.num_categories = num_categories
+
+    def forward(self, pos, x, geometry=None):
+        from torch_points3d_amd.dense import Data
+        B, n = pos.shape[0], pos.shape[1]
+        # one object category per cloud, a fixed function of the cloud's position in the batch (synthetic)
+        cat = (torch.arange(B, device=pos.device) % self.num_categories).view(B, 1).expand(B, n)
+        return self.net(Data(pos=pos, x=x), cat, geometry=geometry).view(B, n, -1).transpose(1, 2)
+
+
 def build_model(kernels, device):
-    from torch_points3d_amd.pointnet2 import PointNet2Unet
     torch.manual_seed(0)
+    if MODEL_CONFIG == "pointnet2_charlesmsg":
+        from torch_points3d_amd.pointnet2 import PointNet2_D
+        net = PointNet2_D(FEAT, NUM_CLASSES, config=MODEL_CONFIG, num_categories=16, kernels=kernels)
+        return PartSegStep(net, 16).to(device).train()
+    from torch_points3d_amd.pointnet2 import PointNet2Unet
     net = PointNet2Unet(FEAT, output_nc=NUM_CLASSES, config=MODEL_CONFIG, kernels=kernels)
     return SegStep(net).to(device).train()
 
@@ -541,7 +562,7 @@ def main():
                     "(rehearsal of the multi-process code path on a single-GPU box)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse "
                     "the multi-process path on a box with fewer GPUs than ranks)")
-    ap.add_argument("--workload", default="pointnet2", choices=["pointnet2", "forward", "kpconv", "knn"],
+    ap.add_argument("--workload", default="pointnet2", choices=["pointnet2", "msg_c3", "forward", "kpconv", "knn"],
                     help="pointnet2: the headline metric (BASELINE configs[1] shapes).  forward: the same network, "
                          "forward pass only (configs[1] as written), with a CPU forward baseline.  kpconv: BASELINE configs[3], "
                          "KPConv unet_4 forward on one 65 536-point cloud, with the CPU mirror of the same modules on "
@@ -571,8 +592,12 @@ def main():
     if args.workload == "knn":
         return run_knn(args)
 
-    global MODEL_CONFIG
+    global MODEL_CONFIG, N_POINTS, NUM_CLASSES
     MODEL_CONFIG = args.model
+    if args.workload == "msg_c3":
+        # BASELINE configs[2]: PointNet++ MSG part segmentation as conf/models/segmentation/pointnet2.yaml:95-130 defines
+        # it (pointnet2_charlesmsg + PointNet2_D head), ShapeNet-shaped input: N = 2048, 16 categories, 50 part classes
+        MODEL_CONFIG, N_POINTS, NUM_CLASSES = "pointnet2_charlesmsg", 2048, 50
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -613,14 +638,14 @@ def main():
     pos, x, y = make_inputs(b_rank, N_POINTS, 1234 + rank, device)
     use_graph = not args.no_graph
     make_opt = lambda params: torch.optim.Adam(params, lr=1e-3, capturable=use_graph)  # noqa: E731
-    if args.no_geometry_prefetch:
+    if args.no_geometry_prefetch or not hasattr(model.net, "precompute_geometry"):
         trainer = ShardedStep(model, make_opt, lambda: F.cross_entropy(model(pos, x), y), world_size=world,
                               use_graph=use_graph, log=log, reduce_always=multi)
     else:
         # sampling / radius searches / 3-NN tables of step i+1 run on a second stream during step i (dp.PipelinedStep)
         net = model.net
         trainer = PipelinedStep(model, make_opt, lambda slot: net.precompute_geometry(pos),
-                                lambda geo: F.cross_entropy(net(Data(pos=pos, x=x), geometry=geo).x, y),
+                                lambda geo: F.cross_entropy(model(pos, x, geometry=geo), y),
                                 world_size=world, use_graph=use_graph, log=log, reduce_always=multi)
     log("model built; warm-up")
     graphed = trainer.warmup_and_capture(args.warmup)
@@ -745,10 +770,22 @@ def main():
                 fcpu = cpu_forward_baseline(args.cpu_sample_clouds, max(args.cpu_sample_iters // 2, 2))
                 forward_only["cpu_baseline"] = fcpu
                 forward_only["gpu_over_cpu"] = round(forward_only["value"] / fcpu["value"], 1)
+        # the north-star spatial kernels on their own (an isolated pass: in the pipelined step they share the chip with
+        # the feature path on another stream, which would inflate their per-launch time)
+        ns_summ = dict(summ)
+        if hasattr(model.net, "precompute_geometry"):
+            ns_timer = _lib.KernelTimer()
+            torch.cuda.synchronize()
+            _lib.set_timer(ns_timer)
+            for _ in range(args.steps):
+                model.net.precompute_geometry(pos)
+            torch.cuda.synchronize()
+            _lib.set_timer(None)
+            ns_summ.update(ns_timer.summary())
         value = world * b_rank * args.steps / dt
-        grouping = "MSG" if MODEL_CONFIG.endswith("_ms") else "SSG"
+        grouping = "MSG" if (MODEL_CONFIG.endswith("_ms") or args.workload == "msg_c3") else "SSG"
         line = {
-            "metric": "point-clouds/sec fwd+bwd PointNet++%s B=32 N=16384" % grouping,
+            "metric": "point-clouds/sec fwd+bwd PointNet++%s B=32 N=%d" % (grouping, N_POINTS),
             "value": round(value, 2),
             "unit": "point-clouds/s",
             "n_gpus": world,
@@ -760,9 +797,9 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": "PointNet++ %s (%s) train step fwd+bwd+Adam, B=%d per GPU, N=16384, "
-                                   "FEAT=3, 10 classes, pos~U[-1,1]^3 (BASELINE configs[%d])"
-                                   % (grouping, MODEL_CONFIG, b_rank, 2 if grouping == "MSG" else 1),
+            "config": {"workload": "PointNet++ %s (%s) train step fwd+bwd+Adam, B=%d per GPU, N=%d, "
+                                   "FEAT=3, %d classes, pos~U[-1,1]^3 (BASELINE configs[%d])"
+                                   % (grouping, MODEL_CONFIG, b_rank, N_POINTS, NUM_CLASSES, 2 if grouping == "MSG" else 1),
                        "launch": ("hip-graph replay" if graphed else "eager") + (
                            "" if args.no_geometry_prefetch else
                            "; sampling + searches of step i+1 on a second stream during step i (every step does both)"),
@@ -772,7 +809,7 @@ def main():
             "roofline": roofline,
             "cpu_baseline": cpu,
             "forward_only": forward_only,
-            "north_star_kernels": north_star_kernels(summ),
+            "north_star_kernels": north_star_kernels(ns_summ),
             "entry_points": entries,
             "kernels": kernels,
         }

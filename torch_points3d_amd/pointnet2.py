@@ -247,13 +247,42 @@ class PointNet2_D(nn.Module):
         last = layers[-1][0]
         return torch.addmm(last.bias, rows, last.weight.reshape(self._num_classes, -1).t())
 
-    def forward(self, data, category=None):
+    def precompute_geometry(self, pos):
+        """as PointNet2Unet.precompute_geometry: sampling, neighbour tables and interpolation tables of `pos` (B,N,3)"""
+        downs, _, ups = self.stages()
+        levels, cur, positions = [], pos, [pos]
+        for down in downs:
+            g = down.precompute(cur)
+            levels.append(g)
+            cur = g.new_pos
+            positions.append(cur)
+        tables, below = [], None
+        for up in ups:
+            skip_pos = positions.pop()
+            tables.append(up.precompute(below, skip_pos))
+            below = skip_pos
+        return Data(down=levels, up=tables)
+
+    def forward(self, data, category=None, geometry=None):
         x = None
         if data.x is not None:
             x = data.x.transpose(1, 2)
             if not (self.fused and x.is_cuda):
                 x = x.contiguous()
-        out = self.model(Data(pos=data.pos, x=x))
+        cur = Data(pos=data.pos, x=x)
+        if geometry is None:
+            out = self.model(cur)  # the nested blocks' own recursion
+        else:
+            # the same module order as that recursion (down ... global ... up), each stage with its precomputed tables
+            downs, inner, ups = self.stages()
+            skips = [cur]
+            for i, down in enumerate(downs):
+                cur = down(cur, precomputed=geometry.down[i])
+                skips.append(cur)
+            cur = inner(cur)
+            for i, up in enumerate(ups):
+                cur = up((cur, skips.pop()), precomputed=geometry.up[i])
+            out = cur
         return self.classify(out.x, category)
 
 
