@@ -30,6 +30,20 @@ def test_library_exports_every_declared_symbol():
     assert _lib.load().tp3d_strerror(-1).decode().startswith("bad argument")
 
 
+def test_cpu_library_exports_every_declared_symbol():
+    """include/tp3d_cpu.h (torch_points_kernels.points_cpu): plain C, loadable without any GPU runtime"""
+    from torch_points3d_amd import build
+    text = open(os.path.join(ROOT, "include", "tp3d_cpu.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    names = sorted(set(re.findall(r"\b(tp3d_cpu_[a-z0-9_]+)\s*\(", text)))
+    assert len(names) >= 6
+    h = ctypes.CDLL(build.build_cpu_library())
+    for n in names:
+        assert hasattr(h, n), "libtp3d_cpu.so does not export " + n
+    import torch_points_kernels.points_cpu as pc
+    assert callable(pc.ball_query) and callable(pc.dense_knn)
+
+
 def test_library_contains_gfx950_code_object():
     from torch_points3d_amd import build
     blob = open(build.build_library(), "rb").read()
