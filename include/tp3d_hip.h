@@ -35,7 +35,7 @@ extern "C" {
 #define TP3D_E_UNSORTED (-3) /* reserved: batch vector not sorted (checked by the host wrapper) */
 #define TP3D_E_TOOBIG (-4)   /* size exceeds what the kernel's index arithmetic supports */
 
-#define TP3D_ABI_VERSION 21
+#define TP3D_ABI_VERSION 22
 
 int tp3d_abi_version(void);
 const char *tp3d_strerror(int code);
@@ -338,6 +338,10 @@ int tp3d_attn_pool_bwd_f32(const float *g, const float *f, const float *dout, co
  * core/common_modules/base_modules.py:29-43):  Y (M, N) = A (M, K; row stride lda >= K) * W (N, K)^T,  N, K <= 32.
  * One row per lane, k ascending per output.  Y is dense (row stride N). */
 int tp3d_gemm_skinny_f32(const float *A, const float *W, int64_t M, int N, int K, int lda, float *Y, void *stream);
+/* The same with BatchNorm (given statistics rows mean / scale / beta of N: eval mode) and LeakyReLU applied to every
+ * output before it is stored: one pass over the rows instead of three (Linear, affine, activation). */
+int tp3d_gemm_skinny_bnact_f32(const float *A, const float *W, int64_t M, int N, int K, int lda, const float *mean,
+                               const float *scale, const float *beta, float slope, float *out, void *stream);
 
 /* Strided shortcut of the KPConv ResnetBBlock (modules/KPConv/blocks.py:206-210):
  *   out[q, c] = max over n of x[neighbors[q,n], c], a shadow neighbour (-1 or >= M) contributing 0.0

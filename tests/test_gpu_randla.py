@@ -121,3 +121,76 @@ def test_gemm_skinny(hip, M, N, K):
     wide = torch.randn(M, K + 5, generator=g).to(DEV)
     torch.testing.assert_close(fused.gemm_skinny(wide[:, 2:2 + K], W).double(), wide[:, 2:2 + K].double() @ W.double().t(),
                                rtol=1e-5, atol=1e-5)
+
+
+def test_eval_mode_edge_mlp_runs_in_one_pass(hip):
+    """Linear -> BatchNorm (running statistics) -> LeakyReLU of a few-channel edge MLP layer under torch.no_grad():
+    tp3d_gemm_skinny_bnact_f32 applies affine and activation in the GEMM's epilogue; same values as the plain modules"""
+    from torch_points3d_amd import fused
+    from torch_points3d_amd.partial_dense import MLP
+    torch.manual_seed(1)
+    mlp = MLP([12, 8, 6], bn_momentum=0.1).to(DEV)
+    with torch.no_grad():
+        for m in mlp.modules():
+            if isinstance(m, torch.nn.BatchNorm1d):
+                m.running_mean.normal_()
+                m.running_var.uniform_(0.5, 2.0)
+                m.weight.uniform_(0.5, 1.5)
+                m.bias.normal_()
+    mlp.eval()
+    x = torch.randn(70000, 12, device=DEV)
+    with torch.no_grad():
+        got = fused.rows_mlp(mlp, x)
+        want = mlp(x)
+    torch.testing.assert_close(got, want, rtol=1e-5, atol=1e-5)
+    # with a gradient wanted the two-kernel path (which keeps the pre-activation for the backward pass) serves it
+    xg = x.clone().requires_grad_(True)
+    fused.rows_mlp(mlp, xg).sum().backward()
+    xr = x.clone().requires_grad_(True)
+    mlp(xr).sum().backward()
+    torch.testing.assert_close(xg.grad, xr.grad, rtol=1e-4, atol=1e-5)
+
+
+def test_dilated_residual_block_and_edge_list(hip):
+    """RandLANetRes (conf/models/segmentation/randlanet.yaml Randlanet_Res, first down module) mirrors the reference's
+    module tree (state_dict keys of DilatedResidualBlock / BaseResnetBlock) and runs on the fused row kernels like the
+    unfused chain; RandlaConv(edge_list=True) exposes the reference's edge_index = [support index, query index]."""
+    import copy
+    from torch_points3d_amd.kpconv_blocks import PDData
+    from torch_points3d_amd.randla import RandLANetRes, RandlaConv
+    torch.manual_seed(2)
+    F = 6
+    block = RandLANetRes(indim=3, outdim=32, ratio=[1, 1], point_pos_nn=[[10, 8, F], [10, 16, 16]],
+                         attention_nn=[[2 * F, 8, 2 * F], [32, 64, 32]], down_conv_nn=[[2 * F, 8, 16], [32, 64, 32]],
+                         index=0, nb_feature=F).to(DEV).eval()
+    keys = set(block.state_dict())
+    for prefix in ("_conv.features_downsample_nn.0.0.weight", "_conv.features_upsample_nn.0.1.batch_norm.running_mean"
+                   if False else "_conv.features_upsample_nn.0.0.weight", "_conv.shortcut_feature_resize_nn.0.0.weight",
+                   "_conv.conv1._conv.point_pos_nn.0.0.weight", "_conv.conv2._conv.global_nn.1.0.weight"):
+        assert prefix in keys, prefix
+    n = 3000
+    pos = torch.rand(n, 3, device=DEV)
+    batch = torch.zeros(n, dtype=torch.long, device=DEV)
+    x = torch.randn(n, F, device=DEV)
+    twin = copy.deepcopy(block)
+    for m in twin.modules():
+        if hasattr(m, "fused"):
+            m.fused = False
+    torch.manual_seed(9)
+    with torch.no_grad():
+        a = block(PDData(pos=pos, batch=batch, x=x))
+    torch.manual_seed(9)  # same random subsampling in both
+    with torch.no_grad():
+        b = twin(PDData(pos=pos, batch=batch, x=x))
+    assert a.x.shape == (n, 32) and torch.equal(a.idx, b.idx)
+    torch.testing.assert_close(a.x, b.x, rtol=1e-4, atol=1e-4)
+    conv = RandlaConv(0.25, 16, point_pos_nn=[10, 8, F], attention_nn=[2 * F, 8, 2 * F], down_conv_nn=[2 * F, 8, 16],
+                      edge_list=True).to(DEV).eval()
+    with torch.no_grad():
+        out = conv(PDData(pos=pos, batch=batch, x=x))
+    ei = out.edge_index
+    assert ei.shape == (2, out.pos.shape[0] * 16)
+    assert torch.equal(ei[1], torch.arange(out.pos.shape[0], device=DEV).repeat_interleave(16))  # query-major
+    assert torch.equal(ei[0].view(-1, 16), out.neighbors)
+    d = (pos[ei[0]] - out.pos[ei[1]]).pow(2).sum(1).view(-1, 16)
+    assert bool((d[:, 1:] >= d[:, :-1] - 1e-7).all())  # closest first

@@ -54,6 +54,7 @@ SIGNATURES = {
     "tp3d_cluster_majority_i64": [_p, _p, _p, _l, _l, _l, _p, _p],
     "tp3d_kpconv_weighted_f32": [_p, _p, _p, _p, _p, _l, _l, _i, _i, _i, _f, _i, _i, _p, _p],
     "tp3d_gemm_skinny_f32": [_p, _p, _l, _i, _i, _i, _p, _p],
+    "tp3d_gemm_skinny_bnact_f32": [_p, _p, _l, _i, _i, _i, _p, _p, _p, _f, _p, _p],
     "tp3d_randla_relpos_f32": [_p, _p, _p, _l, _i, _l, _p, _p],
     "tp3d_attn_pool_fwd_f32": [_p, _p, _p, _l, _i, _i, _i, _i, _p, _p],
     "tp3d_attn_pool_bwd_f32": [_p, _p, _p, _p, _l, _i, _i, _i, _i, _p, _p, _p],
@@ -67,7 +68,7 @@ SIGNATURES = {
 MISC = ("tp3d_abi_version", "tp3d_strerror", "tp3d_last_hip_error", "tp3d_scatter_workspace_bytes",
         "tp3d_bn_workspace_floats", "tp3d_gemm_tn_workspace_floats", "tp3d_ball_query_workspace_bytes",
         "tp3d_gemm_rows_stat_floats", "tp3d_gemm_rows_stat_chunks", "tp3d_gemm_rows_workspace_floats", "tp3d_kpconv_bwd_workspace_bytes", "tp3d_voxel_workspace_bytes", "tp3d_knn_workspace_bytes", "tp3d_kpconv_grad_workspace_bytes")
-ABI_VERSION = 21
+ABI_VERSION = 22
 
 _handle = None
 

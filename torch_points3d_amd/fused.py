@@ -192,6 +192,17 @@ class _LinearBNAct(torch.autograd.Function):
         # the dense contraction on the fp32 MFMA rows kernel (128- or 64-column tiles); BatchNorm statistics come out of
         # its epilogue, except for the long contractions with few output tiles (the 4096-row global / decoder layers),
         # which run as a K-split launch followed by the separate statistics pass over their small output
+        if (not training and _is_skinny(M, Kp, Cout) and not any(ctx.needs_input_grad)):
+            # eval-mode edge MLP layer, no gradient wanted: Linear + BatchNorm (running statistics) + activation in ONE
+            # pass over the rows (tp3d_gemm_skinny_bnact_f32) instead of GEMM, statistics lookup and affine pass
+            with _lib.on_device(dev):
+                stats = _bn_stats(A, M, Cout, gamma, beta, bn, False, dev, st, bias)
+                rows_out = torch.empty((M, Cout), dtype=torch.float32, device=dev)
+                _lib.call("tp3d_gemm_skinny_bnact_f32", _lib.ptr(A), _lib.ptr(W2.contiguous()), M, Cout, Kp, Kp,
+                          _lib.ptr(stats[0]), _lib.ptr(stats[2]), _lib.ptr(stats[3]), slope, _lib.ptr(rows_out), st)
+            if pool_ns:
+                rows_out = rows_out.view(M // pool_ns, pool_ns, Cout).max(1)[0]
+            return rows_out
         own_gemm = _rows_gemm_serves(Cout) and Kp % 4 == 0
         # few output tiles and a contraction of 512..1023 channels: the rows kernel has nothing to hide its K walk
         # behind and a K-split would move more slab bytes than it saves -- library GEMM + separate statistics pass

@@ -149,6 +149,7 @@ class RandlaConv(nn.Module):
         super().__init__()
         self.sampler = RandomSampler(ratio)
         self.k = k
+        self.edge_list = bool(kwargs.get("edge_list", False))
         if kwargs.get("index") == 0 and kwargs.get("nb_feature") is not None:
             kwargs["point_pos_nn"][-1] = kwargs.get("nb_feature")
             kwargs["attention_nn"][0] = kwargs["attention_nn"][-1] = kwargs.get("nb_feature") * 2
@@ -164,7 +165,64 @@ class RandlaConv(nn.Module):
         out = data.shallow_copy() if hasattr(data, "shallow_copy") else PDData(**vars(data))
         out.idx = idx
         out.neighbors = nbr
+        if self.edge_list:
+            # the reference's edge list (message_passing.py:49-52: edge_index = stack([col, row])): query-major, each
+            # query's neighbours closest first -- row 0 = support index, row 1 = query index
+            row = torch.arange(nbr.shape[0], device=nbr.device).repeat_interleave(self.k)
+            col = nbr.reshape(-1)
+            keep = col >= 0
+            out.edge_index = torch.stack([col[keep], row[keep]], dim=0)
         out.x = self._conv(x, (q_pos, pos), nbr)
         out.pos = q_pos
         out.batch = q_batch
         return out
+
+
+class DilatedResidualBlock(nn.Module):
+    """Two RandlaConv in sequence inside a residual frame (modules/RandLANet/modules.py:70-102 on
+    core/base_conv/message_passing.py:212-255 `BaseResnetBlock`): the shortcut rows are gathered with the LAST
+    convolution's sample indices, resized by `shortcut_feature_resize_nn` and added to the up-sampled convolution output.
+    As in the reference, `features_downsample_nn` is evaluated on the input (its BatchNorm statistics move in training
+    mode) but its result is not what the convolutions consume -- they read `data.x` -- and `activation` is unused."""
+
+    def __init__(self, indim, outdim, ratio1, ratio2, point_pos_nn1, point_pos_nn2, attention_nn1, attention_nn2,
+                 global_nn1, global_nn2, *args, **kwargs):
+        super().__init__()
+        if kwargs.get("index") == 0 and kwargs.get("nb_feature") is not None:
+            indim = kwargs.get("nb_feature")
+        self.indim, self.outdim, self.convdim = indim, outdim, outdim
+        self.features_downsample_nn = MLP([indim, outdim // 4])
+        self.features_upsample_nn = MLP([outdim, outdim])
+        self.shortcut_feature_resize_nn = MLP([indim, outdim])
+        self.activation = nn.ReLU()
+        kw = dict(kwargs)
+        self.conv1 = RandlaConv(ratio1, 16, point_pos_nn=point_pos_nn1, attention_nn=attention_nn1,
+                                down_conv_nn=global_nn1, **kw)
+        kw["nb_feature"] = None
+        self.conv2 = RandlaConv(ratio2, 16, point_pos_nn=point_pos_nn2, attention_nn=attention_nn2,
+                                down_conv_nn=global_nn2, **kw)
+
+    def convs(self, data):
+        return self.conv2(self.conv1(data))
+
+    def forward(self, data, **kwargs):
+        shortcut = data.x
+        _fused.rows_mlp(self.features_downsample_nn, data.x)  # evaluated, not consumed (see the class note)
+        out = self.convs(data)
+        x = _fused.rows_mlp(self.features_upsample_nn, out.x)
+        if out.idx is not None:
+            shortcut = shortcut[out.idx]
+        out.x = _fused.rows_mlp(self.shortcut_feature_resize_nn, shortcut) + x
+        return out
+
+
+class RandLANetRes(nn.Module):
+    """conf/models/segmentation/randlanet.yaml `Randlanet_Res` down module: lists of two entries per argument"""
+
+    def __init__(self, indim, outdim, ratio, point_pos_nn, attention_nn, down_conv_nn, *args, **kwargs):
+        super().__init__()
+        self._conv = DilatedResidualBlock(indim, outdim, ratio[0], ratio[1], point_pos_nn[0], point_pos_nn[1],
+                                          attention_nn[0], attention_nn[1], down_conv_nn[0], down_conv_nn[1], *args, **kwargs)
+
+    def forward(self, data):
+        return self._conv(data)
