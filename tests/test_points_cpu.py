@@ -121,12 +121,14 @@ def test_usable_in_forked_workers_after_threaded_use_in_the_parent():
         ind, dist = points_cpu.ball_query(s, qq, radius=0.1, max_num=8, mode=0)
         ctx = mp.get_context("fork")
         q = ctx.Queue()
-        procs = [ctx.Process(target=_child, args=(q,)) for _ in range(2)]
+        procs = [ctx.Process(target=_child, args=(q,), daemon=True) for _ in range(2)]
         for p in procs:
             p.start()
         got = [q.get(timeout=60) for _ in procs]
         for p in procs:
             p.join(timeout=60)
+            if p.is_alive():
+                p.terminate()
             assert p.exitcode == 0
         assert all(g == (int(ind.sum()), float(dist.sum())) for g in got)
     finally:

@@ -32,6 +32,11 @@ class ShardedStep(object):
         capture then crashes at instantiation -- seen with tools/bench_kpconv.py when it warmed up that way)."""
         self.model = model
         self.loss_fn = loss_fn
+        try:
+            from . import fused as _fused_mod
+        except Exception:  # noqa: BLE001 -- the CPU tests drive this class without the HIP library
+            _fused_mod = None
+        self._fused = _fused_mod
         self.world = world_size
         self.reduce_always = reduce_always  # issue the collective even on one rank (rehearsal of the N > 1 path)
         self.log = log or (lambda msg: None)
@@ -85,6 +90,8 @@ class ShardedStep(object):
         loss = self.loss_fn()
         # fresh gradient tensors (no per-parameter "+=" kernels), packed into the flat buffer by one concatenation
         grads = torch.autograd.grad(loss, self.params, allow_unused=True)
+        if self._fused is not None:
+            self._fused.join_wgrad_stream()  # weight-gradient GEMMs issued on the side stream (fused.OVERLAP_WGRAD)
         pieces = []
         for g, p, pad in zip(grads, self.params, self._pads):
             # a parameter the loss does not reach gets a zero gradient (DDP: find_unused_parameters)

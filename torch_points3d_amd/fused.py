@@ -144,6 +144,30 @@ def _rows_gemm_serves(cout):
     return ROWS_GEMM_NARROW or not (0 < cout % 128 <= 64)
 
 
+# Weight-gradient GEMMs on a second stream.  dW_l = dY_l^T A_l is needed only by the optimizer, while the backward chain
+# continues with dA_{l-1} and the HBM-bound BatchNorm backward of the next layer: an MFMA-bound kernel beside a
+# bandwidth-bound one.  Opt-in (a stepper that calls join_wgrad_stream() before it reads the gradients -- dp.ShardedStep
+# does): plain loss.backward() users keep everything on one stream.
+OVERLAP_WGRAD = False
+WGRAD_MIN_ROWS = 65536
+_wgrad_side = {}  # device index -> [side stream, work pending]
+
+
+def _wgrad_stream(dev):
+    slot = _wgrad_side.get(dev.index)
+    if slot is None:
+        slot = _wgrad_side[dev.index] = [torch.cuda.Stream(device=dev), False]
+    return slot
+
+
+def join_wgrad_stream(device=None):
+    """the current stream waits for the weight-gradient GEMMs that were issued on the side stream (no-op otherwise)"""
+    for idx, slot in _wgrad_side.items():
+        if slot[1] and (device is None or device.index in (None, idx)):
+            torch.cuda.current_stream(slot[0].device).wait_stream(slot[0])
+            slot[1] = False
+
+
 def _long_k(M, N, K):
     """few output tiles and a long contraction: served by the K-split launch (no fused statistics)"""
     return _lib.load().tp3d_gemm_rows_workspace_floats(M, N, K) > 0
@@ -256,7 +280,18 @@ class _LinearBNAct(torch.autograd.Function):
                       _lib.ptr(stats[3]), _lib.ptr(stats[0]), _lib.ptr(stats[1]), slope, M, max(pool_ns, 1), Cout,
                       int(training), _lib.ptr(dgb[0]), _lib.ptr(dgb[1]), _lib.ptr(dY), _lib.ptr(ws),
                       _lib.stream_ptr(dev))
-        dW = gemm_tn(dY, A)[:, :Cin].reshape(wshape) if ctx.needs_input_grad[1] else None
+        dW = None
+        if ctx.needs_input_grad[1]:
+            if OVERLAP_WGRAD and M >= WGRAD_MIN_ROWS:
+                slot = _wgrad_stream(dev)
+                slot[0].wait_stream(torch.cuda.current_stream(dev))  # dY is complete on the main stream here
+                with torch.cuda.stream(slot[0]):
+                    dW = gemm_tn(dY, A)[:, :Cin].reshape(wshape)
+                dY.record_stream(slot[0])  # the allocator must not recycle the operands before the side stream is done
+                A.record_stream(slot[0])
+                slot[1] = True
+            else:
+                dW = gemm_tn(dY, A)[:, :Cin].reshape(wshape)
         dA = None
         if ctx.needs_input_grad[0]:
             if _is_skinny(M, W2.shape[1], Cout):
