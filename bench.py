@@ -675,8 +675,9 @@ def main():
         saved = (trainer.world, trainer.reduce_always)
         trainer.world, trainer.reduce_always = 1, False
         _lib.set_timer(timer)
+        eager = getattr(trainer, "serial_eager_step", trainer.eager_step)  # one stream: clean event brackets
         for _ in range(args.steps):
-            trainer.eager_step()
+            eager()
         torch.cuda.synchronize()
         _lib.set_timer(None)
         trainer.world, trainer.reduce_always = saved
@@ -770,18 +771,7 @@ def main():
                 fcpu = cpu_forward_baseline(args.cpu_sample_clouds, max(args.cpu_sample_iters // 2, 2))
                 forward_only["cpu_baseline"] = fcpu
                 forward_only["gpu_over_cpu"] = round(forward_only["value"] / fcpu["value"], 1)
-        # the north-star spatial kernels on their own (an isolated pass: in the pipelined step they share the chip with
-        # the feature path on another stream, which would inflate their per-launch time)
-        ns_summ = dict(summ)
-        if hasattr(model.net, "precompute_geometry"):
-            ns_timer = _lib.KernelTimer()
-            torch.cuda.synchronize()
-            _lib.set_timer(ns_timer)
-            for _ in range(args.steps):
-                model.net.precompute_geometry(pos)
-            torch.cuda.synchronize()
-            _lib.set_timer(None)
-            ns_summ.update(ns_timer.summary())
+        ns_summ = summ  # the per-kernel pass runs on one stream: the spatial kernels are timed on their own
         value = world * b_rank * args.steps / dt
         grouping = "MSG" if (MODEL_CONFIG.endswith("_ms") or args.workload == "msg_c3") else "SSG"
         line = {

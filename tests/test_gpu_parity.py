@@ -132,9 +132,55 @@ def test_three_nn(hip, oracle, B, n, m, kind):
     gd, gi = hip.three_nn(unknown.to(DEV), known.to(DEV))
     rd, ri = oracle.three_nn(unknown, known)
     assert torch.equal(gi.cpu(), ri)
-    torch.testing.assert_close(gd.cpu(), rd, **TOL)
+    assert torch.equal(gd.cpu(), rd)  # correctly rounded sqrt of a bit-identical squared distance
     with pytest.raises(ValueError):
         hip.three_nn(unknown.to(DEV), known[:, :2].to(DEV))
+
+
+@pytest.mark.parametrize("case", ["subset", "lattice", "duplicates", "planar", "one_place", "far_queries", "m64", "m896",
+                                  "m897", "line", "two_clusters", "sparse_shell"])
+def test_three_nn_grid_path_is_exact(hip, oracle, case):
+    """The in-LDS grid walk (64 <= m <= 896, n >= 4 m) must give the scan's answer on the geometries that stress its
+    stop rule and its (distance, index) ranking: exact ties, duplicates, degenerate boxes, queries outside the box of the
+    known cloud, lanes that need several shells."""
+    g = torch.Generator().manual_seed(7)
+    B, n, m = 2, 5000, 512
+    unknown = torch.rand(B, n, 3, generator=g) * 2 - 1
+    if case == "subset":  # the decoder's case: the known points are a subset of the unknown ones (distance 0 hits)
+        known = unknown[:, torch.randperm(n, generator=g)[:m]].contiguous()
+    elif case == "lattice":
+        unknown = torch.randint(0, 9, (B, n, 3), generator=g).float() * 0.125
+        known = torch.randint(0, 9, (B, m, 3), generator=g).float() * 0.125
+    elif case == "duplicates":
+        known = (torch.rand(B, m // 4, 3, generator=g) * 2 - 1).repeat(1, 4, 1)
+    elif case == "planar":
+        known = torch.rand(B, m, 3, generator=g) * 2 - 1
+        known[..., 2] = 0.25
+    elif case == "one_place":
+        known = torch.full((B, m, 3), 0.5)
+    elif case == "far_queries":
+        known = torch.rand(B, m, 3, generator=g) * 0.2
+        unknown = unknown * 5
+    elif case == "m64":
+        m = 64
+        known = torch.rand(B, m, 3, generator=g) * 2 - 1
+    elif case in ("m896", "m897"):  # the largest known cloud the grid form takes / the first the scan takes again
+        n, m = 8192, int(case[1:])
+        unknown = torch.rand(B, n, 3, generator=g) * 2 - 1
+        known = torch.rand(B, m, 3, generator=g) * 2 - 1
+    elif case == "sparse_shell":  # known points on a sphere, unknown ones inside: empty cells around most queries
+        known = torch.nn.functional.normalize(torch.randn(B, m, 3, generator=g), dim=-1)
+        unknown = unknown * 0.5
+    elif case == "line":
+        known = torch.zeros(B, m, 3)
+        known[..., 0] = torch.rand(B, m, generator=g)
+    else:  # two far-apart clusters: most cells empty, queries between them need many shells
+        known = torch.rand(B, m, 3, generator=g) * 0.05
+        known[:, m // 2:] += 3.0
+    gd, gi = hip.three_nn(unknown.to(DEV), known.to(DEV))
+    rd, ri = oracle.three_nn(unknown, known)
+    assert torch.equal(gi.cpu(), ri)
+    assert torch.equal(gd.cpu(), rd)
 
 
 # ------------------------------------------------------------------------- interpolate / grouping

@@ -68,7 +68,10 @@ def bench_ball(reps):
         by = B * (N * 12 + n * 12 + n * ns * 12)
         print("ball_query B=%d N=%d np=%d r=%.2f ns=%d  %8.1f us  %7.1f GB/s algorithmic" % (B, N, n, r, ns, t * 1e3, by / t / 1e6))
         t = timeit(lambda: tp.three_nn(pos, q), reps)
-        print("three_nn   n=%d m=%d  %8.1f us" % (N, n, t * 1e3))
+        sel = tp.furthest_point_sample(pos, n)
+        qf = torch.gather(pos, 1, sel.unsqueeze(-1).expand(-1, -1, 3)).contiguous()  # the decoder's case: FPS subset
+        t2 = timeit(lambda: tp.three_nn(pos, qf), reps)
+        print("three_nn   n=%d m=%d  %8.1f us (known = first m)  %8.1f us (known = FPS subset)" % (N, n, t * 1e3, t2 * 1e3))
 
 
 def bench_kpconv(reps):

@@ -274,3 +274,12 @@ class PipelinedStep(ShardedStep):
 
     def eager_step(self):
         self._eager_step()
+
+    def serial_eager_step(self):
+        """Geometry and training pass back to back on the current stream: what bench.py's per-kernel HIP-event pass runs
+        (with the second stream active, event brackets on one stream also cover time the other stream's kernels hold
+        the chip)."""
+        self._slots[self._cur] = self._geometry_fn(self._cur)
+        self._forward_backward()
+        self._reduce()
+        self.opt.step()
