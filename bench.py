@@ -88,10 +88,21 @@ def build_model(kernels, device):
     return SegStep(net).to(device).train()
 
 
+def seg_loss(logits, y):
+    """Cross entropy over all points; --loss-layout rows feeds it the (B*N, classes) view instead (the form the
+    reference's segmentation models use, models/segmentation/pointnet2.py:97-101)."""
+    if not LOSS_ROWS:
+        return F.cross_entropy(logits, y)
+    return F.cross_entropy(logits.transpose(1, 2).reshape(-1, logits.shape[1]), y.reshape(-1))
+
+
+LOSS_ROWS = False
+
+
 def train_step(model, opt, pos, x, y):
     opt.zero_grad(set_to_none=True)
     logits = model(pos, x)
-    loss = F.cross_entropy(logits, y)
+    loss = seg_loss(logits, y)
     loss.backward()
     opt.step()
     return loss
@@ -574,6 +585,13 @@ def main():
                          "split over the ranks (32/16/8/4 per GPU at 1/2/4/8 GPUs, SURVEY 8e)")
     ap.add_argument("--no-geometry-prefetch", action="store_true",
                     help="compute sampling / searches inside the training pass instead of one step ahead on a second stream")
+    ap.add_argument("--adam", default="fused", choices=["fused", "foreach"],
+                    help="torch.optim.Adam implementation: one fused kernel over the flat parameter buffer, or the "
+                         "multi-tensor form (~15 short launches)")
+    ap.add_argument("--loss-layout", default="nchw", choices=["rows", "nchw"],
+                    help="cross entropy on the (B, classes, N) scores (default; PyTorch's spatial soft-max kernels) or on "
+                         "their (B*N, classes) view (no transposing copies, but PyTorch's row soft-max is 0.7 ms slower on "
+                         "10-wide rows -- measured, kept as a switch)")
     ap.add_argument("--set", action="append", default=[], metavar="NAME=VALUE",
                     help="experiment switch: set an attribute of torch_points3d_amd.fused (e.g. USE_MLP_CHAIN=0) before the "
                          "run; recorded in the JSON line")
@@ -637,15 +655,19 @@ def main():
     model = build_model(None, device)
     pos, x, y = make_inputs(b_rank, N_POINTS, 1234 + rank, device)
     use_graph = not args.no_graph
-    make_opt = lambda params: torch.optim.Adam(params, lr=1e-3, capturable=use_graph)  # noqa: E731
+    # one fused kernel over the flat parameter buffer (the foreach form is ~15 launches of a few microseconds each)
+    make_opt = lambda params: torch.optim.Adam(params, lr=1e-3, fused=args.adam == "fused",  # noqa: E731
+                                               foreach=args.adam == "foreach", capturable=use_graph)
+    global LOSS_ROWS
+    LOSS_ROWS = args.loss_layout == "rows"
     if args.no_geometry_prefetch or not hasattr(model.net, "precompute_geometry"):
-        trainer = ShardedStep(model, make_opt, lambda: F.cross_entropy(model(pos, x), y), world_size=world,
+        trainer = ShardedStep(model, make_opt, lambda: seg_loss(model(pos, x), y), world_size=world,
                               use_graph=use_graph, log=log, reduce_always=multi)
     else:
         # sampling / radius searches / 3-NN tables of step i+1 run on a second stream during step i (dp.PipelinedStep)
         net = model.net
         trainer = PipelinedStep(model, make_opt, lambda slot: net.precompute_geometry(pos),
-                                lambda geo: F.cross_entropy(model(pos, x, geometry=geo), y),
+                                lambda geo: seg_loss(model(pos, x, geometry=geo), y),
                                 world_size=world, use_graph=use_graph, log=log, reduce_always=multi)
     log("model built; warm-up")
     graphed = trainer.warmup_and_capture(args.warmup)

@@ -35,7 +35,7 @@ extern "C" {
 #define TP3D_E_UNSORTED (-3) /* reserved: batch vector not sorted (checked by the host wrapper) */
 #define TP3D_E_TOOBIG (-4)   /* size exceeds what the kernel's index arithmetic supports */
 
-#define TP3D_ABI_VERSION 22
+#define TP3D_ABI_VERSION 23
 
 int tp3d_abi_version(void);
 const char *tp3d_strerror(int code);
@@ -146,12 +146,14 @@ int tp3d_rows_scatter_bwd_f32(const float *grad_rows, const int64_t *idx, const 
 /* BatchNorm statistics of Y (M, C): mean, invstd, scale = gamma*invstd and shift = beta; the normalised value is
  * always formed as (y - mean)*scale + shift (a folded shift beta - mean*scale would cancel against y*scale in fp32
  * when |mean| >> std).  Batch statistics are accumulated as shifted sums per row chunk and merged with Chan's formula.
- * training != 0: batch mean / biased variance (running stats updated in place with `momentum`, unbiased var);
+ * training != 0: batch mean / biased variance (running stats updated in place with `momentum`, unbiased var;
+ * *num_batches_tracked, if given, incremented on the device -- BatchNorm's counter without a launch of its own);
  * training == 0: running statistics.  workspace: tp3d_bn_workspace_floats(M, C) floats. */
 size_t tp3d_bn_workspace_floats(int64_t M, int C);
 int tp3d_bn_stats_f32(const float *Y, int64_t M, int C, float eps, float momentum, const float *gamma,
-                      const float *beta, float *running_mean, float *running_var, int training, float *mean,
-                      float *invstd, float *scale, float *shift, float *workspace, void *stream);
+                      const float *beta, float *running_mean, float *running_var, int64_t *num_batches_tracked,
+                      int training, float *mean, float *invstd, float *scale, float *shift, float *workspace,
+                      void *stream);
 
 /* out = LeakyReLU_slope((Y - mean)*scale + shift) over (M, C);  the pooled form also takes the max over each group of
  * ns consecutive rows (first maximum wins) and records its row in argmax (G, C). */
@@ -203,9 +205,10 @@ int tp3d_gemm_rows_bnact_f32(const float *Y, const float *mean, const float *sca
 int tp3d_gemm_rows_bnbwd_f32(const float *Y, const float *dA, const int *argmax, int ns, const float *mean,
                              const float *scale, const float *beta, const float *c1, const float *c2, float slope,
                              const float *Bt, int64_t M, int N, int K, float *C, void *stream);
-int tp3d_bn_finalize_f32(const float *partial, int chunks, int64_t M, int C, float eps, float momentum,
-                         const float *gamma, const float *beta, float *running_mean, float *running_var, float *mean,
-                         float *invstd, float *scale, float *shift, void *stream);
+/* `partial` is consumed: with more than 64 chunks they are first folded, in place, into 32 slices. */
+int tp3d_bn_finalize_f32(float *partial, int chunks, int64_t M, int C, float eps, float momentum, const float *gamma,
+                         const float *beta, float *running_mean, float *running_var, int64_t *num_batches_tracked,
+                         float *mean, float *invstd, float *scale, float *shift, void *stream);
 
 /* Weight gradient of a 1x1 conv / shared-MLP layer:  out[n,k] = sum_r dY[r,n] * A[r,k]
  * dY (M,N), A (M,K) row-major -> out (N,K); rows split over the grid, fp32 MFMA, fixed-order reduction of the

@@ -299,6 +299,35 @@ def test_gemm_rows_matches_fp64_and_stats(M, N, K):
     assert torch.equal(Ci, torch.mm(Ai.double(), Bi.double()).float())
 
 
+@pytest.mark.parametrize("M,N,offset", [(262144, 128, 0.0), (300000, 64, 40.0), (5000, 256, 0.0), (140000, 132, 3.0)])
+def test_bn_finalize_from_gemm_partials(M, N, offset):
+    """tp3d_bn_finalize_f32 on the partial sums a rows GEMM leaves: few chunks are folded by one workgroup per channel,
+    many (2048 for a launch that fills the persistent grid) first into 32 slices, coalesced and in place.  Mean and
+    variance against fp64, also where |mean| >> std; running statistics and the batch counter updated on the device."""
+    from torch_points3d_amd import _lib, fused
+    g = torch.Generator().manual_seed(M + N)
+    K = 64
+    A = (torch.randn(M, K, generator=g) * 0.1 + offset / K).to(DEV)
+    Bm = (torch.rand(K, N, generator=g) + 0.5).to(DEV)
+    C, part = fused.gemm_rows(A, Bm.t().contiguous(), want_stats=True)
+    ref = C.double()
+    chunks = _lib.load().tp3d_gemm_rows_stat_chunks(M, N)
+    stats = torch.empty(4, N, device=DEV)
+    gamma, beta = torch.rand(N, device=DEV) + 0.5, torch.randn(N, device=DEV)
+    rm, rv = torch.zeros(N, device=DEV), torch.ones(N, device=DEV)
+    nbt = torch.zeros((), dtype=torch.int64, device=DEV)
+    _lib.call("tp3d_bn_finalize_f32", part.data_ptr(), chunks, M, N, 1e-5, 0.1, gamma.data_ptr(), beta.data_ptr(), rm.data_ptr(),
+              rv.data_ptr(), nbt.data_ptr(), stats[0].data_ptr(), stats[1].data_ptr(), stats[2].data_ptr(), stats[3].data_ptr(),
+              _lib.stream_ptr(A.device))
+    mean, var = ref.mean(0), ref.var(0, unbiased=False)
+    torch.testing.assert_close(stats[0].double(), mean, rtol=2e-7, atol=2e-7 * float(var.sqrt().max()))  # float resolution
+    torch.testing.assert_close(stats[1].double(), 1.0 / torch.sqrt(var + 1e-5), rtol=2e-6, atol=0)
+    torch.testing.assert_close(stats[2], gamma * stats[1])
+    assert torch.equal(stats[3], beta) and int(nbt) == 1
+    torch.testing.assert_close(rm.double(), 0.1 * mean, rtol=1e-6, atol=1e-7 * float(var.sqrt().max()))
+    torch.testing.assert_close(rv.double(), 0.9 + 0.1 * var * M / (M - 1), rtol=1e-5, atol=0)
+
+
 @pytest.mark.parametrize("train", [True, False])
 def test_rows_mlp_with_linear_bias_matches_modules(train):
     """The reference's partial-dense MLP keeps the Linear bias in front of BatchNorm (base_modules.py:29-43): the fused

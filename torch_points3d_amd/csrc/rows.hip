@@ -327,27 +327,84 @@ __device__ __forceinline__ void sum_partials(const float *__restrict__ partial, 
 }
 
 // finalize (training): the chunks' (sum d, sum d^2, shift K, rows n) are merged like Chan et al.'s parallel variance.
+// Many chunks (a rows GEMM that fills the persistent grid leaves 2048 of them, 4 MB at 128 channels): one workgroup
+// per channel would gather its column 4 bytes at a time from rows 4*C*4 bytes apart.  First pass instead: workgroup
+// (column tile of 32, slice s) folds the chunks [s*per, (s+1)*per) of its 32 columns -- 128-byte rows, coalesced -- in
+// double, ascending order per thread then a fixed tree, and writes the result back IN PLACE as the slice's first chunk
+// (K = float(mean), S = n (mean - K), Q = M2 + S^2/n, n): the same shifted-sum format, so bn_finalize_kernel folds the slices with a stride.
+constexpr int BM_COLS = 32, BM_LANES = RW_BLOCK / BM_COLS;
+__global__ __launch_bounds__(RW_BLOCK) void bn_merge_slices_kernel(float *__restrict__ partial, int chunks, int per, int C)
+{
+    __shared__ double rn[BM_LANES][BM_COLS], rm[BM_LANES][BM_COLS], r2[BM_LANES][BM_COLS];
+    const int cx = threadIdx.x % BM_COLS, ry = threadIdx.x / BM_COLS;
+    const int c = blockIdx.x * BM_COLS + cx;
+    const int k0 = blockIdx.y * per, k1 = min(k0 + per, chunks);
+    double n = 0.0, mu = 0.0, m2 = 0.0;
+    if (c < C)
+        for (int k = k0 + ry; k < k1; k += BM_LANES) {
+            const float *pk = partial + (size_t)k * 4 * C + c;
+            const double nb = (double)pk[(size_t)3 * C];
+            if (nb > 0.0) {
+                const double S = (double)pk[0], Q = (double)pk[(size_t)C];
+                const double mb = (double)pk[(size_t)2 * C] + S / nb, m2b = Q - S * S / nb;
+                const double tot = n + nb, dm = mb - mu;
+                mu += dm * (nb / tot);
+                m2 += m2b + dm * dm * (n * nb / tot);
+                n = tot;
+            }
+        }
+    rn[ry][cx] = n;
+    rm[ry][cx] = mu;
+    r2[ry][cx] = m2;
+    __syncthreads();
+    for (int off = BM_LANES / 2; off > 0; off >>= 1) {
+        if (ry < off) {
+            const double na = rn[ry][cx], nb = rn[ry + off][cx];
+            const double tot = na + nb;
+            if (nb > 0.0) {
+                const double dm = rm[ry + off][cx] - rm[ry][cx];
+                rm[ry][cx] += dm * (nb / tot);
+                r2[ry][cx] += r2[ry + off][cx] + dm * dm * (na * nb / tot);
+                rn[ry][cx] = tot;
+            }
+        }
+        __syncthreads();
+    }
+    if (ry == 0 && c < C && k0 < k1) {
+        float *pk = partial + (size_t)k0 * 4 * C + c;
+        const double nn = rn[0][cx];
+        const float kf = (float)rm[0][cx];
+        const double sres = nn * (rm[0][cx] - (double)kf);  // what the float shift misses of the slice mean
+        pk[0] = (float)sres;
+        pk[(size_t)C] = (float)(r2[0][cx] + (nn > 0.0 ? sres * sres / nn : 0.0));
+        pk[(size_t)2 * C] = kf;
+        pk[(size_t)3 * C] = (float)nn;
+    }
+}
+
 // A chunk is (n, mean = K + S/n, M2 = Q - S^2/n); two sets merge as
 //   n = na + nb,  mean = ma + (mb - ma) nb / n,  M2 = M2a + M2b + (mb - ma)^2 na nb / n
 // in double: every thread folds its chunks in ascending order, then a fixed tree over the workgroup (reproducible,
 // ONE pass over the partials).  mean, biased var -> scale = gamma*invstd, shift_out = beta; running stats update.
 // eval: scale from the running statistics.  One workgroup per channel.
 __global__ __launch_bounds__(RW_BLOCK) void bn_finalize_kernel(
-    const float *__restrict__ partial, int chunks, int64_t M, int C, float eps, float momentum,
+    const float *__restrict__ partial, int chunks, int chunk_stride, int64_t M, int C, float eps, float momentum,
     const float *__restrict__ gamma, const float *__restrict__ beta, float *__restrict__ running_mean,
-    float *__restrict__ running_var, int training, float *__restrict__ mean_out, float *__restrict__ invstd_out,
-    float *__restrict__ scale_out, float *__restrict__ shift_out)
+    float *__restrict__ running_var, int64_t *__restrict__ batches, int training, float *__restrict__ mean_out,
+    float *__restrict__ invstd_out, float *__restrict__ scale_out, float *__restrict__ shift_out)
 {
     __shared__ double rn[RW_BLOCK], rm[RW_BLOCK], r2[RW_BLOCK];
     const int c = blockIdx.x;
     float mean, var;
     if (training) {
+        if (batches && c == 0 && threadIdx.x == 0) *batches += 1;  // BatchNorm's num_batches_tracked
         double n = 0.0, mu = 0.0, m2 = 0.0;
         for (int k = threadIdx.x; k < chunks; k += RW_BLOCK) {
-            const double nb = (double)partial[((size_t)k * 4 + 3) * C + c];
+            const float *pk = partial + (size_t)k * chunk_stride * 4 * C + c;
+            const double nb = (double)pk[(size_t)3 * C];
             if (nb > 0.0) {
-                const double S = (double)partial[((size_t)k * 4 + 0) * C + c], Q = (double)partial[((size_t)k * 4 + 1) * C + c];
-                const double mb = (double)partial[((size_t)k * 4 + 2) * C + c] + S / nb, m2b = Q - S * S / nb;
+                const double S = (double)pk[0], Q = (double)pk[(size_t)C];
+                const double mb = (double)pk[(size_t)2 * C] + S / nb, m2b = Q - S * S / nb;
                 const double tot = n + nb, dm = mb - mu;
                 mu += dm * (nb / tot);
                 m2 += m2b + dm * dm * (n * nb / tot);
@@ -880,10 +937,30 @@ TP3D_EXPORT int tp3d_bn_plan(int64_t M, int C, int pooled_ns, int64_t *plan)
     return TP3D_OK;
 }
 
+// Statistics from chunk partials: more than BN_DIRECT_CHUNKS of them are first folded into BN_SLICES slices (coalesced,
+// in place), then one workgroup per channel folds those.
+constexpr int BN_DIRECT_CHUNKS = 64, BN_SLICES = 32;
+static int launch_bn_finalize(float *partial, int chunks, int64_t M, int C, float eps, float momentum, const float *gamma,
+                              const float *beta, float *running_mean, float *running_var, int64_t *batches, int training,
+                              float *mean, float *invstd, float *scale, float *shift, hipStream_t s)
+{
+    int n = chunks, stride = 1;
+    if (training && chunks > BN_DIRECT_CHUNKS) {
+        stride = (chunks + BN_SLICES - 1) / BN_SLICES;
+        n = (chunks + stride - 1) / stride;
+        hipLaunchKernelGGL(bn_merge_slices_kernel, dim3((C + BM_COLS - 1) / BM_COLS, n), dim3(RW_BLOCK), 0, s, partial, chunks,
+                           stride, C);
+        if (int rc = check_launch()) return rc;
+    }
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(RW_BLOCK), 0, s, partial, n, stride, M, C, eps, momentum, gamma, beta,
+                       running_mean, running_var, batches, training, mean, invstd, scale, shift);
+    return check_launch();
+}
+
 TP3D_EXPORT int tp3d_bn_stats_f32(const float *Y, int64_t M, int C, float eps, float momentum, const float *gamma,
-                                  const float *beta, float *running_mean, float *running_var, int training,
-                                  float *mean, float *invstd, float *scale, float *shift, float *workspace,
-                                  void *stream)
+                                  const float *beta, float *running_mean, float *running_var,
+                                  int64_t *num_batches_tracked, int training, float *mean, float *invstd, float *scale,
+                                  float *shift, float *workspace, void *stream)
 {
     if (M <= 0 || C <= 0 || !mean || !invstd || !scale || !shift) return TP3D_E_BADARG;
     if (!training && (!running_mean || !running_var)) return TP3D_E_BADARG;
@@ -906,21 +983,20 @@ TP3D_EXPORT int tp3d_bn_stats_f32(const float *Y, int64_t M, int C, float eps, f
         }
         if (int rc = check_launch()) return rc;
     }
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(RW_BLOCK), 0, s, workspace, chunks, M, C, eps, momentum, gamma,
-                       beta, running_mean, running_var, training, mean, invstd, scale, shift);
-    return check_launch();
+    return launch_bn_finalize(workspace, chunks, M, C, eps, momentum, gamma, beta, running_mean, running_var,
+                              num_batches_tracked, training, mean, invstd, scale, shift, s);
 }
 
 // training-mode statistics from per-chunk (sum, sum of squares) partials written by another kernel's epilogue
 // (tp3d_gemm_rows_f32): partial[chunk][2][C]
-TP3D_EXPORT int tp3d_bn_finalize_f32(const float *partial, int chunks, int64_t M, int C, float eps, float momentum,
+TP3D_EXPORT int tp3d_bn_finalize_f32(float *partial, int chunks, int64_t M, int C, float eps, float momentum,
                                      const float *gamma, const float *beta, float *running_mean, float *running_var,
-                                     float *mean, float *invstd, float *scale, float *shift, void *stream)
+                                     int64_t *num_batches_tracked, float *mean, float *invstd, float *scale, float *shift,
+                                     void *stream)
 {
     if (M <= 0 || C <= 0 || chunks <= 0 || !partial || !mean || !invstd || !scale || !shift) return TP3D_E_BADARG;
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(RW_BLOCK), 0, (hipStream_t)stream, partial, chunks, M, C, eps,
-                       momentum, gamma, beta, running_mean, running_var, 1, mean, invstd, scale, shift);
-    return check_launch();
+    return launch_bn_finalize(partial, chunks, M, C, eps, momentum, gamma, beta, running_mean, running_var,
+                              num_batches_tracked, 1, mean, invstd, scale, shift, (hipStream_t)stream);
 }
 
 TP3D_EXPORT int tp3d_bn_act_f32(const float *Y, const float *mean, const float *scale, const float *shift, float slope,

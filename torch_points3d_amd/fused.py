@@ -127,8 +127,15 @@ def _finalize_stats(part, M, C, gamma, beta, bn, dev, st):
     stats = torch.empty((4, C), dtype=torch.float32, device=dev)
     _lib.call("tp3d_bn_finalize_f32", _lib.ptr(part), _lib.load().tp3d_gemm_rows_stat_chunks(M, C), M, C, float(bn.eps),
               float(bn.momentum), _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(bn.running_mean), _lib.ptr(bn.running_var),
-              _lib.ptr(stats[0]), _lib.ptr(stats[1]), _lib.ptr(stats[2]), _lib.ptr(stats[3]), st)
+              _lib.ptr(bn.num_batches_tracked), _lib.ptr(stats[0]), _lib.ptr(stats[1]), _lib.ptr(stats[2]), _lib.ptr(stats[3]), st)
+    _note_training_pass(bn)
     return stats
+
+
+def _note_training_pass(bn):
+    """The kernels update running_mean / running_var / num_batches_tracked in place without touching the tensors'
+    version counters: eval-mode statistics cached on the module (_bn_stats) are keyed on this count as well."""
+    bn._tp3d_train_passes = getattr(bn, "_tp3d_train_passes", 0) + 1
 
 
 ROWS_GEMM_MIN_COLS = 32   # narrower outputs (class scores, edge MLPs) stay on the library / skinny kernels
@@ -179,15 +186,17 @@ def _bn_stats(Y, M, C, gamma, beta, bn, training, dev, st, bias=None):
     key = None
     if not training:
         key = tuple((t.data_ptr(), t._version) for t in (gamma, beta, bn.running_mean, bn.running_var)
-                    + ((bias,) if bias is not None else ()))
+                    + ((bias,) if bias is not None else ())) + (getattr(bn, "_tp3d_train_passes", 0),)
         hit = getattr(bn, "_tp3d_eval_stats", None)
         if hit is not None and hit[0] == key:
             return hit[1]
     stats = torch.empty((4, C), dtype=torch.float32, device=dev)
     ws = _lib.bn_workspace(M, C, dev)
     _lib.call("tp3d_bn_stats_f32", _lib.ptr(Y), M, C, float(bn.eps), float(bn.momentum), _lib.ptr(gamma), _lib.ptr(beta),
-              _lib.ptr(bn.running_mean), _lib.ptr(bn.running_var), int(training), _lib.ptr(stats[0]), _lib.ptr(stats[1]),
-              _lib.ptr(stats[2]), _lib.ptr(stats[3]), _lib.ptr(ws), st)
+              _lib.ptr(bn.running_mean), _lib.ptr(bn.running_var), _lib.ptr(bn.num_batches_tracked) if training else None,
+              int(training), _lib.ptr(stats[0]), _lib.ptr(stats[1]), _lib.ptr(stats[2]), _lib.ptr(stats[3]), _lib.ptr(ws), st)
+    if training:
+        _note_training_pass(bn)
     if key is not None:
         if bias is not None:
             stats[0].sub_(bias.detach())  # (Y + b - running_mean) * scale + beta == (Y - (running_mean - b)) * scale + beta
@@ -257,8 +266,7 @@ class _LinearBNAct(torch.autograd.Function):
                 out = torch.empty((M, Cout), dtype=torch.float32, device=dev)
                 _lib.call("tp3d_bn_act_f32", _lib.ptr(Y), _lib.ptr(stats[0]), _lib.ptr(stats[2]), _lib.ptr(stats[3]), slope, M, Cout,
                           _lib.ptr(out), st)
-        if training:
-            bn.num_batches_tracked.add_(1)
+        if training:  # (num_batches_tracked was advanced by the statistics kernel)
             if bias is not None:
                 bn.running_mean.add_(bias.detach(), alpha=float(bn.momentum))  # the kernels saw the mean without it
         ctx.save_for_backward(A, W2, Y, stats, arg)
@@ -354,7 +362,6 @@ class _MLPChain(torch.autograd.Function):
                               layers[l - 1][1], _lib.ptr(W2), M, Cout, Kp, _lib.ptr(Y), _lib.ptr(part), st)
                 if training:
                     stats.append(_finalize_stats(part, M, Cout, gamma, beta, bn, dev, st))
-                    bn.num_batches_tracked.add_(1)
                 else:
                     stats.append(_bn_stats(Y, M, Cout, gamma, beta, bn, False, dev, st))
                 Ys.append(Y)
@@ -463,8 +470,6 @@ class _BNAct(torch.autograd.Function):
             else:
                 out = torch.empty((M, C), dtype=torch.float32, device=dev)
                 _lib.call("tp3d_bn_act_f32", _lib.ptr(Y), _lib.ptr(stats[0]), _lib.ptr(stats[2]), _lib.ptr(stats[3]), slope, M, C, _lib.ptr(out), st)
-        if training:
-            bn.num_batches_tracked.add_(1)
         ctx.save_for_backward(Y, stats, arg)
         ctx.cfg = (slope, training, pool_ns)
         return out
