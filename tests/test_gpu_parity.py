@@ -76,6 +76,41 @@ def test_ball_query_dense_bit_exact(hip, oracle, B, N, npnt, r, ns, kind, sort):
     assert torch.equal(gd.cpu(), rd)  # same fp32 evaluation order: exact
 
 
+@pytest.mark.parametrize("case", ["chunk_tail", "one_query", "same_place", "planar", "dense_ball", "zero_radius", "far_apart"])
+def test_ball_query_dense_edge_geometries(hip, oracle, case):
+    """Unsorted dense queries at set-abstraction sizes on the geometries that stress a grid search: a cloud one point past
+    a 1024 boundary, a single centre, coincident centres, a planar cloud, saturated and empty balls, centres far outside
+    the cloud's box."""
+    g = torch.Generator().manual_seed(11)
+    B, N, npnt, r, ns = 2, 5000, 512, 0.2, 64
+    x = torch.rand(B, N, 3, generator=g) * 2 - 1
+    y = x[:, torch.randperm(N, generator=g)[:npnt]].contiguous()
+    if case == "chunk_tail":
+        N = 2049
+        x = x[:, :N].contiguous()
+        y = x[:, -npnt:].contiguous()  # includes the single point of the last chunk
+    elif case == "one_query":
+        y = x[:, 4321:4322].contiguous()
+    elif case == "same_place":  # every centre on the same point: one cell, 512 lists hit by the same support points
+        y = x[:, 7:8].expand(B, npnt, 3).contiguous()
+    elif case == "planar":
+        x[..., 1] = 0.5
+        y = x[:, :npnt].contiguous()
+    elif case == "dense_ball":  # far more hits than slots in the first chunk already
+        x = x * 0.05
+        y = x[:, :npnt].contiguous()
+        ns = 16
+    elif case == "zero_radius":
+        r = 0.0
+    else:  # centres far outside the cloud's box and from each other
+        y = (torch.rand(B, npnt, 3, generator=g) * 2 - 1) * 40
+        y[:, :8] = x[:, :8]
+    gi, gd = hip.ball_query(r, ns, x.to(DEV), y.to(DEV))
+    ri, rd = oracle.ball_query(r, ns, x, y)
+    assert torch.equal(gi.cpu(), ri)
+    assert torch.equal(gd.cpu(), rd)
+
+
 def test_ball_query_dirichlet_kat(hip):
     # reference test/test_losses.py:16-24
     pos = torch.tensor([[[0, 0, 0], [1, 0, 0], [1.1, 0, 0]]], dtype=torch.float, device=DEV)
