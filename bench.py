@@ -136,6 +136,12 @@ def algorithmic_bytes(name, a):
     if name == "tp3d_rows_scatter_bwd_f32":  # B, L, div, nbins, ld, col0, C
         B, L, div, nbins, ld, col0, C = a[:7]
         return B * (L * 8 + (L // div) * C * 4 + nbins * C * 4)
+    if name == "tp3d_rows_scatter_invert":  # B, L, div, nbins: the table in, its inverted form out
+        B, L, div, nbins = a[:4]
+        return B * (L * 8 + L * 4 + (nbins + 1) * 4)
+    if name == "tp3d_rows_scatter_apply_f32":  # B, L, div, nbins, ld, col0, C, with_weights
+        B, L, div, nbins, ld, col0, C = a[:7]
+        return B * (L * 4 + (L // div) * C * 4 + nbins * C * 4)
     if name == "tp3d_bn_stats_f32":  # M, C, training
         M, C = a[:2]
         return M * C * 4
@@ -666,7 +672,7 @@ def main():
     else:
         # sampling / radius searches / 3-NN tables of step i+1 run on a second stream during step i (dp.PipelinedStep)
         net = model.net
-        trainer = PipelinedStep(model, make_opt, lambda slot: net.precompute_geometry(pos),
+        trainer = PipelinedStep(model, make_opt, lambda slot: net.precompute_geometry(pos, backward_tables=True),
                                 lambda geo: seg_loss(model(pos, x, geometry=geo), y),
                                 world_size=world, use_graph=use_graph, log=log, reduce_always=multi)
     log("model built; warm-up")

@@ -35,7 +35,7 @@ extern "C" {
 #define TP3D_E_UNSORTED (-3) /* reserved: batch vector not sorted (checked by the host wrapper) */
 #define TP3D_E_TOOBIG (-4)   /* size exceeds what the kernel's index arithmetic supports */
 
-#define TP3D_ABI_VERSION 23
+#define TP3D_ABI_VERSION 24
 
 int tp3d_abi_version(void);
 const char *tp3d_strerror(int code);
@@ -142,6 +142,13 @@ int tp3d_group_concat_fwd_f32(const float *pos, const float *new_pos, const floa
 int tp3d_rows_scatter_bwd_f32(const float *grad_rows, const int64_t *idx, const float *weight, int B, int L, int div,
                               int nbins, int ld, int col0, int C, float *grad_x_cl, void *workspace,
                               size_t workspace_bytes, void *stream);
+/* The same in two halves: the inverted table depends on idx / weight only (geometry, not features), so it can be built
+ * ahead of the backward pass -- tp3d_rows_scatter_invert fills `workspace` (same size query), tp3d_rows_scatter_apply_f32
+ * consumes a table built for the same (idx, weight, B, L, div, nbins); with_weights = the table was built with weights. */
+int tp3d_rows_scatter_invert(const int64_t *idx, const float *weight, int B, int L, int div, int nbins, void *workspace,
+                             size_t workspace_bytes, void *stream);
+int tp3d_rows_scatter_apply_f32(const float *grad_rows, int B, int L, int div, int nbins, int ld, int col0, int C,
+                                int with_weights, float *grad_x_cl, void *table, size_t table_bytes, void *stream);
 
 /* BatchNorm statistics of Y (M, C): mean, invstd, scale = gamma*invstd and shift = beta; the normalised value is
  * always formed as (y - mean)*scale + shift (a folded shift beta - mean*scale would cancel against y*scale in fp32

@@ -238,7 +238,8 @@ def test_pipelined_step_same_trajectory_as_sharded_step():
     a, b = make(), make()
     ta = ShardedStep(a, lambda ps: torch.optim.SGD(ps, lr=0.05), lambda: F.cross_entropy(a(Data(pos=pos, x=x)).x, y),
                      world_size=1, use_graph=False)
-    tb = PipelinedStep(b, lambda ps: torch.optim.SGD(ps, lr=0.05), lambda slot: b.precompute_geometry(pos),
+    tb = PipelinedStep(b, lambda ps: torch.optim.SGD(ps, lr=0.05),
+                       lambda slot: b.precompute_geometry(pos, backward_tables=True),  # inverted tables built ahead as well
                        lambda geo_: F.cross_entropy(b(Data(pos=pos, x=x), geometry=geo_).x, y), world_size=1, use_graph=True)
     assert tb.warmup_and_capture(2)
     for _ in range(2 + 2):  # the eager warm-up steps of the pipelined stepper (2) and its side-stream warm-up (2 passes)
@@ -297,6 +298,37 @@ def test_gemm_rows_matches_fp64_and_stats(M, N, K):
     Bi = torch.randint(-3, 4, (K, N), generator=g).float().to(DEV)
     Ci, _ = fused.gemm_rows(Ai, Bi.t().contiguous())
     assert torch.equal(Ci, torch.mm(Ai.double(), Bi.double()).float())
+
+
+def test_scatter_tables_built_ahead_give_the_same_gradients():
+    """group_concat / interp_concat with a table from fused.scatter_table (inverted before the pass, as the geometry
+    prefetch does) against the same ops inverting inside their backward: bit-identical gradients."""
+    from torch_points3d_amd import fused
+    g = torch.Generator().manual_seed(5)
+    B, N, npnt, ns, C = 3, 700, 128, 32, 20
+    pos = torch.rand(B, N, 3, generator=g).to(DEV)
+    new_pos = pos[:, :npnt].contiguous()
+    idx = torch.randint(0, N, (B, npnt, ns), generator=g).to(DEV)
+    x = torch.randn(B, N, C, generator=g).to(DEV)
+    grads = []
+    for table in (None, fused.scatter_table(idx, None, N, 1)):
+        xr = x.clone().requires_grad_(True)
+        rows = fused.group_concat(pos, new_pos, xr, idx, 0.3, True, table)
+        rows.backward(torch.ones_like(rows) * torch.arange(rows.shape[1], device=DEV))
+        grads.append(xr.grad)
+    assert torch.equal(grads[0], grads[1])
+    n, m, C1, C2 = 900, 128, 24, 10
+    idx3 = torch.randint(0, m, (B, n, 3), generator=g).to(DEV)
+    w3 = torch.rand(B, n, 3, generator=g).to(DEV)
+    feat = torch.randn(B, m, C1, generator=g).to(DEV)
+    skip = torch.randn(B, n, C2, generator=g).to(DEV)
+    grads = []
+    for table in (None, fused.scatter_table(idx3, w3, m, 3)):
+        fr, sr = feat.clone().requires_grad_(True), skip.clone().requires_grad_(True)
+        rows = fused.interp_concat(fr, idx3, w3, sr, table)
+        rows.backward(torch.cos(torch.arange(rows.numel(), device=DEV, dtype=torch.float32)).view_as(rows))
+        grads.append((fr.grad, sr.grad))
+    assert torch.equal(grads[0][0], grads[1][0]) and torch.equal(grads[0][1], grads[1][1])
 
 
 @pytest.mark.parametrize("M,N,offset", [(262144, 128, 0.0), (300000, 64, 40.0), (5000, 256, 0.0), (140000, 132, 3.0)])

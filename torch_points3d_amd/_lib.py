@@ -28,6 +28,8 @@ SIGNATURES = {
     "tp3d_group_bwd_f32": [_p, _p, _i, _i, _i, _i, _i, _p, _p, ctypes.c_size_t, _p],
     "tp3d_group_concat_fwd_f32": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _f, _i, _p, _p],
     "tp3d_rows_scatter_bwd_f32": [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p, _p, ctypes.c_size_t, _p],
+    "tp3d_rows_scatter_invert": [_p, _p, _i, _i, _i, _i, _p, ctypes.c_size_t, _p],
+    "tp3d_rows_scatter_apply_f32": [_p, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p, ctypes.c_size_t, _p],
     "tp3d_bn_stats_f32": [_p, _l, _i, _f, _f, _p, _p, _p, _p, _p, _i, _p, _p, _p, _p, _p, _p],
     "tp3d_bn_act_f32": [_p, _p, _p, _p, _f, _l, _i, _p, _p],
     "tp3d_bn_act_maxpool_f32": [_p, _p, _p, _p, _f, _l, _i, _i, _p, _p, _p],
@@ -68,7 +70,7 @@ SIGNATURES = {
 MISC = ("tp3d_abi_version", "tp3d_strerror", "tp3d_last_hip_error", "tp3d_scatter_workspace_bytes",
         "tp3d_bn_workspace_floats", "tp3d_gemm_tn_workspace_floats", "tp3d_ball_query_workspace_bytes",
         "tp3d_gemm_rows_stat_floats", "tp3d_gemm_rows_stat_chunks", "tp3d_gemm_rows_workspace_floats", "tp3d_kpconv_bwd_workspace_bytes", "tp3d_voxel_workspace_bytes", "tp3d_knn_workspace_bytes", "tp3d_kpconv_grad_workspace_bytes")
-ABI_VERSION = 23
+ABI_VERSION = 24
 
 _handle = None
 

@@ -875,9 +875,37 @@ TP3D_EXPORT int tp3d_scatter_plan(int B, int L, int nbins, int with_weights, int
     return TP3D_OK;
 }
 
-TP3D_EXPORT int tp3d_rows_scatter_bwd_f32(const float *grad_rows, const int64_t *idx, const float *weight, int B,
-                                          int L, int div, int nbins, int ld, int col0, int C, float *grad_x_cl,
-                                          void *workspace, size_t workspace_bytes, void *stream)
+// The inverted neighbour table ("which slots point at support point k") depends on idx / weight only -- geometry, not
+// features: tp3d_rows_scatter_invert builds it into `workspace`, tp3d_rows_scatter_apply_f32 consumes a table built
+// earlier for the same (idx, weight, B, L, div, nbins) -- e.g. one step ahead on another stream, beside the sampling
+// and the searches -- and tp3d_rows_scatter_bwd_f32 does both.
+TP3D_EXPORT int tp3d_rows_scatter_invert(const int64_t *idx, const float *weight, int B, int L, int div, int nbins,
+                                         void *workspace, size_t workspace_bytes, void *stream)
+{
+    if (B < 0 || L < 0 || div <= 0 || nbins <= 0) return TP3D_E_BADARG;
+    if (B == 0 || L == 0) return TP3D_OK;
+    if (!idx || !workspace || B > 65535) return TP3D_E_BADARG;
+    hipStream_t s = (hipStream_t)stream;
+    ScatterWorkspace w = carve_scatter_workspace(workspace, B, L, nbins, weight != nullptr);
+    if (workspace_bytes < w.bytes) return TP3D_E_BADARG;
+    // One large cloud (partial-dense decoders), or clouds whose tables do not fit one workgroup's LDS (multi-scale
+    // grouping: 512 x 128 slots per cloud): invert ONE flat table over the whole device instead of one table per
+    // workgroup (scratch holds the histogram and the cursors), then turn slot ids into row ids and line the weights up.
+    // (measured on the 49 152-slot decoder tables, which fit LDS: flat 523 us vs per-cloud 354 us, so off by default)
+    if (scatter_goes_flat(B, L, nbins)) {
+        const int64_t slots = (int64_t)B * L, bins = (int64_t)B * nbins;
+        if (int rc = invert_table(idx, slots, bins, w.scratch, w.start, w.scratch + bins, w.order, s, L, nbins, w.merge_tmp))
+            return rc;
+        hipLaunchKernelGGL(slots_to_rows_kernel, dim3((unsigned)((slots + 255) / 256)), dim3(256), 0, s, w.order, weight, div,
+                           (int)slots, w.start, (int)bins, w.wsorted);
+        return check_launch();
+    }
+    return csr_transpose(idx, B, L, nbins, div, weight, w.start, w.order, w.wsorted, w.scratch, s);
+}
+
+TP3D_EXPORT int tp3d_rows_scatter_apply_f32(const float *grad_rows, int B, int L, int div, int nbins, int ld, int col0,
+                                            int C, int with_weights, float *grad_x_cl, void *table, size_t table_bytes,
+                                            void *stream)
 {
     // grad_rows: (B, L/div rows, ld); slot l of cloud b refers to row l/div; destinations: (B, nbins, C)
     if (B < 0 || L < 0 || div <= 0 || nbins <= 0 || ld <= 0 || col0 < 0 || C < 0 || col0 + C > ld) return TP3D_E_BADARG;
@@ -885,23 +913,10 @@ TP3D_EXPORT int tp3d_rows_scatter_bwd_f32(const float *grad_rows, const int64_t 
     if (!grad_x_cl) return TP3D_E_BADARG;
     hipStream_t s = (hipStream_t)stream;
     if (L == 0) return zero_async(grad_x_cl, (size_t)B * nbins * C * sizeof(float), s);
-    if (!grad_rows || !idx || !workspace || B > 65535) return TP3D_E_BADARG;
-    ScatterWorkspace w = carve_scatter_workspace(workspace, B, L, nbins, weight != nullptr);
-    if (workspace_bytes < w.bytes) return TP3D_E_BADARG;
-    // One large cloud (partial-dense decoders), or clouds whose tables do not fit one workgroup's LDS (multi-scale
-    // grouping: 512 x 128 slots per cloud): invert ONE flat table over the whole device instead of one table per
-    // workgroup (scratch holds the histogram and the cursors), then turn slot ids into row ids and line the weights up.
-    // (measured on the 49 152-slot decoder tables, which fit LDS: flat 523 us vs per-cloud 354 us, so off by default)
+    if (!grad_rows || !table || B > 65535) return TP3D_E_BADARG;
+    ScatterWorkspace w = carve_scatter_workspace(table, B, L, nbins, with_weights != 0);
+    if (table_bytes < w.bytes) return TP3D_E_BADARG;
     const bool flat = scatter_goes_flat(B, L, nbins);
-    if (flat) {
-        const int64_t slots = (int64_t)B * L, bins = (int64_t)B * nbins;
-        if (int rc = invert_table(idx, slots, bins, w.scratch, w.start, w.scratch + bins, w.order, s, L, nbins, w.merge_tmp))
-            return rc;
-        hipLaunchKernelGGL(slots_to_rows_kernel, dim3((unsigned)((slots + 255) / 256)), dim3(256), 0, s, w.order, weight, div,
-                           (int)slots, w.start, (int)bins, w.wsorted);
-    } else if (int rc = csr_transpose(idx, B, L, nbins, div, weight, w.start, w.order, w.wsorted, w.scratch, s)) {
-        return rc;
-    }
     dim3 grid((nbins + RW_BLOCK / 64 - 1) / (RW_BLOCK / 64), B);
     if (C > 128)
         hipLaunchKernelGGL(rows_gather_sum_kernel<4>, grid, dim3(RW_BLOCK), 0, s, grad_rows, w.start, w.order, w.wsorted,
@@ -913,6 +928,20 @@ TP3D_EXPORT int tp3d_rows_scatter_bwd_f32(const float *grad_rows, const int64_t 
         hipLaunchKernelGGL(rows_gather_sum_kernel<1>, grid, dim3(RW_BLOCK), 0, s, grad_rows, w.start, w.order, w.wsorted,
                            nbins, L, L / div, ld, col0, C, grad_x_cl, flat ? 1 : 0);
     return check_launch();
+}
+
+TP3D_EXPORT int tp3d_rows_scatter_bwd_f32(const float *grad_rows, const int64_t *idx, const float *weight, int B,
+                                          int L, int div, int nbins, int ld, int col0, int C, float *grad_x_cl,
+                                          void *workspace, size_t workspace_bytes, void *stream)
+{
+    if (B < 0 || L < 0 || div <= 0 || nbins <= 0 || ld <= 0 || col0 < 0 || C < 0 || col0 + C > ld) return TP3D_E_BADARG;
+    if (B == 0 || C == 0) return TP3D_OK;
+    if (!grad_x_cl) return TP3D_E_BADARG;
+    if (L == 0) return zero_async(grad_x_cl, (size_t)B * nbins * C * sizeof(float), (hipStream_t)stream);
+    if (!grad_rows || !idx || !workspace || B > 65535) return TP3D_E_BADARG;
+    if (int rc = tp3d_rows_scatter_invert(idx, weight, B, L, div, nbins, workspace, workspace_bytes, stream)) return rc;
+    return tp3d_rows_scatter_apply_f32(grad_rows, B, L, div, nbins, ld, col0, C, weight != nullptr, grad_x_cl, workspace,
+                                       workspace_bytes, stream);
 }
 
 TP3D_EXPORT size_t tp3d_bn_workspace_floats(int64_t M, int C)

@@ -164,14 +164,19 @@ class BaseDenseConvolutionDown(nn.Module):
     def conv(self, x, pos, new_pos, radius_idx, scale_idx):
         raise NotImplementedError
 
-    def precompute(self, pos):
+    def precompute(self, pos, backward_tables=False):
         """The geometry of this level for the cloud `pos` (B,N,3): everything forward() derives from positions alone --
-        sampled indices, sampled positions, one neighbour table per scale.  Pass the result as forward(precomputed=)."""
+        sampled indices, sampled positions, one neighbour table per scale.  Pass the result as forward(precomputed=).
+        backward_tables: also the inverted form of every neighbour table, which the backward pass of the fused grouping
+        gathers through (fused.scatter_table) -- geometry as well, so it can leave the training pass with the rest."""
         with torch.no_grad():
             idx = self.sampler(pos).long()
             new_pos = pos.gather(1, idx.unsqueeze(-1).repeat(1, 1, pos.shape[-1]))
             tables = [self.neighbour_finder(pos, new_pos, scale_idx=s) for s in range(self.neighbour_finder.num_scales)]
-        return Data(idx=idx, new_pos=new_pos, radius_idx=tables)
+            inverse = [None] * len(tables)
+            if backward_tables and pos.is_cuda and getattr(self, "fused", False):
+                inverse = [_fused.scatter_table(t, None, pos.shape[1], 1) for t in tables]
+        return Data(idx=idx, new_pos=new_pos, radius_idx=tables, radius_inv=inverse)
 
     def forward(self, data, sample_idx=None, precomputed=None, **kwargs):
         x, pos = data.x, data.pos
@@ -186,7 +191,8 @@ class BaseDenseConvolutionDown(nn.Module):
         for scale_idx in range(self.neighbour_finder.num_scales):
             radius_idx = (precomputed.radius_idx[scale_idx] if precomputed is not None
                           else self.neighbour_finder(pos, new_pos, scale_idx=scale_idx))
-            ms_x.append(self.conv(x, pos, new_pos, radius_idx, scale_idx))
+            table = None if precomputed is None else getattr(precomputed, "radius_inv", [None] * (scale_idx + 1))[scale_idx]
+            ms_x.append(self.conv(x, pos, new_pos, radius_idx, scale_idx, **({} if table is None else {"table": table})))
         if all(_is_channel_last(t) for t in ms_x):
             # fused path: scales are (B, C_i, np) VIEWS of channel-last storage; concatenate the storage itself
             new_x = ms_x[0] if len(ms_x) == 1 else torch.cat([t.transpose(1, 2) for t in ms_x], 2).transpose(1, 2)
@@ -228,7 +234,7 @@ class PointNetMSGDown(BaseDenseConvolutionDown):
             return torch.cat([grouped_pos, grouped_features], dim=1)  # (B,3+C,np,ns), xyz first
         return grouped_features
 
-    def _conv_fused(self, parts, x, pos, new_pos, radius_idx, scale_idx):
+    def _conv_fused(self, parts, x, pos, new_pos, radius_idx, scale_idx, table=None):
         """Same arithmetic on (rows, C) activations: HIP gather/BN/act/pool kernels around library GEMMs."""
         B, npnt, ns = radius_idx.shape
         x_cl = None
@@ -236,16 +242,16 @@ class PointNetMSGDown(BaseDenseConvolutionDown):
             x_cl = _fused._cl(x)
         elif x is not None:
             return None  # use_xyz=False never occurs in the bundled configs: keep it on the reference graph
-        rows = _fused.group_concat(pos, new_pos, x_cl, radius_idx, self.radii[scale_idx], self.normalize_xyz)
+        rows = _fused.group_concat(pos, new_pos, x_cl, radius_idx, self.radii[scale_idx], self.normalize_xyz, table)
         pooled = _fused.run_mlp(rows, parts, pool_ns=ns)  # (B*np, Cout)
         return pooled.view(B, npnt, -1).transpose(1, 2)  # (B, Cout, np) view of channel-last storage
 
-    def conv(self, x, pos, new_pos, radius_idx, scale_idx):
+    def conv(self, x, pos, new_pos, radius_idx, scale_idx, table=None):
         assert scale_idx < len(self.mlps)
         if self.fused and _use_fused(self._tp, x, pos):
             parts = _fused.mlp_parts(self.mlps[scale_idx])
             if parts is not None:
-                out = self._conv_fused(parts, x, pos, new_pos, radius_idx, scale_idx)
+                out = self._conv_fused(parts, x, pos, new_pos, radius_idx, scale_idx, table)
                 if out is not None:
                     return out
         feats = self._prepare_features(x, pos, new_pos, radius_idx, scale_idx)
@@ -287,19 +293,22 @@ class DenseFPModule(BaseDenseConvolutionUp):
         self.fused = fused
         self.nn = MLP2D(up_conv_nn, bn=bn, activation=activation, bias=False)
 
-    def precompute(self, pos, pos_skip):
+    def precompute(self, pos, pos_skip, backward_tables=False):
         """3-NN interpolation table of this stage: (idx (B,n,3), inverse-distance weights (B,n,3)); None below the
-        global module (pos is None there)."""
+        global module (pos is None there).  backward_tables: also its inverted form (fused.scatter_table)."""
         if pos is None:
             return None
         with torch.no_grad():
             dist, idx = self._tp.three_nn(pos_skip, pos)
+            table = None
             if self._tp is _hip_kernels and dist.is_cuda:
                 weight = _fused.idw_weights(dist)
+                if backward_tables and self.fused:
+                    table = _fused.scatter_table(idx, weight, pos.shape[1], 3)
             else:
                 dist_recip = 1.0 / (dist + 1e-8)
                 weight = dist_recip / torch.sum(dist_recip, dim=2, keepdim=True)
-        return Data(idx=idx, weight=weight)
+        return Data(idx=idx, weight=weight, table=table)
 
     def _forward_fused(self, data, data_skip, precomputed=None):
         """interpolate + skip concat + MLP on (rows, C): HIP kernels around library GEMMs; None -> reference graph."""
@@ -315,7 +324,8 @@ class DenseFPModule(BaseDenseConvolutionUp):
             rows = x.transpose(1, 2).expand(B, n, x.shape[1])
             rows = _fused.cat_rows([rows] + ([skip_cl] if skip_cl is not None else []))
         elif precomputed is not None:
-            rows = _fused.interp_concat(_fused._cl(x), precomputed.idx, precomputed.weight, skip_cl)
+            rows = _fused.interp_concat(_fused._cl(x), precomputed.idx, precomputed.weight, skip_cl,
+                                        getattr(precomputed, "table", None))
         else:
             dist, idx = self._tp.three_nn(pos_skip, pos)
             rows = _fused.interp_concat(_fused._cl(x), idx, _fused.idw_weights(dist), skip_cl)

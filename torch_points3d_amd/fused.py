@@ -601,11 +601,29 @@ def run_mlp(rows, parts, pool_ns=0):
     return rows
 
 
+def scatter_table(idx, weight, nbins, div):
+    """The inverted form of a neighbour table idx (B, rows, slots) over `nbins` support points (with the interpolation
+    weights lined up, if given): what the backward pass of group_concat / interp_concat gathers through.  It depends on
+    the geometry only, so a stepper that computes the geometry ahead of the training pass (dp.PipelinedStep) builds it
+    there as well; pass it as `table=` and the backward pass skips the inversion."""
+    dev = idx.device
+    B = idx.shape[0]
+    L = idx[0].numel()
+    nbytes = _lib.load().tp3d_scatter_workspace_bytes(B, L, nbins, int(weight is not None))
+    buf = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    idx = idx.contiguous()
+    w = None if weight is None else weight.contiguous()
+    with _lib.on_device(dev):
+        _lib.call("tp3d_rows_scatter_invert", _lib.ptr(idx), _lib.ptr(w), B, L, div, nbins, _lib.ptr(buf), nbytes,
+                  _lib.stream_ptr(dev))
+    return buf
+
+
 class _GroupConcat(torch.autograd.Function):
     """rows[(b,j,s)] = [pos[b,idx]-new_pos[b,j] (/r), x_cl[b,idx], 0-pad to 4k columns]; differentiable wrt x_cl."""
 
     @staticmethod
-    def forward(ctx, pos, new_pos, x_cl, idx, radius, normalize):
+    def forward(ctx, pos, new_pos, x_cl, idx, radius, normalize, table=None):
         dev = pos.device
         B, N, _ = pos.shape
         _, npnt, ns = idx.shape
@@ -617,36 +635,40 @@ class _GroupConcat(torch.autograd.Function):
         with _lib.on_device(dev):
             _lib.call("tp3d_group_concat_fwd_f32", _lib.ptr(pos), _lib.ptr(new_pos), _lib.ptr(xc), _lib.ptr(idx), B, N,
                       npnt, ns, C, ld, float(radius), int(bool(normalize)), _lib.ptr(out), _lib.stream_ptr(dev))
-        ctx.save_for_backward(idx)
+        ctx.save_for_backward(idx, table)
         ctx.dims = (B, N, npnt, ns, C, ld)
         return out
 
     @staticmethod
     def backward(ctx, grad_rows):
-        (idx,) = ctx.saved_tensors
+        idx, table = ctx.saved_tensors
         B, N, npnt, ns, C, ld = ctx.dims
         if C == 0 or not ctx.needs_input_grad[2]:
-            return None, None, None, None, None, None
+            return None, None, None, None, None, None, None
         dev = grad_rows.device
         grad_rows = grad_rows.contiguous()
         g = torch.empty((B, N, C), dtype=torch.float32, device=dev)
         L = npnt * ns
-        ws, ws_bytes = _lib.scatter_workspace(B, L, N, False, dev)
         with _lib.on_device(dev):
-            _lib.call("tp3d_rows_scatter_bwd_f32", _lib.ptr(grad_rows), _lib.ptr(idx), None, B, L, 1, N, ld, 3, C,
-                      _lib.ptr(g), _lib.ptr(ws), ws_bytes, _lib.stream_ptr(dev))
-        return None, None, g, None, None, None
+            if table is not None:  # inverted ahead of the pass (scatter_table)
+                _lib.call("tp3d_rows_scatter_apply_f32", _lib.ptr(grad_rows), B, L, 1, N, ld, 3, C, 0, _lib.ptr(g),
+                          _lib.ptr(table), table.numel(), _lib.stream_ptr(dev))
+            else:
+                ws, ws_bytes = _lib.scatter_workspace(B, L, N, False, dev)
+                _lib.call("tp3d_rows_scatter_bwd_f32", _lib.ptr(grad_rows), _lib.ptr(idx), None, B, L, 1, N, ld, 3, C,
+                          _lib.ptr(g), _lib.ptr(ws), ws_bytes, _lib.stream_ptr(dev))
+        return None, None, g, None, None, None, None
 
 
-def group_concat(pos, new_pos, x_cl, idx, radius, normalize):
-    return _GroupConcat.apply(pos, new_pos, x_cl, idx, radius, normalize)
+def group_concat(pos, new_pos, x_cl, idx, radius, normalize, table=None):
+    return _GroupConcat.apply(pos, new_pos, x_cl, idx, radius, normalize, table)
 
 
 class _InterpConcat(torch.autograd.Function):
     """rows[(b,i)] = [sum_t w_t * feat_cl[b, idx_t], skip_cl[b,i]]; differentiable wrt feat_cl and skip_cl."""
 
     @staticmethod
-    def forward(ctx, feat_cl, idx, weight, skip_cl):
+    def forward(ctx, feat_cl, idx, weight, skip_cl, table=None):
         dev = feat_cl.device
         B, m, C1 = feat_cl.shape
         n = idx.shape[1]
@@ -658,31 +680,35 @@ class _InterpConcat(torch.autograd.Function):
         with _lib.on_device(dev):
             _lib.call("tp3d_interp_concat_fwd_f32", _lib.ptr(feat_cl), _lib.ptr(idx), _lib.ptr(weight), _lib.ptr(sk), B,
                       m, n, C1, C2, ld, _lib.ptr(out), _lib.stream_ptr(dev))
-        ctx.save_for_backward(idx, weight)
+        ctx.save_for_backward(idx, weight, table)
         ctx.dims = (B, m, n, C1, C2, ld)
         return out
 
     @staticmethod
     def backward(ctx, grad_rows):
-        idx, weight = ctx.saved_tensors
+        idx, weight, table = ctx.saved_tensors
         B, m, n, C1, C2, ld = ctx.dims
         dev = grad_rows.device
         grad_rows = grad_rows.contiguous()
         g_feat = None
         if ctx.needs_input_grad[0]:
             g_feat = torch.empty((B, m, C1), dtype=torch.float32, device=dev)
-            ws, ws_bytes = _lib.scatter_workspace(B, 3 * n, m, True, dev)
             with _lib.on_device(dev):
-                _lib.call("tp3d_rows_scatter_bwd_f32", _lib.ptr(grad_rows), _lib.ptr(idx), _lib.ptr(weight), B, 3 * n,
-                          3, m, ld, 0, C1, _lib.ptr(g_feat), _lib.ptr(ws), ws_bytes, _lib.stream_ptr(dev))
+                if table is not None:  # inverted ahead of the pass (scatter_table)
+                    _lib.call("tp3d_rows_scatter_apply_f32", _lib.ptr(grad_rows), B, 3 * n, 3, m, ld, 0, C1, 1,
+                              _lib.ptr(g_feat), _lib.ptr(table), table.numel(), _lib.stream_ptr(dev))
+                else:
+                    ws, ws_bytes = _lib.scatter_workspace(B, 3 * n, m, True, dev)
+                    _lib.call("tp3d_rows_scatter_bwd_f32", _lib.ptr(grad_rows), _lib.ptr(idx), _lib.ptr(weight), B, 3 * n,
+                              3, m, ld, 0, C1, _lib.ptr(g_feat), _lib.ptr(ws), ws_bytes, _lib.stream_ptr(dev))
         g_skip = None
         if C2 and ctx.needs_input_grad[3]:
             g_skip = grad_rows.view(B, n, ld)[:, :, C1:C1 + C2]
-        return g_feat, None, None, g_skip
+        return g_feat, None, None, g_skip, None
 
 
-def interp_concat(feat_cl, idx, weight, skip_cl):
-    return _InterpConcat.apply(feat_cl, idx, weight, skip_cl)
+def interp_concat(feat_cl, idx, weight, skip_cl, table=None):
+    return _InterpConcat.apply(feat_cl, idx, weight, skip_cl, table)
 
 
 def cat_rows(parts):

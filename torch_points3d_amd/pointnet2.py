@@ -77,23 +77,25 @@ class PointNet2Unet(nn.Module):
     def output_nc(self):
         return self._output_nc
 
-    def precompute_geometry(self, pos):
+    def precompute_geometry(self, pos, backward_tables=False):
         """Everything the forward pass derives from the positions alone -- per set-abstraction level the sampled indices
         / positions / neighbour tables, per feature-propagation stage the 3-NN interpolation table -- computed once for
         `pos` (B,N,3).  Pass it as forward(data, geometry=): the pass then contains no sampling and no search, so the
         geometry of the NEXT batch can be computed on a second stream while this batch trains (dp.PipelinedStep), the
         dense-format counterpart of the reference's MultiScaleTransform precompute
-        (core/data_transform/transforms.py:579-654)."""
+        (core/data_transform/transforms.py:579-654).  backward_tables: for a training pass -- also the inverted neighbour
+        and interpolation tables its backward pass gathers through (not for the first level, whose input features are
+        the data and take no gradient)."""
         levels, cur, positions = [], pos, [pos]
-        for down in self.down_modules:
-            g = down.precompute(cur)
+        for i, down in enumerate(self.down_modules):
+            g = down.precompute(cur, backward_tables=backward_tables and i > 0)
             levels.append(g)
             cur = g.new_pos
             positions.append(cur)
         ups, below = [], None  # `below` = position set of the stage's input (None under the global module)
         for up in self.up_modules:
             skip_pos = positions.pop()
-            ups.append(up.precompute(below, skip_pos))
+            ups.append(up.precompute(below, skip_pos, backward_tables=backward_tables))
             below = skip_pos
         return Data(down=levels, up=ups)
 
@@ -247,19 +249,19 @@ class PointNet2_D(nn.Module):
         last = layers[-1][0]
         return torch.addmm(last.bias, rows, last.weight.reshape(self._num_classes, -1).t())
 
-    def precompute_geometry(self, pos):
+    def precompute_geometry(self, pos, backward_tables=False):
         """as PointNet2Unet.precompute_geometry: sampling, neighbour tables and interpolation tables of `pos` (B,N,3)"""
         downs, _, ups = self.stages()
         levels, cur, positions = [], pos, [pos]
-        for down in downs:
-            g = down.precompute(cur)
+        for i, down in enumerate(downs):
+            g = down.precompute(cur, backward_tables=backward_tables and i > 0)
             levels.append(g)
             cur = g.new_pos
             positions.append(cur)
         tables, below = [], None
         for up in ups:
             skip_pos = positions.pop()
-            tables.append(up.precompute(below, skip_pos))
+            tables.append(up.precompute(below, skip_pos, backward_tables=backward_tables))
             below = skip_pos
         return Data(down=levels, up=tables)
 
