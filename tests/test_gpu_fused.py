@@ -300,6 +300,30 @@ def test_gemm_rows_matches_fp64_and_stats(M, N, K):
     assert torch.equal(Ci, torch.mm(Ai.double(), Bi.double()).float())
 
 
+@pytest.mark.parametrize("G,ns,C", [(700, 128, 128), (64, 32, 64), (33, 8, 1024), (5, 64, 2052), (300, 16, 100), (40, 7, 128),
+                                    (90, 64, 7), (2048, 128, 128)])
+def test_bn_act_maxpool_is_the_first_maximum_of_every_group(G, ns, C):
+    """tp3d_bn_act_maxpool_f32 against the plain formulas, exactly: value and arg-max row, on data with many exact ties
+    inside a group (max_pool2d's first-maximum rule) and negative scales."""
+    from torch_points3d_amd import _lib
+    g = torch.Generator().manual_seed(G + ns + C)
+    Y = torch.randint(-3, 4, (G * ns, C), generator=g).float().to(DEV)  # small integers: ties everywhere
+    mean = torch.randint(-1, 2, (C,), generator=g).float().to(DEV)
+    scale = (torch.randint(0, 2, (C,), generator=g).float() * 2 - 1).to(DEV) * 0.5
+    shift = torch.randint(-1, 2, (C,), generator=g).float().to(DEV) * 0.25
+    slope = 0.25
+    out = torch.empty(G, C, device=DEV)
+    arg = torch.empty(G, C, dtype=torch.int32, device=DEV)
+    _lib.call("tp3d_bn_act_maxpool_f32", Y.data_ptr(), mean.data_ptr(), scale.data_ptr(), shift.data_ptr(), slope, G, ns, C,
+              out.data_ptr(), arg.data_ptr(), _lib.stream_ptr(Y.device))
+    z = (Y - mean) * scale + shift
+    a = torch.where(z > 0, z, z * slope).view(G, ns, C)
+    want = a.max(dim=1).values
+    first = (a == want.unsqueeze(1)).float().argmax(dim=1)  # the first row holding the maximum
+    assert torch.equal(out, want)
+    assert torch.equal(arg.long(), first)
+
+
 def test_scatter_tables_built_ahead_give_the_same_gradients():
     """group_concat / interp_concat with a table from fused.scatter_table (inverted before the pass, as the geometry
     prefetch does) against the same ops inverting inside their backward: bit-identical gradients."""

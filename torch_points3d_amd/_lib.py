@@ -133,8 +133,9 @@ def load():
 class KernelTimer(object):
     """Optional per-entry-point device timing with HIP events on the launch stream (bench.py's roofline leg).
 
-    Events are recorded on torch's current stream, which is the stream every launch is enqueued on, so the
-    elapsed time brackets exactly the kernels (and memsets) one C-ABI call enqueues.
+    Events are recorded on torch's current stream, which is the stream every launch is enqueued on, with the stream
+    drained in front of every bracket, so the elapsed time covers exactly the kernels (and memsets) one C-ABI call
+    enqueues plus one launch latency.
     """
 
     def __init__(self):
@@ -179,6 +180,10 @@ def call(name, *args):
     if _timer is not None:
         a = torch.cuda.Event(enable_timing=True)
         b = torch.cuda.Event(enable_timing=True)
+        # The stream is drained first: hipEventElapsedTime counts from the moment the START marker began to wait in the
+        # queue, not from the end of the work in front of it, so a bracket recorded while earlier kernels are still
+        # running also covers what is left of them (seen as a 5 us statistics kernel "taking" 0.2 ms behind a GEMM).
+        torch.cuda.current_stream().synchronize()
         a.record()
         rc = fn(*args)
         b.record()
