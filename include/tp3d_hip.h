@@ -379,8 +379,8 @@ int tp3d_gemm_rows_plan(int64_t M, int N, int K, int64_t *plan);
 /* plan[3]: rows per chunk, chunks, workspace floats written by tp3d_bn_stats_f32 (pooled_ns = 0) or
  * tp3d_bn_act_bwd_f32 (pooled_ns = its ns; 1 for the dense form) */
 int tp3d_bn_plan(int64_t M, int C, int pooled_ns, int64_t *plan);
-/* plan[8]: byte offsets of start, order, scratch, wsorted (-1 = none), merge_tmp; workspace bytes; 1 = table
- * inverted flat over the batch; ints of scratch that path needs */
+/* plan[9]: byte offsets of start, order, scratch, wsorted (-1 = none), merge_tmp; workspace bytes; 1 = table
+ * inverted flat over the batch; ints of scratch that path needs; byte offset of the hub list (1 + B*nbins ints) */
 int tp3d_scatter_plan(int B, int L, int nbins, int with_weights, int64_t *plan);
 
 #ifdef __cplusplus

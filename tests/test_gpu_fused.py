@@ -355,6 +355,39 @@ def test_scatter_tables_built_ahead_give_the_same_gradients():
     assert torch.equal(grads[0][0], grads[1][0]) and torch.equal(grads[0][1], grads[1][1])
 
 
+@pytest.mark.parametrize("C", [20, 100, 320])
+def test_scatter_backward_with_hub_points(C):
+    """Neighbour tables in which a few support points collect hundreds or thousands of slots (the first hit of a padded
+    ball query does): runs of more than 128 slots are summed by a whole workgroup in 16 pieces.  Against an fp64
+    index_add, and identical from call to call."""
+    from torch_points3d_amd import fused
+    g = torch.Generator().manual_seed(C)
+    B, N, npnt, ns = 3, 600, 128, 64
+    idx = torch.randint(0, N, (B, npnt, ns), generator=g)
+    idx[:, :, 40:] = idx[:, :, :1]                      # padding with the first hit
+    idx[0, :100] = 7                                    # one point holding 6400 slots
+    idx[1, :, :] = torch.randint(0, 3, (npnt, ns), generator=g)  # every slot on three points
+    idx = idx.to(DEV)
+    pos = torch.rand(B, N, 3, generator=g).to(DEV)
+    new_pos = pos[:, :npnt].contiguous()
+    x = torch.randn(B, N, C, generator=g).to(DEV)
+    cot = None
+    outs = []
+    for table in (None, fused.scatter_table(idx, None, N, 1), None):
+        xr = x.clone().requires_grad_(True)
+        rows = fused.group_concat(pos, new_pos, xr, idx, 0.3, False, table)
+        if cot is None:
+            cot = torch.randn(rows.shape, generator=g).to(DEV)
+        rows.backward(cot)
+        outs.append(xr.grad)
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    want = torch.zeros(B, N, C, dtype=torch.float64, device=DEV)
+    gr = cot.view(B, npnt * ns, -1)[:, :, 3:3 + C].double()
+    for b in range(B):
+        want[b].index_add_(0, idx[b].reshape(-1), gr[b])
+    torch.testing.assert_close(outs[0].double(), want, rtol=1e-5, atol=1e-4)
+
+
 @pytest.mark.parametrize("M,N,offset", [(262144, 128, 0.0), (300000, 64, 40.0), (5000, 256, 0.0), (140000, 132, 3.0)])
 def test_bn_finalize_from_gemm_partials(M, N, offset):
     """tp3d_bn_finalize_f32 on the partial sums a rows GEMM leaves: few chunks are folded by one workgroup per channel,

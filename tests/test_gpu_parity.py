@@ -289,7 +289,13 @@ def test_grouping_bwd_giant_bins(hip, oracle, npnt, ns, N):
     cot_rows = torch.zeros_like(rows)
     cot_rows[:, 3:3 + C] = cot.permute(0, 2, 3, 1).reshape(-1, C).to(DEV)
     rows.backward(cot_rows)
-    assert torch.equal(xa.grad.transpose(1, 2).cpu(), fb.grad)
+    # runs of more than 128 slots are summed there by a whole workgroup in 16 pieces (one wave walking thousands of rows
+    # held the launch): a fixed association, reproducible, but not the oracle's sequential one -- so close, not equal
+    ga = xa.grad.transpose(1, 2).cpu()
+    torch.testing.assert_close(ga, fb.grad, rtol=1e-5, atol=1e-5 * float(fb.grad.abs().max()))
+    xb = feat.transpose(1, 2).contiguous().to(DEV).requires_grad_(True)
+    fused.group_concat(pos, new_pos, xb, idx.to(DEV), 1.0, False).backward(cot_rows)
+    assert torch.equal(xb.grad, xa.grad)
 
 
 def test_strided_and_int32_inputs_are_normalised(hip, oracle):

@@ -96,7 +96,7 @@ def test_scatter_plan_carves_disjoint_ranges_large_enough():
               (4, 65537, 100), (2, 90112, 512), (32, 90112, 16384), (1, 3, 70000), (2, 76800, 300), (2, 5120, 2000),
               (1, 1048576, 262144), (8, 1, 1), (1, 65536, 36000), (1, 65536, 20000)]
     for (B, L, nbins), ww in itertools.product(shapes, (0, 1)):
-        o_start, o_order, o_scratch, o_w, o_merge, total, flat, flat_ints = _plan("tp3d_scatter_plan", 8, B, L, nbins, ww)
+        o_start, o_order, o_scratch, o_w, o_merge, total, flat, flat_ints, o_hubs = _plan("tp3d_scatter_plan", 9, B, L, nbins, ww)
         assert total == h.tp3d_scatter_workspace_bytes(B, L, nbins, ww)
         ends = [(o_start, B * (nbins + 1) * 4), (o_order, B * L * 4), (o_scratch, B * L * 4)]
         if ww:
@@ -104,6 +104,7 @@ def test_scatter_plan_carves_disjoint_ranges_large_enough():
         else:
             assert o_w == -1
         ends.append((o_merge, B * L * 4))
+        ends.append((o_hubs, (B * nbins + 1) * 4))  # count + ids of the destinations with long runs
         pos = 0
         for off, size in ends:
             assert off % 16 == 0 and off >= pos, (B, L, nbins, ww)

@@ -363,6 +363,8 @@ ScatterWorkspace carve_scatter_workspace(void *ws, int B, int L, int nbins, bool
     }
     w.merge_tmp = reinterpret_cast<int *>(p + off);
     off += up((size_t)B * L * 4);
+    w.hubs = reinterpret_cast<int *>(p + off);
+    off += up(((size_t)B * nbins + 1) * 4);
     w.bytes = off;
     return w;
 }

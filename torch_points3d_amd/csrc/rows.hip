@@ -98,13 +98,76 @@ __device__ __forceinline__ float rl_f(float x, int lane)
 // one wave per destination point, lanes over channels: every read is a contiguous row segment.  NP = channel slots per
 // lane (c = lane + 64 p): a row of up to 64 NP channels is fetched in one traversal of the run, so 4 NP independent
 // loads are in flight per lane (two traversals of 64 channels each ran the 128-channel decoder tables at 1.6 TB/s).
+//
+// acc[p] += sum over the slots [lo, hi) of the run, in slot order, of (weight *) row[c[p]]
+template <int NP>
+__device__ __forceinline__ void gather_run(const float *__restrict__ base, const int *__restrict__ od,
+                                           const float *__restrict__ ws, int lo, int hi, int ld, const int (&c)[NP],
+                                           float (&acc)[NP], int lane)
+{
+    // the run's (row, weight) pairs are fetched 64 at a time with one coalesced load, then broadcast lane by
+    // lane (v_readlane), so independent row reads are in flight instead of a dependent index->row chain
+    for (int j0 = lo; j0 < hi; j0 += 64) {
+        const int cnt = min(64, hi - j0);
+        const int my_r = (lane < cnt) ? od[j0 + lane] : 0;
+        const float my_w = (ws && lane < cnt) ? ws[j0 + lane] : 1.0f;
+        int t = 0;
+        // U rows per step, all their loads issued before the first add (latency per step counts on a long run)
+        auto take = [&](auto utag) {
+            constexpr int U = decltype(utag)::value;
+            int r[U];
+            float wv[U], v[U][NP];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                r[u] = __builtin_amdgcn_readlane(my_r, t + u);
+                wv[u] = ws ? rl_f(my_w, t + u) : 1.0f;
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int p = 0; p < NP; ++p) v[u][p] = base[(size_t)r[u] * ld + c[p]];
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int p = 0; p < NP; ++p) acc[p] = acc[p] + (ws ? wv[u] * v[u][p] : v[u][p]);  // slot order
+            t += U;
+        };
+        while (t + 8 <= cnt) take(std::integral_constant<int, 8>());
+        if (t + 4 <= cnt) take(std::integral_constant<int, 4>());
+        // tail of 1..3 rows (most runs of a grouping table are that short): requested together, summed in order
+        const int rem = cnt - t;
+        if (rem > 0) {
+            const int r0 = __builtin_amdgcn_readlane(my_r, t);
+            const int r1 = __builtin_amdgcn_readlane(my_r, min(t + 1, cnt - 1));
+            const int r2 = __builtin_amdgcn_readlane(my_r, min(t + 2, cnt - 1));
+            const float w0 = ws ? rl_f(my_w, t) : 1.0f, w1 = ws ? rl_f(my_w, min(t + 1, cnt - 1)) : 1.0f,
+                        w2 = ws ? rl_f(my_w, min(t + 2, cnt - 1)) : 1.0f;
+#pragma unroll
+            for (int p = 0; p < NP; ++p) {
+                const float v0 = base[(size_t)r0 * ld + c[p]], v1 = base[(size_t)r1 * ld + c[p]],
+                            v2 = base[(size_t)r2 * ld + c[p]];
+                acc[p] = acc[p] + (ws ? w0 * v0 : v0);
+                if (rem > 1) acc[p] = acc[p] + (ws ? w1 * v1 : v1);
+                if (rem > 2) acc[p] = acc[p] + (ws ? w2 * v2 : v2);
+            }
+        }
+    }
+}
+
+// Runs longer than HUB_MIN slots are left to rows_gather_hub_kernel (hub_min > 0): the first hit of a padded ball query
+// collects every padding slot of every ball it opens -- 1295 slots on a 128-centre, 128-slot table over 512 points --
+// and one wave walking that run alone held the whole launch (0.65 ms where a table of the same size without hubs takes
+// 0.14 ms).
+constexpr int HUB_MIN = 128;
+constexpr int HUB_BLOCK = 1024;
+
 template <int NP>
 __global__ __launch_bounds__(RW_BLOCK) void rows_gather_sum_kernel(const float *__restrict__ grad_rows,
                                                                     const int *__restrict__ start,
                                                                     const int *__restrict__ order,
                                                                     const float *__restrict__ wsorted, int nbins,
                                                                     int L, int rows_per_cloud, int ld, int col0,
-                                                                    int C, float *__restrict__ out, int flat)
+                                                                    int C, float *__restrict__ out, int flat, int hub_min)
 {
     const int lane = threadIdx.x & 63;
     const int64_t dest = (int64_t)blockIdx.x * (RW_BLOCK / 64) + (threadIdx.x >> 6);  // destination point k
@@ -115,6 +178,7 @@ __global__ __launch_bounds__(RW_BLOCK) void rows_gather_sum_kernel(const float *
     const int *od = flat ? order : order + (size_t)b * L;
     const float *ws = wsorted ? (flat ? wsorted : wsorted + (size_t)b * L) : nullptr;
     const int lo = st[dest], hi = st[dest + 1];
+    if (hub_min > 0 && hi - lo > hub_min) return;  // a hub: rows_gather_hub_kernel
     const float *base = grad_rows + (flat ? (size_t)0 : (size_t)b * rows_per_cloud * ld) + col0;
     for (int c0 = 0; c0 < C; c0 += 64 * NP) {
         int c[NP];
@@ -124,57 +188,69 @@ __global__ __launch_bounds__(RW_BLOCK) void rows_gather_sum_kernel(const float *
             c[p] = min(c0 + p * 64 + lane, C - 1);
             acc[p] = 0.0f;
         }
-        // the run's (row, weight) pairs are fetched 64 at a time with one coalesced load, then broadcast lane by
-        // lane (v_readlane), so independent row reads are in flight instead of a dependent index->row chain
-        for (int j0 = lo; j0 < hi; j0 += 64) {
-            const int cnt = min(64, hi - j0);
-            const int my_r = (lane < cnt) ? od[j0 + lane] : 0;
-            const float my_w = (ws && lane < cnt) ? ws[j0 + lane] : 1.0f;
-            int t = 0;
-            // U rows per step, all their loads issued before the first add (a destination that collects thousands of
-            // slots -- the shared first hit of padded ball queries -- is one wave's serial walk: latency per step counts)
-            auto take = [&](auto utag) {
-                constexpr int U = decltype(utag)::value;
-                int r[U];
-                float wv[U], v[U][NP];
-#pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    r[u] = __builtin_amdgcn_readlane(my_r, t + u);
-                    wv[u] = ws ? rl_f(my_w, t + u) : 1.0f;
-                }
-#pragma unroll
-                for (int u = 0; u < U; ++u)
-#pragma unroll
-                    for (int p = 0; p < NP; ++p) v[u][p] = base[(size_t)r[u] * ld + c[p]];
-#pragma unroll
-                for (int u = 0; u < U; ++u)
-#pragma unroll
-                    for (int p = 0; p < NP; ++p) acc[p] = acc[p] + (ws ? wv[u] * v[u][p] : v[u][p]);  // slot order
-                t += U;
-            };
-            while (t + 8 <= cnt) take(std::integral_constant<int, 8>());
-            if (t + 4 <= cnt) take(std::integral_constant<int, 4>());
-            // tail of 1..3 rows (most runs of a grouping table are that short): requested together, summed in order
-            const int rem = cnt - t;
-            if (rem > 0) {
-                const int r0 = __builtin_amdgcn_readlane(my_r, t);
-                const int r1 = __builtin_amdgcn_readlane(my_r, min(t + 1, cnt - 1));
-                const int r2 = __builtin_amdgcn_readlane(my_r, min(t + 2, cnt - 1));
-                const float w0 = ws ? rl_f(my_w, t) : 1.0f, w1 = ws ? rl_f(my_w, min(t + 1, cnt - 1)) : 1.0f,
-                            w2 = ws ? rl_f(my_w, min(t + 2, cnt - 1)) : 1.0f;
-#pragma unroll
-                for (int p = 0; p < NP; ++p) {
-                    const float v0 = base[(size_t)r0 * ld + c[p]], v1 = base[(size_t)r1 * ld + c[p]],
-                                v2 = base[(size_t)r2 * ld + c[p]];
-                    acc[p] = acc[p] + (ws ? w0 * v0 : v0);
-                    if (rem > 1) acc[p] = acc[p] + (ws ? w1 * v1 : v1);
-                    if (rem > 2) acc[p] = acc[p] + (ws ? w2 * v2 : v2);
-                }
-            }
-        }
+        gather_run<NP>(base, od, ws, lo, hi, ld, c, acc, lane);
 #pragma unroll
         for (int p = 0; p < NP; ++p)
             if (c0 + p * 64 + lane < C) out[((size_t)b * nbins + dest) * C + c0 + p * 64 + lane] = acc[p];
+    }
+}
+
+// hubs[0] = number of destinations with more than HUB_MIN slots, hubs[1..] = their ids b * nbins + k (any order)
+__global__ __launch_bounds__(256) void find_hubs_kernel(const int *__restrict__ start, int B, int nbins, int flat,
+                                                        int *__restrict__ hubs)
+{
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= (int64_t)B * nbins) return;
+    const int b = (int)(e / nbins), k = (int)(e - (int64_t)b * nbins);
+    const int *st = flat ? start + (size_t)b * nbins : start + (size_t)b * (nbins + 1);
+    if (st[k + 1] - st[k] > HUB_MIN) hubs[1 + atomicAdd(&hubs[0], 1)] = (int)e;
+}
+
+// One workgroup of 16 waves per hub: the run is cut into 16 contiguous pieces, one per wave (each summed in slot order),
+// and the pieces are added in piece order -- a fixed association, so the result is reproducible run to run.
+template <int NP>
+__global__ __launch_bounds__(HUB_BLOCK) void rows_gather_hub_kernel(const float *__restrict__ grad_rows,
+                                                                     const int *__restrict__ start,
+                                                                     const int *__restrict__ order,
+                                                                     const float *__restrict__ wsorted,
+                                                                     const int *__restrict__ hubs, int nbins, int L,
+                                                                     int rows_per_cloud, int ld, int col0, int C,
+                                                                     float *__restrict__ out, int flat)
+{
+    constexpr int NW = HUB_BLOCK / 64;
+    __shared__ float part[NW][64 * NP];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int count = hubs[0];
+    for (int h = blockIdx.x; h < count; h += gridDim.x) {
+        const int e = hubs[1 + h];
+        const int b = e / nbins, dest = e - b * nbins;
+        const int *st = flat ? start + (size_t)b * nbins : start + (size_t)b * (nbins + 1);
+        const int *od = flat ? order : order + (size_t)b * L;
+        const float *ws = wsorted ? (flat ? wsorted : wsorted + (size_t)b * L) : nullptr;
+        const int lo = st[dest], hi = st[dest + 1];
+        const int per = ((hi - lo + NW - 1) / NW + 7) & ~7;  // slots per wave, a multiple of the 8-row step
+        const int wlo = min(lo + wave * per, hi), whi = min(wlo + per, hi);
+        const float *base = grad_rows + (flat ? (size_t)0 : (size_t)b * rows_per_cloud * ld) + col0;
+        for (int c0 = 0; c0 < C; c0 += 64 * NP) {
+            int c[NP];
+            float acc[NP];
+#pragma unroll
+            for (int p = 0; p < NP; ++p) {
+                c[p] = min(c0 + p * 64 + lane, C - 1);
+                acc[p] = 0.0f;
+            }
+            gather_run<NP>(base, od, ws, wlo, whi, ld, c, acc, lane);
+#pragma unroll
+            for (int p = 0; p < NP; ++p) part[wave][p * 64 + lane] = acc[p];
+            __syncthreads();
+            for (int x = threadIdx.x; x < 64 * NP; x += HUB_BLOCK) {
+                float sum = part[0][x];
+                for (int w = 1; w < NW; ++w) sum = sum + part[w][x];
+                const int cc = c0 + x;  // x = p * 64 + lane
+                if (cc < C) out[((size_t)b * nbins + dest) * C + cc] = sum;
+            }
+            __syncthreads();
+        }
     }
 }
 
@@ -858,8 +934,9 @@ static bool scatter_goes_flat(int B, int L, int nbins)
 }
 }  // namespace tp3d
 
-// plan[0..7] = byte offsets of start, order, scratch, wsorted (-1 without weights), merge_tmp in the workspace, its
-// size in bytes, 1 when the table is inverted flat over the whole batch, ints of `scratch` that path uses
+// plan[0..8] = byte offsets of start, order, scratch, wsorted (-1 without weights), merge_tmp in the workspace, its
+// size in bytes, 1 when the table is inverted flat over the whole batch, ints of `scratch` that path uses, byte offset
+// of the hub list (1 + B*nbins ints)
 TP3D_EXPORT int tp3d_scatter_plan(int B, int L, int nbins, int with_weights, int64_t *plan)
 {
     if (B <= 0 || L <= 0 || nbins <= 0 || !plan) return TP3D_E_BADARG;
@@ -872,6 +949,7 @@ TP3D_EXPORT int tp3d_scatter_plan(int B, int L, int nbins, int with_weights, int
     plan[5] = (int64_t)w.bytes;
     plan[6] = scatter_goes_flat(B, L, nbins) ? 1 : 0;
     plan[7] = plan[6] ? 2 * (int64_t)B * nbins : 0;  // invert_table: histogram + cursors
+    plan[8] = (char *)w.hubs - (char *)nullptr;
     return TP3D_OK;
 }
 
@@ -892,15 +970,22 @@ TP3D_EXPORT int tp3d_rows_scatter_invert(const int64_t *idx, const float *weight
     // grouping: 512 x 128 slots per cloud): invert ONE flat table over the whole device instead of one table per
     // workgroup (scratch holds the histogram and the cursors), then turn slot ids into row ids and line the weights up.
     // (measured on the 49 152-slot decoder tables, which fit LDS: flat 523 us vs per-cloud 354 us, so off by default)
-    if (scatter_goes_flat(B, L, nbins)) {
+    const bool flat = scatter_goes_flat(B, L, nbins);
+    if (flat) {
         const int64_t slots = (int64_t)B * L, bins = (int64_t)B * nbins;
         if (int rc = invert_table(idx, slots, bins, w.scratch, w.start, w.scratch + bins, w.order, s, L, nbins, w.merge_tmp))
             return rc;
         hipLaunchKernelGGL(slots_to_rows_kernel, dim3((unsigned)((slots + 255) / 256)), dim3(256), 0, s, w.order, weight, div,
                            (int)slots, w.start, (int)bins, w.wsorted);
-        return check_launch();
+        if (int rc = check_launch()) return rc;
+    } else if (int rc = csr_transpose(idx, B, L, nbins, div, weight, w.start, w.order, w.wsorted, w.scratch, s)) {
+        return rc;
     }
-    return csr_transpose(idx, B, L, nbins, div, weight, w.start, w.order, w.wsorted, w.scratch, s);
+    // the destinations whose runs are long enough to be summed by a whole workgroup (rows_gather_hub_kernel)
+    if (int rc = zero_async(w.hubs, sizeof(int), s)) return rc;
+    hipLaunchKernelGGL(find_hubs_kernel, dim3((unsigned)(((int64_t)B * nbins + 255) / 256)), dim3(256), 0, s, w.start, B, nbins,
+                       flat ? 1 : 0, w.hubs);
+    return check_launch();
 }
 
 TP3D_EXPORT int tp3d_rows_scatter_apply_f32(const float *grad_rows, int B, int L, int div, int nbins, int ld, int col0,
@@ -918,15 +1003,24 @@ TP3D_EXPORT int tp3d_rows_scatter_apply_f32(const float *grad_rows, int B, int L
     if (table_bytes < w.bytes) return TP3D_E_BADARG;
     const bool flat = scatter_goes_flat(B, L, nbins);
     dim3 grid((nbins + RW_BLOCK / 64 - 1) / (RW_BLOCK / 64), B);
-    if (C > 128)
+    const dim3 hub_grid(256);  // the hub count lives on the device: a fixed grid strides over the list (usually a few dozen)
+    const int fl = flat ? 1 : 0;
+    if (C > 128) {
         hipLaunchKernelGGL(rows_gather_sum_kernel<4>, grid, dim3(RW_BLOCK), 0, s, grad_rows, w.start, w.order, w.wsorted,
-                           nbins, L, L / div, ld, col0, C, grad_x_cl, flat ? 1 : 0);
-    else if (C > 64)
+                           nbins, L, L / div, ld, col0, C, grad_x_cl, fl, HUB_MIN);
+        hipLaunchKernelGGL(rows_gather_hub_kernel<4>, hub_grid, dim3(HUB_BLOCK), 0, s, grad_rows, w.start, w.order, w.wsorted,
+                           w.hubs, nbins, L, L / div, ld, col0, C, grad_x_cl, fl);
+    } else if (C > 64) {
         hipLaunchKernelGGL(rows_gather_sum_kernel<2>, grid, dim3(RW_BLOCK), 0, s, grad_rows, w.start, w.order, w.wsorted,
-                           nbins, L, L / div, ld, col0, C, grad_x_cl, flat ? 1 : 0);
-    else
+                           nbins, L, L / div, ld, col0, C, grad_x_cl, fl, HUB_MIN);
+        hipLaunchKernelGGL(rows_gather_hub_kernel<2>, hub_grid, dim3(HUB_BLOCK), 0, s, grad_rows, w.start, w.order, w.wsorted,
+                           w.hubs, nbins, L, L / div, ld, col0, C, grad_x_cl, fl);
+    } else {
         hipLaunchKernelGGL(rows_gather_sum_kernel<1>, grid, dim3(RW_BLOCK), 0, s, grad_rows, w.start, w.order, w.wsorted,
-                           nbins, L, L / div, ld, col0, C, grad_x_cl, flat ? 1 : 0);
+                           nbins, L, L / div, ld, col0, C, grad_x_cl, fl, HUB_MIN);
+        hipLaunchKernelGGL(rows_gather_hub_kernel<1>, hub_grid, dim3(HUB_BLOCK), 0, s, grad_rows, w.start, w.order, w.wsorted,
+                           w.hubs, nbins, L, L / div, ld, col0, C, grad_x_cl, fl);
+    }
     return check_launch();
 }
 

@@ -64,6 +64,7 @@ struct ScatterWorkspace {
     int *scratch;    // B*L (only touched when a cloud's tables do not fit LDS)
     float *wsorted;  // B*L or null
     int *merge_tmp;  // B*L: second buffer of the run merge that sorts bins of more than 1024 slots (flat inversion)
+    int *hubs;       // 1 + B*nbins: count, then the ids b*nbins + k of the destinations with long runs (rows.hip)
     size_t bytes;
 };
 ScatterWorkspace carve_scatter_workspace(void *ws, int B, int L, int nbins, bool with_weights);
