@@ -323,7 +323,7 @@ __global__ __launch_bounds__(GR_BLOCK_T, (WIDE && PRO != PRO_NONE) ? 2 : 1) void
 // STATS: 0 none, 1 one statistics chunk per (128-row block, wave row), 2 one per (workgroup, wave row) (needs
 // gridDim.x % (8*tiles_n) == 0: every item of a workgroup then lies in the same column tile)
 template <int STATS>
-__global__ __launch_bounds__(GR_BLOCK_T) void gemm_rows_wide_kernel(const float *__restrict__ A, const float *__restrict__ Bt,
+__global__ __launch_bounds__(GR_BLOCK_T, 2) void gemm_rows_wide_kernel(const float *__restrict__ A, const float *__restrict__ Bt,
                                                                 int64_t M, int N, int K, int tiles_n, int64_t items,
                                                                 float *__restrict__ C, float *__restrict__ partial)
 {
@@ -334,6 +334,7 @@ __global__ __launch_bounds__(GR_BLOCK_T) void gemm_rows_wide_kernel(const float 
     const int wr = wave >> 1, wc = wave & 1;
     const int l31 = lane & 31, lh = lane >> 5;
     const int ksteps = (K + GR_BK - 1) / GR_BK;
+    const int tail_groups = (K - (ksteps - 1) * GR_BK + 7) / 8;  // 8-wide k groups of the last step that hold columns
 
     // Work items = (row block, column tile) in an XCD-aware order: the column tiles of one row block are 8 ids
     // apart, i.e. on the same XCD (shared L2 for A).  Workgroups are PERSISTENT: each walks items id, id + G, ...
@@ -399,24 +400,29 @@ __global__ __launch_bounds__(GR_BLOCK_T) void gemm_rows_wide_kernel(const float 
             __syncthreads();
             if (ks + 1 < ksteps) fetch(m0, n0, (ks + 1) * GR_BK);
             else if (next_item < items) fetch(nm0, nn0, 0);  // next item's first K-step rides under this epilogue
+            // last step of a contraction that is not a multiple of 32 (131 + 1 padding columns, 3 + 5, ...): only the
+            // 8-wide k groups that hold real columns -- a fifth step of 4 columns costs a quarter step, not a whole one
+            const int ng = (ks + 1 < ksteps) ? GR_BK / 8 : tail_groups;  // wave-uniform
 #pragma unroll
             for (int g = 0; g < GR_BK / 8; ++g) {
-                float4 a[2], b[2];
+                if (g < ng) {
+                    float4 a[2], b[2];
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
-                    a[i] = *reinterpret_cast<const float4 *>(&sA[((wr * 2 + i) * 32 + l31) * GR_LD + g * 8 + lh * 4]);
+                    for (int i = 0; i < 2; ++i)
+                        a[i] = *reinterpret_cast<const float4 *>(&sA[((wr * 2 + i) * 32 + l31) * GR_LD + g * 8 + lh * 4]);
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    b[j] = *reinterpret_cast<const float4 *>(&sB[((wc * 2 + j) * 32 + l31) * GR_LD + g * 8 + lh * 4]);
+                    for (int j = 0; j < 2; ++j)
+                        b[j] = *reinterpret_cast<const float4 *>(&sB[((wc * 2 + j) * 32 + l31) * GR_LD + g * 8 + lh * 4]);
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
+                    for (int i = 0; i < 2; ++i)
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) {
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].x, b[j].x, acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].y, b[j].y, acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].z, b[j].z, acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, b[j].w, acc[i][j], 0, 0, 0);
-                    }
+                        for (int j = 0; j < 2; ++j) {
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].x, b[j].x, acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].y, b[j].y, acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].z, b[j].z, acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, b[j].w, acc[i][j], 0, 0, 0);
+                        }
+                }
             }
             __syncthreads();
         }
