@@ -144,7 +144,9 @@ int tp3d_rows_scatter_bwd_f32(const float *grad_rows, const int64_t *idx, const 
                               size_t workspace_bytes, void *stream);
 /* The same in two halves: the inverted table depends on idx / weight only (geometry, not features), so it can be built
  * ahead of the backward pass -- tp3d_rows_scatter_invert fills `workspace` (same size query), tp3d_rows_scatter_apply_f32
- * consumes a table built for the same (idx, weight, B, L, div, nbins); with_weights = the table was built with weights. */
+ * consumes a table built for the same (idx, weight, B, L, div, nbins); with_weights = the table was built with weights.
+ * Sums run in ascending slot order; a destination with more than 128 slots is summed in 16 contiguous pieces that are
+ * then added in order (fixed association: reproducible, not the sequential sum bit for bit). */
 int tp3d_rows_scatter_invert(const int64_t *idx, const float *weight, int B, int L, int div, int nbins, void *workspace,
                              size_t workspace_bytes, void *stream);
 int tp3d_rows_scatter_apply_f32(const float *grad_rows, int B, int L, int div, int nbins, int ld, int col0, int C,
