@@ -1,9 +1,17 @@
 import os
 import sys
 
-import numpy as np
-import pytest
-import torch
+# The reference-graph variants of the parity tests (fused=False: the reference's own Conv2d / BatchNorm2d graph around
+# the HIP spatial kernels) run their 1x1 convolutions on MIOpen, whose implicit-GEMM backward-data kernel
+# (igemm_bwd_gtcx35_nhwc_fp32_*) reads past the end of small tensors: harmless inside PyTorch's caching allocator unless
+# the tensor sits at the end of a mapped segment, then "Memory access fault by GPU" and an abort -- the intermittent
+# abort of rounds 1 and 2, located with tests/guard/run_guarded.py.  That solver family is switched off for the test
+# process (must happen before MIOpen is first used); the product path (fused=True) never calls MIOpen.
+os.environ.setdefault("MIOPEN_DEBUG_CONV_IMPLICIT_GEMM", "0")
+
+import numpy as np  # noqa: E402
+import pytest  # noqa: E402
+import torch  # noqa: E402
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:

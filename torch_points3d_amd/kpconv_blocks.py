@@ -207,7 +207,10 @@ class ResnetBBlock(nn.Module):
             else:
                 padded = torch.cat([shortcut_x, torch.zeros_like(shortcut_x[:1, :])], dim=0)  # shadow feature row
                 idx = torch.where(idx < 0, torch.full_like(idx, shortcut_x.shape[0]), idx)
-                shortcut_x = padded[idx].max(dim=1)[0]
+                # (index_select, not padded[idx]: the backward of 2-D advanced indexing runs ATen's
+                #  indexing_backward_kernel_small_stride, which reads past the end of its index buffer on this ROCm build
+                #  -- tests/guard/ found it)
+                shortcut_x = torch.index_select(padded, 0, idx.reshape(-1)).view(idx.shape[0], idx.shape[1], -1).max(dim=1)[0]
         output.x = output.x + seq(self.shortcut_op, shortcut_x)
         return output
 
