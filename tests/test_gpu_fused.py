@@ -322,6 +322,13 @@ def test_bn_act_maxpool_is_the_first_maximum_of_every_group(G, ns, C):
     first = (a == want.unsqueeze(1)).float().argmax(dim=1)  # the first row holding the maximum
     assert torch.equal(out, want)
     assert torch.equal(arg.long(), first)
+    # a NaN in a window is the window's result, as with max_pool2d (the first one)
+    Y[3 * ns + 2, 0] = float("nan")
+    Y[3 * ns + 5, 0] = float("nan")
+    _lib.call("tp3d_bn_act_maxpool_f32", Y.data_ptr(), mean.data_ptr(), scale.data_ptr(), shift.data_ptr(), slope, G, ns, C,
+              out.data_ptr(), arg.data_ptr(), _lib.stream_ptr(Y.device))
+    assert bool(torch.isnan(out[3, 0])) and int(arg[3, 0]) == 2
+    assert not bool(torch.isnan(out[2])[0]) and torch.equal(out[4:], want[4:])
 
 
 def test_scatter_tables_built_ahead_give_the_same_gradients():

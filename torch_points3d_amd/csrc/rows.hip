@@ -590,6 +590,16 @@ __global__ __launch_bounds__(RW_BLOCK) void bn_act_maxpool_kernel(const float *_
         float best = -INFINITY;
         int bs = 0;
         int s = 0;
+        // a NaN wins and stays (max_pool2d's rule: the first NaN of the window is the result); tested on the bit pattern
+        // because the file is compiled with -fno-honor-nans, which lets the compiler drop floating-point NaN tests
+        auto take = [&](float a, int row) {
+            const bool is_nan = (__float_as_uint(a) & 0x7fffffffu) > 0x7f800000u;
+            const bool have_nan = (__float_as_uint(best) & 0x7fffffffu) > 0x7f800000u;
+            if (!have_nan && (is_nan || a > best)) {
+                best = a;
+                bs = row;
+            }
+        };
         for (; s + 8 <= ns; s += 8) {  // eight independent row loads in flight, compared in row order
             float v[8];
 #pragma unroll
@@ -597,20 +607,12 @@ __global__ __launch_bounds__(RW_BLOCK) void bn_act_maxpool_kernel(const float *_
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const float z = (v[u] - mu) * sc + sh;
-                const float a = z > 0.0f ? z : z * slope;
-                if (a > best) {
-                    best = a;
-                    bs = s + u;
-                }
+                take(z > 0.0f ? z : z * slope, s + u);
             }
         }
         for (; s < ns; ++s) {
             const float z = (y[(size_t)s * C] - mu) * sc + sh;
-            const float a = z > 0.0f ? z : z * slope;
-            if (a > best) {
-                best = a;
-                bs = s;
-            }
+            take(z > 0.0f ? z : z * slope, s);
         }
         out[e] = best;
         arg[e] = bs;
