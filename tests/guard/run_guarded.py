@@ -3,6 +3,7 @@
 launch that makes it and the Python traceback of the abort names the call.  Usage (on the GPU box):
 
     python tests/guard/run_guarded.py tests/test_gpu_parity.py -k test_model_gradients_elementwise
+    python tests/guard/run_guarded.py --script bench.py --no-graph --steps 2 --warmup 1 --no-cpu-baseline
 """
 import os
 import subprocess
@@ -21,11 +22,16 @@ def build():
 
 
 CHILD = r"""
-import sys, faulthandler
+import sys, faulthandler, runpy
 faulthandler.enable()
 import torch
 alloc = torch.cuda.memory.CUDAPluggableAllocator(sys.argv[1], "guard_malloc", "guard_free")
 torch.cuda.memory.change_current_allocator(alloc)
+if len(sys.argv) > 2 and sys.argv[2] == "--script":  # any script instead of a pytest selection
+    script = sys.argv[3]
+    sys.argv = [script] + sys.argv[4:]
+    runpy.run_path(script, run_name="__main__")
+    sys.exit(0)
 import pytest
 sys.exit(pytest.main(["-q", "-p", "no:cacheprovider"] + sys.argv[2:]))
 """
