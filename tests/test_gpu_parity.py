@@ -220,6 +220,18 @@ def test_three_nn_grid_path_is_exact(hip, oracle, case):
 
 # ------------------------------------------------------------------------- interpolate / grouping
 
+def _assert_scatter_grad(got, want, flat_idx, nbins):
+    """(B, C, nbins) scatter-add gradients: bit-identical to the oracle's sequential sum wherever a destination collects
+    at most 128 slots (GS_HUB_MIN of csrc/csr.hip); longer runs are summed in a fixed parallel order, i.e. to round-off."""
+    for b in range(got.shape[0]):
+        runs = torch.bincount(flat_idx[b], minlength=nbins)
+        short = runs <= 128
+        assert torch.equal(got[b][:, short], want[b][:, short])
+        if not bool(short.all()):
+            torch.testing.assert_close(got[b][:, ~short], want[b][:, ~short], rtol=1e-5,
+                                       atol=1e-5 * float(want[b].abs().max()))
+
+
 @pytest.mark.parametrize("B,C,m,n", [(2, 256, 128, 512), (2, 128, 512, 1024), (3, 5, 7, 130), (1, 33, 3, 1),
                                      (2, 3, 512, 16384), (1, 2, 64, 40000), (2, 1, 9, 300)])
 def test_three_interpolate_fwd_bwd(hip, oracle, B, C, m, n):
@@ -236,8 +248,11 @@ def test_three_interpolate_fwd_bwd(hip, oracle, B, C, m, n):
     assert torch.equal(oa.cpu(), ob.detach())  # fixed 3-term order, no fma: exact
     oa.backward(cot.to(DEV))
     ob.backward(cot)
-    # transpose + gather-sum accumulates in the oracle's order (ascending (i,t), mul then add): exact
-    assert torch.equal(fa.grad.cpu(), fb.grad)
+    # transpose + gather-sum accumulates in the oracle's order (ascending (i,t), mul then add): exact for every known
+    # point that collects at most 128 slots; longer runs are summed by a whole workgroup in a fixed parallel order
+    _assert_scatter_grad(fa.grad.cpu(), fb.grad, idx.reshape(B, -1), m)
+    (g2,) = torch.autograd.grad(hip.three_interpolate(fa, idx.to(DEV), w.to(DEV)), fa, cot.to(DEV))
+    assert torch.equal(g2, fa.grad)  # no atomics: bitwise reproducible run to run
 
 
 @pytest.mark.parametrize("B,C,N,npnt,ns", [(2, 8, 1024, 512, 64), (2, 131, 512, 128, 64), (3, 3, 50, 7, 5),
@@ -257,7 +272,7 @@ def test_grouping_fwd_bwd(hip, oracle, B, C, N, npnt, ns):
     assert torch.equal(oa.cpu(), ob.detach())
     oa.backward(cot.to(DEV))
     ob.backward(cot)
-    assert torch.equal(fa.grad.cpu(), fb.grad)  # ascending-slot accumulation, same as the oracle: exact
+    _assert_scatter_grad(fa.grad.cpu(), fb.grad, idx.reshape(B, -1), N)  # ascending-slot accumulation, as the oracle
     (g2,) = torch.autograd.grad(hip.grouping_operation(fa, idx.to(DEV)), fa, cot.to(DEV))
     assert torch.equal(g2, fa.grad)  # no atomics: bitwise reproducible run to run
 
@@ -266,8 +281,8 @@ def test_grouping_fwd_bwd(hip, oracle, B, C, N, npnt, ns):
 def test_grouping_bwd_giant_bins(hip, oracle, npnt, ns, N):
     """Dense ball queries pad with their first hit: when that is the same point for many queries, one destination
     collects thousands of slots (here npnt * (ns - 40)).  The inverse-index build sorts such a bin window segment by
-    window segment; the accumulation order -- hence the result -- must still be the oracle's, bit for bit.
-    (600 x 128 slots do not fit the in-LDS tables: second code path.)"""
+    window segment; the short runs keep the oracle's accumulation order bit for bit, the giant one is summed in a fixed
+    parallel order.  (600 x 128 slots do not fit the in-LDS tables: second code path.)"""
     B, C = 2, 5
     g = torch.Generator().manual_seed(npnt + ns)
     feat = torch.randn(B, C, N, generator=g)
@@ -279,7 +294,12 @@ def test_grouping_bwd_giant_bins(hip, oracle, npnt, ns, N):
     fb = feat.clone().requires_grad_(True)
     hip.grouping_operation(fa, idx.to(DEV)).backward(cot.to(DEV))
     oracle.grouping_operation(fb, idx).backward(cot)
-    assert torch.equal(fa.grad.cpu(), fb.grad)
+    # runs of more than 128 slots are summed by a whole workgroup (pieces per wave, strides per lane, fixed order): the
+    # oracle's sequential sum to fp32 round-off, and the same bits from call to call (the reference accumulates with
+    # atomics in no fixed order at all)
+    torch.testing.assert_close(fa.grad.cpu(), fb.grad, rtol=1e-5, atol=1e-5 * float(fb.grad.abs().max()))
+    (g2,) = torch.autograd.grad(hip.grouping_operation(fa, idx.to(DEV)), fa, cot.to(DEV))
+    assert torch.equal(g2, fa.grad)
     # the channel-last rows path (fused set abstraction) goes through the same tables
     from torch_points3d_amd import fused
     pos = torch.rand(B, N, 3, generator=g).to(DEV)

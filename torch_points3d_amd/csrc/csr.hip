@@ -253,6 +253,8 @@ int csr_transpose(const int64_t *idx, int B, int L, int nbins, int div, const fl
 // CC channel rows are staged in LDS (coalesced read of grad_out, each byte fetched once); every lane owns a
 // destination k, reads its (order, weight) run once and accumulates CC channels from LDS.
 constexpr int GS_BLOCK = 512;
+constexpr int GS_HUB_MIN = 128;   // longer runs are summed by the whole workgroup
+constexpr int GS_HUB_CAP = 1024;  // hubs listed per (cloud, channel group); further ones are walked by their lane
 
 template <int CC, bool WEIGHTED, bool IN_LDS>
 __global__ __launch_bounds__(GS_BLOCK) void gather_sum_kernel(const float *__restrict__ rows,
@@ -283,8 +285,25 @@ __global__ __launch_bounds__(GS_BLOCK) void gather_sum_kernel(const float *__res
     const int *st = start + (size_t)b * (nbins + 1);
     const int *od = order + (size_t)b * Lslots;
     const float *ws = WEIGHTED ? wsorted + (size_t)b * Lslots : nullptr;
+    // Destinations with more than GS_HUB_MIN slots (the shared first hit of padded ball queries collects hundreds to
+    // thousands) are not walked by one lane while its workgroup waits: they are listed and then summed by the whole
+    // workgroup, every wave a contiguous piece of the run, every lane a stride of the piece, the partial sums added in a
+    // fixed order (lanes by butterfly, then pieces in order): reproducible run to run; shorter runs keep the oracle's
+    // sequential order bit for bit.  (128 centres x 128 slots over 512 points, 128 channels: 1.5 ms -> see DESIGN.md.)
+    __shared__ int s_nhub;
+    __shared__ int s_hub[GS_HUB_CAP];
+    __shared__ float s_part[GS_BLOCK / 64][CC];
+    if (tid == 0) s_nhub = 0;
+    __syncthreads();
     for (int k = tid; k < nbins; k += GS_BLOCK) {
         const int lo = st[k], hi = st[k + 1];
+        if (hi - lo > GS_HUB_MIN) {
+            const int pos = atomicAdd(&s_nhub, 1);
+            if (pos < GS_HUB_CAP) {
+                s_hub[pos] = k;
+                continue;
+            }  // (list full: this lane walks it after all)
+        }
         float acc[CC];
 #pragma unroll
         for (int cc = 0; cc < CC; ++cc) acc[cc] = 0.0f;
@@ -302,6 +321,43 @@ __global__ __launch_bounds__(GS_BLOCK) void gather_sum_kernel(const float *__res
 #pragma unroll
         for (int cc = 0; cc < CC; ++cc)
             if (cc < nc) out[((size_t)b * C + c0 + cc) * nbins + k] = acc[cc];
+    }
+    __syncthreads();
+    const int nhub = min(s_nhub, GS_HUB_CAP);
+    const int lane = tid & 63, wave = tid >> 6;
+    constexpr int NW = GS_BLOCK / 64;
+    for (int h = 0; h < nhub; ++h) {
+        const int k = s_hub[h];
+        const int lo = st[k], hi = st[k + 1];
+        const int per = (hi - lo + NW - 1) / NW;
+        const int plo = min(lo + wave * per, hi), phi = min(plo + per, hi);
+        float acc[CC];
+#pragma unroll
+        for (int cc = 0; cc < CC; ++cc) acc[cc] = 0.0f;
+        for (int j = plo + lane; j < phi; j += 64) {
+            const int r = od[j];
+            const float w = WEIGHTED ? ws[j] : 1.0f;
+#pragma unroll
+            for (int cc = 0; cc < CC; ++cc)
+                if (cc < nc) {
+                    const float v = src[(size_t)cc * Lrow + r];
+                    acc[cc] = acc[cc] + (WEIGHTED ? w * v : v);
+                }
+        }
+#pragma unroll
+        for (int cc = 0; cc < CC; ++cc)
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) acc[cc] = acc[cc] + __shfl_xor(acc[cc], off);
+        if (lane == 0)
+#pragma unroll
+            for (int cc = 0; cc < CC; ++cc) s_part[wave][cc] = acc[cc];
+        __syncthreads();
+        if (tid < nc) {
+            float sum = s_part[0][tid];
+            for (int w = 1; w < NW; ++w) sum = sum + s_part[w][tid];
+            out[((size_t)b * C + c0 + tid) * nbins + k] = sum;
+        }
+        __syncthreads();
     }
 }
 
