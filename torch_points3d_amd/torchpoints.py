@@ -311,13 +311,6 @@ class _Grouping(torch.autograd.Function):
         grad_out = _f32(grad_out)
         B, C, np_, ns = grad_out.shape
         ws, ws_bytes = _lib.scatter_workspace(B, np_ * ns, ctx.N, False, dev)
-        if _rows_route(B, np_ * ns, C, False):
-            rows = grad_out.permute(0, 2, 3, 1).contiguous()  # (B, np, ns, C): channel-last gradient rows
-            g_cl = torch.empty((B, ctx.N, C), dtype=torch.float32, device=dev)
-            with _lib.on_device(dev):
-                _lib.call("tp3d_rows_scatter_bwd_f32", _lib.ptr(rows), _lib.ptr(idx), None, B, np_ * ns, 1, ctx.N, C, 0, C,
-                          _lib.ptr(g_cl), _lib.ptr(ws), ws_bytes, _lib.stream_ptr(dev))
-            return g_cl.transpose(1, 2).contiguous(), None
         g = torch.empty((B, C, ctx.N), dtype=torch.float32, device=dev)
         with _lib.on_device(dev):
             _lib.call("tp3d_group_bwd_f32", _lib.ptr(grad_out), _lib.ptr(idx), B, C, ctx.N, np_, ns, _lib.ptr(g),
