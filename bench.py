@@ -77,14 +77,17 @@ class PartSegStep(nn.Module):
         return self.net(Data(pos=pos, x=x), cat, geometry=geometry).view(B, n, -1).transpose(1, 2)
 
 
+FUSED = True  # --reference-graph: the reference's (B,C,np,ns) module graph around the HIP kernels (pure drop-in mode)
+
+
 def build_model(kernels, device):
     torch.manual_seed(0)
     if MODEL_CONFIG == "pointnet2_charlesmsg":
         from torch_points3d_amd.pointnet2 import PointNet2_D
-        net = PointNet2_D(FEAT, NUM_CLASSES, config=MODEL_CONFIG, num_categories=16, kernels=kernels)
+        net = PointNet2_D(FEAT, NUM_CLASSES, config=MODEL_CONFIG, num_categories=16, kernels=kernels, fused=FUSED)
         return PartSegStep(net, 16).to(device).train()
     from torch_points3d_amd.pointnet2 import PointNet2Unet
-    net = PointNet2Unet(FEAT, output_nc=NUM_CLASSES, config=MODEL_CONFIG, kernels=kernels)
+    net = PointNet2Unet(FEAT, output_nc=NUM_CLASSES, config=MODEL_CONFIG, kernels=kernels, fused=FUSED)
     return SegStep(net).to(device).train()
 
 
@@ -591,6 +594,10 @@ def main():
                          "split over the ranks (32/16/8/4 per GPU at 1/2/4/8 GPUs, SURVEY 8e)")
     ap.add_argument("--no-geometry-prefetch", action="store_true",
                     help="compute sampling / searches inside the training pass instead of one step ahead on a second stream")
+    ap.add_argument("--reference-graph", action="store_true",
+                    help="what a user gets by switching ONLY the torch_points_kernels package: the reference's own "
+                         "(B,C,npoint,nsample) Conv2d/BatchNorm2d module graph (MIOpen / rocBLAS) around the HIP spatial "
+                         "kernels, instead of the channel-last fused modules; an extra line, not the headline")
     ap.add_argument("--adam", default="fused", choices=["fused", "foreach"],
                     help="torch.optim.Adam implementation: one fused kernel over the flat parameter buffer, or the "
                          "multi-tensor form (~15 short launches)")
@@ -602,6 +609,9 @@ def main():
                     help="experiment switch: set an attribute of torch_points3d_amd.fused (e.g. USE_MLP_CHAIN=0) before the "
                          "run; recorded in the JSON line")
     args = ap.parse_args()
+    if args.reference_graph:
+        global FUSED
+        FUSED = False
     if args.set:
         from torch_points3d_amd import fused as _fz
         for kv in args.set:
