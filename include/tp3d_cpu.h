@@ -46,6 +46,13 @@ int tp3d_cpu_ball_fill(const void *grid, const float *query, int64_t nq, float r
  * points cannot fill receive -1 / -1.0f. */
 int tp3d_cpu_knn(const void *grid, const float *query, int64_t nq, int k, int64_t *idx, float *dist2, int threads);
 
+/* Region growing over a fixed-width neighbour table (rows end at their first -1): the clusters reached from the lowest
+ * unvisited point through the table's edges, members in discovery order, clusters of fewer than min_size points dropped.
+ * Replaces the numba loop behind torch_points_kernels.region_grow (reference models/panoptic/pointgroup.py:101-115).
+ * members: n slots, cluster_start: n + 1 slots.  Returns the number of clusters kept, or a negative error. */
+int64_t tp3d_cpu_grow_clusters(const int64_t *neighbours, int64_t n, int width, int64_t min_size, int64_t *members,
+                               int64_t *cluster_start);
+
 #ifdef __cplusplus
 }
 #endif

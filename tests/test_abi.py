@@ -52,8 +52,10 @@ def test_library_contains_gfx950_code_object():
 
 def test_drop_in_module_exposes_reference_api():
     import torch_points_kernels as tp
-    for n in ("furthest_point_sample", "ball_query", "three_nn", "three_interpolate", "grouping_operation"):
+    for n in ("furthest_point_sample", "ball_query", "three_nn", "three_interpolate", "grouping_operation",
+              "region_grow", "instance_iou"):  # every name the reference imports from the package
         assert callable(getattr(tp, n))
+    import torch_points_kernels.points_cpu  # noqa: F401  (core/data_transform/transforms.py:16)
 
 
 def test_cpu_tensors_are_refused_not_emulated():

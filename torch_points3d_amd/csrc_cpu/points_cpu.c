@@ -22,7 +22,7 @@ typedef struct {
     int64_t *order; /* n point ids, cell by cell, ascending id inside a cell */
 } Grid;
 
-int tp3d_cpu_abi_version(void) { return 1; }
+int tp3d_cpu_abi_version(void) { return 2; }
 
 static inline float sqdist3(const float *a, const float *b)
 {
@@ -348,4 +348,51 @@ int tp3d_cpu_knn(const void *grid, const float *query, int64_t nq, int k, int64_
     KnnCtx c = {(const Grid *)grid, query, k, idx, dist2};
     parallel_ranges(knn_range, &c, nq, threads);
     return TP3D_CPU_OK;
+}
+
+/* Region growing over a fixed-width neighbour table (torch_points3d/models/panoptic/pointgroup.py:101-115 clusters the
+ * points of one semantic label this way): clusters = the sets reached from the lowest unvisited point through the
+ * table's directed edges among unvisited points; a row ends at its first -1.  Members are listed in discovery order
+ * (the seed first); clusters of fewer than min_size points are dropped.
+ *   neighbours (n, width) int64;  members: n int64 slots;  cluster_start: n + 1 int64 slots
+ * Returns the number of clusters kept (>= 0) or a negative error. */
+int64_t tp3d_cpu_grow_clusters(const int64_t *neighbours, int64_t n, int width, int64_t min_size, int64_t *members,
+                               int64_t *cluster_start)
+{
+    if (n < 0 || width < 0 || (n > 0 && (!members || !cluster_start || (width > 0 && !neighbours)))) return TP3D_CPU_E_BADARG;
+    if (!cluster_start) return 0;
+    unsigned char *visited = (unsigned char *)calloc((size_t)(n > 0 ? n : 1), 1);
+    int64_t *stack = (int64_t *)malloc(sizeof(int64_t) * (size_t)(n > 0 ? n : 1));
+    if (!visited || !stack) {
+        free(visited);
+        free(stack);
+        return TP3D_CPU_E_NOMEM;
+    }
+    int64_t kept = 0, used = 0;
+    cluster_start[0] = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        if (visited[i]) continue;
+        const int64_t first = used;
+        int64_t top = 0;
+        visited[i] = 1;
+        stack[top++] = i;
+        members[used++] = i;
+        while (top > 0) {
+            const int64_t k = stack[--top];
+            const int64_t *row = neighbours + k * width;
+            for (int t = 0; t < width; ++t) {
+                const int64_t nb = row[t];
+                if (nb < 0) break;
+                if (nb >= n || visited[nb]) continue;
+                visited[nb] = 1;
+                stack[top++] = nb;
+                members[used++] = nb;
+            }
+        }
+        if (used - first >= min_size) cluster_start[++kept] = used;
+        else used = first; /* too small: its slots are reused (the points stay visited) */
+    }
+    free(visited);
+    free(stack);
+    return kept;
 }

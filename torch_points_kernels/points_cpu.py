@@ -44,7 +44,9 @@ def _lib():
         h.tp3d_cpu_ball_count.argtypes = [_p, _p, _l, _f, _p, _i]
         h.tp3d_cpu_ball_fill.argtypes = [_p, _p, _l, _f, _i, _i, _p, _p, _p, _i]
         h.tp3d_cpu_knn.argtypes = [_p, _p, _l, _i, _p, _p, _i]
-        if h.tp3d_cpu_abi_version() != 1:
+        h.tp3d_cpu_grow_clusters.restype = _l
+        h.tp3d_cpu_grow_clusters.argtypes = [_p, _l, _i, _l, _p, _p]
+        if h.tp3d_cpu_abi_version() != 2:
             raise RuntimeError("libtp3d_cpu.so ABI mismatch")
         _h = h
     return _h
