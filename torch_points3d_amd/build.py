@@ -42,8 +42,21 @@ def is_stale():
     if not os.path.exists(LIB_PATH):
         return True
     t = os.path.getmtime(LIB_PATH)
+    if _linked_sources() != [os.path.basename(x) for x in sources()]:
+        return True  # a source file was added or removed since the last link
     deps = sources() + glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(ROOT, "include", "*.h"))
     return any(os.path.getmtime(d) > t for d in deps)
+
+
+MANIFEST = os.path.join(OBJ_DIR, "linked.txt")
+
+
+def _linked_sources():
+    try:
+        with open(MANIFEST) as f:
+            return f.read().split()
+    except OSError:
+        return None
 
 
 def _headers():
@@ -84,6 +97,8 @@ def build_library(force=False, verbose=False):
     if verbose:
         print(" ".join(link))
     subprocess.check_call(link)
+    with open(MANIFEST, "w") as f:
+        f.write("\n".join(os.path.basename(x) for x in sources()) + "\n")
     return LIB_PATH
 
 
