@@ -17,7 +17,8 @@ namespace tp3d {
 
 constexpr int GB_BLOCK = 1024;
 constexpr int GQ_BLOCK = 256;     // 4 waves, one query per wave
-constexpr int GQ_CAP = 1024;      // candidate slots per query (overflow -> exact in-order scan of the cloud)
+constexpr int GQ_CAP = 640;       // hit slots per query (overflow -> exact in-order scan of the cloud); 5 KB of LDS per
+                                  // wave = 32 resident waves per CU, the latency-bound kernel's only lever
 
 // Cell edge and cell counts of one cloud from its bounding box (shared by both builders).
 // cell > 0: at least 1.01 * cell (so +-1 cell covers a ball of that radius with margin for the fp32 rounding of the
@@ -45,6 +46,81 @@ __device__ __forceinline__ GridInfo make_grid_info(const float lo3[3], const flo
     gi.gz = min(G, (int)floorf(e2 * gi.inv_cs) + 1);
     gi.pad = 0;
     return gi;
+}
+
+// Exclusive scan of a cell histogram in LDS by one GB_BLOCK workgroup (per-thread serial chunk + wave scan +
+// cross-wave): cnt[k] and cs_out[k] become base + the start of bin k; cs_out[nused] = L (or `last` when given; not
+// written when last < 0: a slab that is not the cloud's last one).  Ends without a barrier.
+__device__ __forceinline__ void grid_scan_cells(int *cnt, int *cs_out, int nused, int L, int *s_scan, int base = 0,
+                                                int last = 0)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int per = (nused + GB_BLOCK - 1) / GB_BLOCK;
+    const int k0 = min(tid * per, nused), k1 = min(k0 + per, nused);
+    int sum = 0;
+    for (int k = k0; k < k1; ++k) sum += cnt[k];
+    int incl = sum;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int v = __shfl_up(incl, off);
+        if (lane >= off) incl += v;
+    }
+    if (lane == 63) s_scan[wave] = incl;
+    __syncthreads();
+    if (tid == 0) {
+        int run = 0;
+        for (int w = 0; w < GB_BLOCK / 64; ++w) {
+            const int v = s_scan[w];
+            s_scan[w] = run;
+            run += v;
+        }
+    }
+    __syncthreads();
+    int run = base + s_scan[wave] + incl - sum;
+    for (int k = k0; k < k1; ++k) {
+        const int v = cnt[k];
+        cnt[k] = run;
+        cs_out[k] = run;  // start of bin k
+        run += v;
+    }
+    if (tid == 0 && last >= 0) cs_out[nused] = last ? last : L;
+}
+
+// Bounding box of the PT points each thread holds -> GridInfo of the cloud in s_info / info[b] (ends with a barrier).
+__device__ __forceinline__ void grid_box_to_info(float mn[3], float mx[3], int L, float radius, float target, int G,
+                                                 float (*s_red)[GB_BLOCK / 64], GridInfo *s_info, GridInfo *out)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            mn[a] = fminf(mn[a], __shfl_xor(mn[a], off));
+            mx[a] = fmaxf(mx[a], __shfl_xor(mx[a], off));
+        }
+    if (lane == 0)
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            s_red[a][wave] = mn[a];
+            s_red[3 + a][wave] = mx[a];
+        }
+    __syncthreads();
+    if (tid == 0) {
+        float lo3[3], hi3[3];
+        for (int a = 0; a < 3; ++a) {
+            lo3[a] = s_red[a][0];
+            hi3[a] = s_red[3 + a][0];
+            for (int w = 1; w < GB_BLOCK / 64; ++w) {
+                lo3[a] = fminf(lo3[a], s_red[a][w]);
+                hi3[a] = fmaxf(hi3[a], s_red[3 + a][w]);
+            }
+        }
+        if (L == 0) lo3[0] = lo3[1] = lo3[2] = hi3[0] = hi3[1] = hi3[2] = 0.0f;
+        const GridInfo gi = make_grid_info(lo3, hi3, L, radius, target, G);
+        *s_info = gi;
+        *out = gi;
+    }
+    __syncthreads();
 }
 
 // seg == nullptr: dense (cloud b owns rows [b*N, (b+1)*N)); else rows [seg[b], seg[b+1]).
@@ -76,36 +152,7 @@ __global__ __launch_bounds__(GB_BLOCK) void grid_build_kernel(const float *__res
             mn[a] = fminf(mn[a], v);
             mx[a] = fmaxf(mx[a], v);
         }
-#pragma unroll
-    for (int a = 0; a < 3; ++a)
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) {
-            mn[a] = fminf(mn[a], __shfl_xor(mn[a], off));
-            mx[a] = fmaxf(mx[a], __shfl_xor(mx[a], off));
-        }
-    if (lane == 0)
-#pragma unroll
-        for (int a = 0; a < 3; ++a) {
-            s_red[a][wave] = mn[a];
-            s_red[3 + a][wave] = mx[a];
-        }
-    __syncthreads();
-    if (tid == 0) {
-        float lo3[3], hi3[3];
-        for (int a = 0; a < 3; ++a) {
-            lo3[a] = s_red[a][0];
-            hi3[a] = s_red[3 + a][0];
-            for (int w = 1; w < GB_BLOCK / 64; ++w) {
-                lo3[a] = fminf(lo3[a], s_red[a][w]);
-                hi3[a] = fmaxf(hi3[a], s_red[3 + a][w]);
-            }
-        }
-        if (L == 0) lo3[0] = lo3[1] = lo3[2] = hi3[0] = hi3[1] = hi3[2] = 0.0f;
-        const GridInfo gi = make_grid_info(lo3, hi3, L, radius, target, G);
-        s_info = gi;
-        info[b] = gi;
-    }
-    __syncthreads();
+    grid_box_to_info(mn, mx, L, radius, target, G, s_red, &s_info, &info[b]);
     const GridInfo gi = s_info;
     // only the gx*gy*gz cells the cloud actually spans are touched (the arrays are sized for the G^3 worst case)
     const int nused = gi.gx * gi.gy * gi.gz;
@@ -119,38 +166,7 @@ __global__ __launch_bounds__(GB_BLOCK) void grid_build_kernel(const float *__res
     };
     for (int j = tid; j < L; j += GB_BLOCK) atomicAdd(&cnt[cell_of(j)], 1);
     __syncthreads();
-    // ---- exclusive scan of the histogram (per-thread serial chunk + wave scan + cross-wave)
-    {
-        const int per = (nused + GB_BLOCK - 1) / GB_BLOCK;
-        const int k0 = min(tid * per, nused), k1 = min(k0 + per, nused);
-        int sum = 0;
-        for (int k = k0; k < k1; ++k) sum += cnt[k];
-        int incl = sum;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const int v = __shfl_up(incl, off);
-            if (lane >= off) incl += v;
-        }
-        if (lane == 63) s_scan[wave] = incl;
-        __syncthreads();
-        if (tid == 0) {
-            int run = 0;
-            for (int w = 0; w < GB_BLOCK / 64; ++w) {
-                const int v = s_scan[w];
-                s_scan[w] = run;
-                run += v;
-            }
-        }
-        __syncthreads();
-        int run = s_scan[wave] + incl - sum;
-        for (int k = k0; k < k1; ++k) {
-            const int v = cnt[k];
-            cnt[k] = run;
-            cs_out[k] = run;  // start of bin k
-            run += v;
-        }
-        if (tid == 0) cs_out[nused] = L;
-    }
+    grid_scan_cells(cnt, cs_out, nused, L, s_scan);
     __syncthreads();
     for (int j = tid; j < L; j += GB_BLOCK) {
         const int pos = atomicAdd(&cnt[cell_of(j)], 1);  // cnt[k] ends as the END of bin k
@@ -165,6 +181,170 @@ __global__ __launch_bounds__(GB_BLOCK) void grid_build_kernel(const float *__res
     }
 }
 
+// The same build for clouds of at most GB_BLOCK * PT points, by gridDim.y workgroups per cloud.  Every thread keeps its
+// PT points in registers from one batch of loads (no second or third walk over the cloud, no id table in LDS); every
+// workgroup of a cloud reads the whole cloud and derives the same box and cells, but owns one contiguous slab of the
+// cell range: it histograms, scans and fills only the points of its slab, behind the count of the points in front of
+// it.  One workgroup per cloud is bound by what one CU can load and scatter (20 us for 16384 points); the slabs spread
+// that over the chip, and blockIdx.y-major launch order keeps the workgroups of a cloud on one XCD (shared L2).
+template <int PT>
+__global__ __launch_bounds__(GB_BLOCK) void grid_build_reg_kernel(const float *__restrict__ x, const int64_t *__restrict__ seg,
+                                                                   int N, float radius, float target, int G,
+                                                                   GridInfo *__restrict__ info, int *__restrict__ cell_start,
+                                                                   float4 *__restrict__ sorted_pt)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ float s_red[6][GB_BLOCK / 64];
+    __shared__ int s_scan[32];
+    __shared__ int s_before;
+    __shared__ GridInfo s_info;
+    const int b = blockIdx.x, slab = blockIdx.y, slabs = gridDim.y, tid = threadIdx.x, lane = tid & 63;
+    const int64_t lo = seg ? seg[b] : (int64_t)b * N;
+    const int L = seg ? (int)(seg[b + 1] - seg[b]) : N;
+    const float *p = x + lo * 3;
+    const int nbins = G * G * G;
+    int *cnt = reinterpret_cast<int *>(smem);
+    int *cs_out = cell_start + (size_t)b * (nbins + 1);
+
+    float px[PT], py[PT], pz[PT];
+    float mn[3] = {3.0e38f, 3.0e38f, 3.0e38f}, mx[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+#pragma unroll
+    for (int i = 0; i < PT; ++i) px[i] = py[i] = pz[i] = 0.0f;
+    if (L > 0) {
+#pragma unroll
+        for (int i = 0; i < PT; ++i) {  // unconditional loads (clamped row), so that all 3 PT are in flight together
+            const int j = min(tid + i * GB_BLOCK, L - 1);
+            px[i] = p[(size_t)j * 3 + 0];
+            py[i] = p[(size_t)j * 3 + 1];
+            pz[i] = p[(size_t)j * 3 + 2];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < PT; ++i)
+        if (tid + i * GB_BLOCK < L) {
+            mn[0] = fminf(mn[0], px[i]), mx[0] = fmaxf(mx[0], px[i]);
+            mn[1] = fminf(mn[1], py[i]), mx[1] = fmaxf(mx[1], py[i]);
+            mn[2] = fminf(mn[2], pz[i]), mx[2] = fmaxf(mx[2], pz[i]);
+        }
+    if (tid == 0) s_before = 0;
+    // (min / max do not depend on the order of the reduction: every workgroup of the cloud gets the same GridInfo)
+    grid_box_to_info(mn, mx, L, radius, target, G, s_red, &s_info, &info[b]);
+    const GridInfo gi = s_info;
+    const int nused = gi.gx * gi.gy * gi.gz;
+    const int c_lo = (int)((int64_t)nused * slab / slabs), c_hi = (int)((int64_t)nused * (slab + 1) / slabs);
+    const int mine = c_hi - c_lo;
+    for (int k = tid; k < mine; k += GB_BLOCK) cnt[k] = 0;
+    __syncthreads();
+    int cell[PT];
+    int before = 0;  // this thread's points in the slabs in front
+#pragma unroll
+    for (int i = 0; i < PT; ++i) {
+        const int cx = cell_coord(px[i], gi.minx, gi.inv_cs, gi.gx);
+        const int cy = cell_coord(py[i], gi.miny, gi.inv_cs, gi.gy);
+        const int cz = cell_coord(pz[i], gi.minz, gi.inv_cs, gi.gz);
+        const int c = (cz * gi.gy + cy) * gi.gx + cx;
+        const bool live = tid + i * GB_BLOCK < L;
+        cell[i] = (live && c >= c_lo && c < c_hi) ? c - c_lo : -1;
+        before += (live && c < c_lo) ? 1 : 0;
+        if (cell[i] >= 0) atomicAdd(&cnt[cell[i]], 1);
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) before += __shfl_xor(before, off);
+    if (lane == 0 && before) atomicAdd(&s_before, before);
+    __syncthreads();
+    const int base = s_before;
+    grid_scan_cells(cnt, cs_out + c_lo, mine, 0, s_scan, base, slab + 1 == slabs ? L : -1);
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < PT; ++i)
+        if (cell[i] >= 0) {
+            const int pos = atomicAdd(&cnt[cell[i]], 1);  // cnt[] holds the cloud-relative starts of the slab's cells
+            sorted_pt[lo + pos] = make_float4(px[i], py[i], pz[i], __int_as_float(tid + i * GB_BLOCK));
+        }
+}
+
+// A query with more hits than LDS slots (a very dense ball): exact in-order scan of its cloud by the wave (inlined: as a
+// call it costs the common path register spills).
+__device__ __forceinline__ void grid_query_overflow(const float *__restrict__ x, int64_t lo, int L, float qx, float qy, float qz,
+                                                 float r2, int nsample, int sort, bool partial, int64_t goff,
+                                                 int64_t *__restrict__ io, float *__restrict__ dd)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t padv_empty = partial ? -1 : 0;
+    // Unsorted: the first nsample hits in index order ARE the answer, so stop once nsample are found.
+    // Sorted: keep every hit's rank bookkeeping simple by falling back to nsample smallest (d, id) via
+    // repeated selection over the scan (rare path; correctness over speed).
+    if (!sort) {
+        int cnt = 0;
+        int first = 0;
+        for (int st = 0; st < L && cnt < nsample; st += 64) {
+            const int k = st + lane;
+            const bool valid = k < L;
+            const int kk = valid ? k : 0;
+            const float d = sqdist3(x[(lo + kk) * 3 + 0], x[(lo + kk) * 3 + 1], x[(lo + kk) * 3 + 2], qx, qy, qz);
+            const bool hit = valid && d < r2;
+            const unsigned long long mask = __ballot(hit);
+            if (mask) {
+                if (cnt == 0) first = st + __builtin_ctzll(mask);
+                const int slot = cnt + lanes_below(mask);
+                if (hit && slot < nsample) {
+                    io[slot] = goff + k;
+                    dd[slot] = d;
+                }
+                cnt += __builtin_popcountll(mask);
+            }
+        }
+        const int64_t padv = partial ? -1 : (cnt ? first : 0);
+        for (int s = min(cnt, nsample) + lane; s < nsample; s += 64) {
+            io[s] = padv;
+            dd[s] = -1.0f;
+        }
+    } else {
+        // selection of the nsample smallest (d, id): pass s finds the smallest pair greater than the previous
+        float pd = -1.0f;
+        int pi = -1;
+        int emitted = 0;
+        int64_t firstv = padv_empty;
+        for (; emitted < nsample; ++emitted) {
+            float bd = 3.0e38f;
+            int bi = 0x7fffffff;
+            for (int st = 0; st < L; st += 64) {
+                const int k = st + lane;
+                if (k < L) {
+                    const float d = sqdist3(x[(lo + k) * 3 + 0], x[(lo + k) * 3 + 1], x[(lo + k) * 3 + 2], qx, qy, qz);
+                    const bool after = d > pd || (d == pd && k > pi);
+                    if (d < r2 && after && (d < bd || (d == bd && k < bi))) {
+                        bd = d;
+                        bi = k;
+                    }
+                }
+            }
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) {
+                const float od = __shfl_xor(bd, off);
+                const int oi = __shfl_xor(bi, off);
+                if (od < bd || (od == bd && oi < bi)) {
+                    bd = od;
+                    bi = oi;
+                }
+            }
+            if (bi == 0x7fffffff) break;
+            if (lane == 0) {
+                io[emitted] = goff + bi;
+                dd[emitted] = bd;
+            }
+            if (emitted == 0) firstv = goff + bi;
+            pd = bd;
+            pi = bi;
+        }
+        const int64_t padv = partial ? -1 : firstv;
+        for (int s = emitted + lane; s < nsample; s += 64) {
+            io[s] = padv;
+            dd[s] = -1.0f;
+        }
+    }
+}
+
 // One wave per query.  dense: cloud = q / np, indices cloud-local, pad = first hit (0 if none);
 // partial: cloud = batch_y[q], indices global rows, pad = -1.
 __global__ __launch_bounds__(GQ_BLOCK) void grid_query_kernel(
@@ -173,7 +353,7 @@ __global__ __launch_bounds__(GQ_BLOCK) void grid_query_kernel(
     int G, const GridInfo *__restrict__ info, const int *__restrict__ cell_start,
     const float4 *__restrict__ sorted_pt, int64_t *__restrict__ idx, float *__restrict__ dist2)
 {
-    __shared__ int s_id[GQ_BLOCK / 64][GQ_CAP];
+    __shared__ __attribute__((aligned(16))) int s_id[GQ_BLOCK / 64][GQ_CAP + 4];  // + the pad of the four-wide ranking reads
     __shared__ float s_d[GQ_BLOCK / 64][GQ_CAP];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t q = (int64_t)blockIdx.x * (GQ_BLOCK / 64) + wave;
@@ -256,105 +436,64 @@ __global__ __launch_bounds__(GQ_BLOCK) void grid_query_kernel(
         }
     }
     if (overflow) {
-        // more candidates than LDS slots (very dense ball): exact in-order scan of the cloud for this query.
-        // Unsorted: the first nsample hits in index order ARE the answer, so stop once nsample are found.
-        // Sorted: keep every hit's rank bookkeeping simple by falling back to nsample smallest (d, id) via
-        // repeated selection over the scan (rare path; correctness over speed).
-        if (!sort) {
-            int cnt = 0;
-            int first = 0;
-            for (int st = 0; st < L && cnt < nsample; st += 64) {
-                const int k = st + lane;
-                const bool valid = k < L;
-                const int kk = valid ? k : 0;
-                const float d = sqdist3(x[(lo + kk) * 3 + 0], x[(lo + kk) * 3 + 1], x[(lo + kk) * 3 + 2], qx, qy, qz);
-                const bool hit = valid && d < r2;
-                const unsigned long long mask = __ballot(hit);
-                if (mask) {
-                    if (cnt == 0) first = st + __builtin_ctzll(mask);
-                    const int slot = cnt + lanes_below(mask);
-                    if (hit && slot < nsample) {
-                        io[slot] = goff + k;
-                        dd[slot] = d;
-                    }
-                    cnt += __builtin_popcountll(mask);
-                }
-            }
-            const int64_t padv = partial ? -1 : (cnt ? first : 0);
-            for (int s = min(cnt, nsample) + lane; s < nsample; s += 64) {
-                io[s] = padv;
-                dd[s] = -1.0f;
-            }
-        } else {
-            // selection of the nsample smallest (d, id): pass s finds the smallest pair greater than the previous
-            float pd = -1.0f;
-            int pi = -1;
-            int emitted = 0;
-            int64_t firstv = padv_empty;
-            for (; emitted < nsample; ++emitted) {
-                float bd = 3.0e38f;
-                int bi = 0x7fffffff;
-                for (int st = 0; st < L; st += 64) {
-                    const int k = st + lane;
-                    if (k < L) {
-                        const float d = sqdist3(x[(lo + k) * 3 + 0], x[(lo + k) * 3 + 1], x[(lo + k) * 3 + 2], qx, qy, qz);
-                        const bool after = d > pd || (d == pd && k > pi);
-                        if (d < r2 && after && (d < bd || (d == bd && k < bi))) {
-                            bd = d;
-                            bi = k;
-                        }
-                    }
-                }
-#pragma unroll
-                for (int off = 32; off >= 1; off >>= 1) {
-                    const float od = __shfl_xor(bd, off);
-                    const int oi = __shfl_xor(bi, off);
-                    if (od < bd || (od == bd && oi < bi)) {
-                        bd = od;
-                        bi = oi;
-                    }
-                }
-                if (bi == 0x7fffffff) break;
-                if (lane == 0) {
-                    io[emitted] = goff + bi;
-                    dd[emitted] = bd;
-                }
-                if (emitted == 0) firstv = goff + bi;
-                pd = bd;
-                pi = bi;
-            }
-            const int64_t padv = partial ? -1 : firstv;
-            for (int s = emitted + lane; s < nsample; s += 64) {
-                io[s] = padv;
-                dd[s] = -1.0f;
-            }
-        }
+        grid_query_overflow(x, lo, L, qx, qy, qz, r2, nsample, sort, partial, goff, io, dd);
         return;
     }
+    if (!sort && lane < 4) cid[h + lane] = 0x7fffffff;  // the index ranking reads four ids at a time
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_wave_barrier();
     // ---- rank the h candidates: by index (sort=0) or by (distance, index) (sort=1); emit ranks < nsample
     int64_t firstv = padv_empty;
-    for (int t = lane; t < ((h + 63) & ~63); t += 64) {
-        const bool have = t < h;
-        const int mi = have ? cid[t] : 0x7fffffff;
-        const float md = have ? cd[t] : 3.0e38f;
-        int rank = 0;
-        if (!sort) {
-            for (int u = 0; u < h; ++u) rank += (cid[u] < mi) ? 1 : 0;
-        } else {
+    if (!sort) {
+        // two candidates per lane and four ids per LDS read: the kernel is bound by the VALU instructions it issues, and
+        // a ball of 65..128 hits (the common case at nsample 64) would otherwise walk the list twice
+        for (int t0 = 0; t0 < h; t0 += 128) {
+            const int ta = t0 + lane, tb = ta + 64;
+            const bool ha = ta < h, hb = tb < h, two = t0 + 64 < h;
+            const int ma = ha ? cid[ta] : 0x7fffffff, mb = hb ? cid[tb] : 0x7fffffff;
+            int ra = 0, rb = 0;
+            if (two) {
+                for (int u = 0; u < h; u += 4) {
+                    const int4 v = *reinterpret_cast<const int4 *>(&cid[u]);
+                    ra += (v.x < ma ? 1 : 0) + (v.y < ma ? 1 : 0) + (v.z < ma ? 1 : 0) + (v.w < ma ? 1 : 0);
+                    rb += (v.x < mb ? 1 : 0) + (v.y < mb ? 1 : 0) + (v.z < mb ? 1 : 0) + (v.w < mb ? 1 : 0);
+                }
+            } else {
+                for (int u = 0; u < h; u += 4) {
+                    const int4 v = *reinterpret_cast<const int4 *>(&cid[u]);
+                    ra += (v.x < ma ? 1 : 0) + (v.y < ma ? 1 : 0) + (v.z < ma ? 1 : 0) + (v.w < ma ? 1 : 0);
+                }
+            }
+            if (ha && ra < nsample) {
+                io[ra] = goff + ma;
+                dd[ra] = cd[ta];
+            }
+            if (hb && rb < nsample) {
+                io[rb] = goff + mb;
+                dd[rb] = cd[tb];
+            }
+            const unsigned long long za = __ballot(ha && ra == 0), zb = __ballot(hb && rb == 0);
+            if (za) firstv = goff + __shfl(ma, __builtin_ctzll(za));
+            if (zb) firstv = goff + __shfl(mb, __builtin_ctzll(zb));
+        }
+    } else {
+        for (int t = lane; t < ((h + 63) & ~63); t += 64) {
+            const bool have = t < h;
+            const int mi = have ? cid[t] : 0x7fffffff;
+            const float md = have ? cd[t] : 3.0e38f;
+            int rank = 0;
             for (int u = 0; u < h; ++u) {
                 const float ud = cd[u];
                 const int ui = cid[u];
                 rank += (ud < md || (ud == md && ui < mi)) ? 1 : 0;
             }
+            if (have && rank < nsample) {
+                io[rank] = goff + mi;
+                dd[rank] = md;
+            }
+            const unsigned long long zero = __ballot(have && rank == 0);
+            if (zero) firstv = goff + __shfl(mi, __builtin_ctzll(zero));
         }
-        if (have && rank < nsample) {
-            io[rank] = goff + mi;
-            dd[rank] = md;
-        }
-        const unsigned long long zero = __ballot(have && rank == 0);
-        if (zero) firstv = goff + __shfl(mi, __builtin_ctzll(zero));
     }
     const int64_t padv = partial ? -1 : firstv;
     for (int s = min(h, nsample) + lane; s < nsample; s += 64) {
@@ -575,6 +714,25 @@ int grid_build(const float *x, const int64_t *seg, int num_clouds, int64_t rows,
         const size_t lds = (((size_t)G * G * G * 4 + 15) & ~(size_t)15) + (size_t)Lmax * 2;
         static bool attr_set[64] = {false};
         allow_large_dynamic_lds(reinterpret_cast<const void *>(&grid_build_kernel), (int)GRID_LDS_BUDGET, attr_set);
+        if (Lmax <= GB_BLOCK * 16) {
+            const size_t lds_reg = (size_t)G * G * G * 4;
+#define TP3D_BUILD_REG(PT)                                                                                            \
+    do {                                                                                                              \
+        static bool set_##PT[64] = {false};                                                                           \
+        allow_large_dynamic_lds(reinterpret_cast<const void *>(&grid_build_reg_kernel<PT>), (int)GRID_LDS_BUDGET,     \
+                                set_##PT);                                                                            \
+        hipLaunchKernelGGL(grid_build_reg_kernel<PT>, dim3(num_clouds, 8), dim3(GB_BLOCK), lds_reg, s, x, seg, N, cell, \
+                           target, G, w.info, w.cell_start, w.sorted_pt);                                             \
+    } while (0)
+            if (Lmax <= GB_BLOCK * 4)
+                TP3D_BUILD_REG(4);
+            else if (Lmax <= GB_BLOCK * 8)
+                TP3D_BUILD_REG(8);
+            else
+                TP3D_BUILD_REG(16);
+#undef TP3D_BUILD_REG
+            return check_launch();
+        }
         hipLaunchKernelGGL(grid_build_kernel, dim3(num_clouds), dim3(GB_BLOCK), lds, s, x, seg, N, cell, target, G, w.info,
                            w.cell_start, w.sorted_pt);
         return check_launch();
