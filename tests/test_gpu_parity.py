@@ -76,7 +76,8 @@ def test_ball_query_dense_bit_exact(hip, oracle, B, N, npnt, r, ns, kind, sort):
     assert torch.equal(gd.cpu(), rd)  # same fp32 evaluation order: exact
 
 
-@pytest.mark.parametrize("case", ["chunk_tail", "one_query", "same_place", "planar", "dense_ball", "zero_radius", "far_apart"])
+@pytest.mark.parametrize("case", ["chunk_tail", "one_query", "same_place", "planar", "dense_ball", "zero_radius", "far_apart",
+                                  "one_cell", "slot_limit"])
 def test_ball_query_dense_edge_geometries(hip, oracle, case):
     """Unsorted dense queries at set-abstraction sizes on the geometries that stress a grid search: a cloud one point past
     a 1024 boundary, a single centre, coincident centres, a planar cloud, saturated and empty balls, centres far outside
@@ -102,6 +103,13 @@ def test_ball_query_dense_edge_geometries(hip, oracle, case):
         ns = 16
     elif case == "zero_radius":
         r = 0.0
+    elif case == "one_cell":  # the whole cloud on one point: a grid of a single cell, most cell slabs of the build empty
+        x = x[:, :1].expand(B, N, 3).contiguous()
+        y = x[:, :npnt].contiguous()
+    elif case == "slot_limit":  # balls of 150..1000 hits, 45 % above the per-query hit slots of the grid search (640)
+        x = x * 0.5
+        r = 0.36
+        y = x[:, :npnt].contiguous()
     else:  # centres far outside the cloud's box and from each other
         y = (torch.rand(B, npnt, 3, generator=g) * 2 - 1) * 40
         y[:, :8] = x[:, :8]

@@ -67,16 +67,9 @@ __device__ __forceinline__ void grid_scan_cells(int *cnt, int *cs_out, int nused
     }
     if (lane == 63) s_scan[wave] = incl;
     __syncthreads();
-    if (tid == 0) {
-        int run = 0;
-        for (int w = 0; w < GB_BLOCK / 64; ++w) {
-            const int v = s_scan[w];
-            s_scan[w] = run;
-            run += v;
-        }
-    }
-    __syncthreads();
-    int run = base + s_scan[wave] + incl - sum;
+    int run = base + incl - sum;
+#pragma unroll
+    for (int w = 0; w < GB_BLOCK / 64; ++w) run += (w < wave) ? s_scan[w] : 0;  // the waves in front
     for (int k = k0; k < k1; ++k) {
         const int v = cnt[k];
         cnt[k] = run;
@@ -105,20 +98,24 @@ __device__ __forceinline__ void grid_box_to_info(float mn[3], float mx[3], int L
             s_red[3 + a][wave] = mx[a];
         }
     __syncthreads();
-    if (tid == 0) {
+    if (wave == 0) {  // the GB_BLOCK / 64 = 16 wave results, one per lane of a 16-lane row
         float lo3[3], hi3[3];
+#pragma unroll
         for (int a = 0; a < 3; ++a) {
-            lo3[a] = s_red[a][0];
-            hi3[a] = s_red[3 + a][0];
-            for (int w = 1; w < GB_BLOCK / 64; ++w) {
-                lo3[a] = fminf(lo3[a], s_red[a][w]);
-                hi3[a] = fmaxf(hi3[a], s_red[3 + a][w]);
+            lo3[a] = s_red[a][lane & (GB_BLOCK / 64 - 1)];
+            hi3[a] = s_red[3 + a][lane & (GB_BLOCK / 64 - 1)];
+#pragma unroll
+            for (int off = GB_BLOCK / 128; off >= 1; off >>= 1) {
+                lo3[a] = fminf(lo3[a], __shfl_xor(lo3[a], off));
+                hi3[a] = fmaxf(hi3[a], __shfl_xor(hi3[a], off));
             }
         }
         if (L == 0) lo3[0] = lo3[1] = lo3[2] = hi3[0] = hi3[1] = hi3[2] = 0.0f;
         const GridInfo gi = make_grid_info(lo3, hi3, L, radius, target, G);
-        *s_info = gi;
-        *out = gi;
+        if (lane == 0) {
+            *s_info = gi;
+            *out = gi;
+        }
     }
     __syncthreads();
 }
