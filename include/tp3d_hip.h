@@ -35,7 +35,7 @@ extern "C" {
 #define TP3D_E_UNSORTED (-3) /* reserved: batch vector not sorted (checked by the host wrapper) */
 #define TP3D_E_TOOBIG (-4)   /* size exceeds what the kernel's index arithmetic supports */
 
-#define TP3D_ABI_VERSION 24
+#define TP3D_ABI_VERSION 25
 
 int tp3d_abi_version(void);
 const char *tp3d_strerror(int code);
@@ -206,6 +206,18 @@ int tp3d_gemm_rows_f32(const float *A, const float *Bt, int64_t M, int N, int K,
  * K <= 1536. */
 int tp3d_gemm_rows_bnact_f32(const float *Y, const float *mean, const float *scale, const float *beta, float slope,
                              const float *Bt, int64_t M, int N, int K, float *C, float *stat_partial, void *stream);
+/* The same fused contraction on the split-role kernel (csrc/gemm_rows_sp.hip: four MFMA waves fed by four loader waves
+ * that apply the prologue on their way into LDS, so it costs the MFMA waves nothing).  act_out != NULL additionally
+ * receives the activated rows (M,K) the backward pass of the next layer contracts with (training); stat_partial as for
+ * tp3d_gemm_rows_f32 but with tp3d_gemm_rows_sp_chunks(M, N, K) chunks of 4 * N floats.  Shapes: K % 4 == 0,
+ * 4 <= K <= 512, N % 128 not in 1..64, N <= 1024 in 1, 2, 4 or 8 column tiles, at least 512 output tiles --
+ * tp3d_gemm_rows_sp_chunks returns 0 for a shape that is not served (TP3D_E_BADARG from the launch).
+ * Replaces the Conv2d -> BatchNorm2d -> LeakyReLU hand-over between two layers of MLP2D
+ * (core/common_modules/dense_modules.py:25-29). */
+int tp3d_gemm_rows_sp_chunks(int64_t M, int N, int K);
+int tp3d_gemm_rows_bnact_sp_f32(const float *Y, const float *mean, const float *scale, const float *beta, float slope,
+                                const float *Bt, int64_t M, int N, int K, float *C, float *stat_partial, float *act_out,
+                                void *stream);
 /* Input-gradient GEMM of a layer with its BatchNorm + activation BACKWARD applied to the A operand while it is staged:
  *   C[M,N] = dY[M,K] * Bt[N,K]^T,  dY = scale*(dZ - c1 - (Y - mean)*c2),  dZ = dA * act'((Y - mean)*scale + beta)
  * Y (M,K) pre-BatchNorm output of the layer, dA (M,K) gradient of its activated output -- or, with argmax != NULL, the

@@ -465,9 +465,12 @@ def test_rows_mlp_with_linear_bias_matches_modules(train):
 
 
 @pytest.mark.parametrize("pool_ns", [0, 16])
-@pytest.mark.parametrize("widths", [[8, 64, 64, 128], [132, 128, 128, 256], [12, 32, 96, 196], [260, 64]])
+@pytest.mark.parametrize("widths,M,loader", [([8, 64, 64, 128], 4000, False), ([132, 128, 128, 256], 4000, False),
+                                             ([12, 32, 96, 196], 4000, False), ([260, 64], 4000, False),
+                                             ([8, 64, 64, 128], 4000, True), ([132, 128, 128, 256], 4000, True),
+                                             ([12, 64, 128, 256, 132, 128], 66000, True)])
 @pytest.mark.parametrize("train", [True, False])
-def test_mlp_chain_matches_layerwise_path(widths, pool_ns, train):
+def test_mlp_chain_matches_layerwise_path(widths, M, loader, pool_ns, train):
     """The fused layer chain (BatchNorm / activation folded into the GEMM prologues, statistics in the epilogues,
     dY and the activated inputs never written) against the layer-by-layer kernels it replaces: same outputs, same
     gradients for the input rows and every parameter, same running statistics."""
@@ -486,26 +489,81 @@ def test_mlp_chain_matches_layerwise_path(widths, pool_ns, train):
     twin = copy.deepcopy(mlp)
     mlp.train(train)
     twin.train(train)
-    M = 4000 if pool_ns == 0 else 250 * pool_ns + 0
+    # loader: hidden BatchNorm + activation in the loader waves of the split-role GEMM (the 66000-row case is large enough
+    # for that kernel: 128-, 256- and 128-column outputs on it, the 64- and 132-column ones on the separate pass)
     rows = torch.randn(M, widths[0], generator=torch.Generator().manual_seed(5)).to(DEV)
     ra, rb = rows.clone().requires_grad_(True), rows.clone().requires_grad_(True)
     cot = torch.randn((M // pool_ns) if pool_ns else M, widths[-1], generator=torch.Generator().manual_seed(6)).to(DEV)
-    old = fused.CHAIN_MIN_ROWS, fused.USE_MLP_CHAIN
+    old = fused.CHAIN_MIN_ROWS, fused.USE_MLP_CHAIN, fused.CHAIN_LOADER
     try:
-        fused.CHAIN_MIN_ROWS, fused.USE_MLP_CHAIN = 0, True
+        fused.CHAIN_MIN_ROWS, fused.USE_MLP_CHAIN, fused.CHAIN_LOADER = 0, True, loader
         assert fused._chain_ok(ra, fused.mlp_parts(mlp))
         out = fused.run_mlp(ra, fused.mlp_parts(mlp), pool_ns)
         fused.USE_MLP_CHAIN = False
         want = fused.run_mlp(rb, fused.mlp_parts(twin), pool_ns)
     finally:
-        fused.CHAIN_MIN_ROWS, fused.USE_MLP_CHAIN = old
+        fused.CHAIN_MIN_ROWS, fused.USE_MLP_CHAIN, fused.CHAIN_LOADER = old
     torch.testing.assert_close(out, want, rtol=1e-5, atol=1e-5)
     out.backward(cot)
     want.backward(cot)
     # a LeakyReLU mask can flip on a last-bit forward difference between the two paths (different GEMM kernels for the
-    # narrow layers): bound the bulk tightly, allow isolated outliers through the L2 norm
-    assert float((ra.grad - rb.grad).norm() / rb.grad.norm()) < 1e-3
+    # narrow layers, another partition of the statistics chunks): bound the bulk tightly, allow isolated outliers through
+    # the L2 norm (the five-layer 66000-row case has 16 times the elements that can flip)
+    bound = 1e-3 if M <= 4000 else 3e-3
+    assert float((ra.grad - rb.grad).norm() / rb.grad.norm()) < bound
     for (k, a), (_, b) in zip(mlp.named_parameters(), twin.named_parameters()):
-        assert float((a.grad - b.grad).norm() / (b.grad.norm() + 1e-12)) < 1e-3, k
+        assert float((a.grad - b.grad).norm() / (b.grad.norm() + 1e-12)) < bound, k
     for (k, a), (_, b) in zip(mlp.state_dict().items(), twin.state_dict().items()):
         torch.testing.assert_close(a.float(), b.float(), rtol=1e-5, atol=1e-6, msg=lambda m, k=k: k + ": " + m)
+
+
+@pytest.mark.parametrize("M,N,K", [(66000, 128, 128), (65537, 256, 132), (131072, 128, 64), (70000, 512, 36), (66000, 224, 8)])
+def test_split_role_gemm_applies_the_previous_layers_batchnorm(M, N, K):
+    """tp3d_gemm_rows_bnact_sp_f32 against the two kernels it stands for (tp3d_bn_act_f32, then tp3d_gemm_rows_f32): the
+    same output, the activated rows as side output bit for bit, statistics chunks that finalize to the statistics of the
+    output; ragged row counts, a contraction tail, one to four column tiles."""
+    from torch_points3d_amd import _lib, fused
+    h = _lib.load()
+    g = torch.Generator().manual_seed(M + N + K)
+    Y = (torch.randn(M, K, generator=g) * 2 + 0.3).to(DEV)
+    Bt = (torch.randn(N, K, generator=g) * 0.2).to(DEV)
+    mean, scale, beta = (torch.randn(K, generator=g) * 0.2).to(DEV), (torch.rand(K, generator=g) + 0.5).to(DEV), \
+        (torch.randn(K, generator=g) * 0.3).to(DEV)
+    chunks = h.tp3d_gemm_rows_sp_chunks(M, N, K)
+    assert chunks == 2 * 512 // ((N + 127) // 128)
+    st = _lib.stream_ptr(Y.device)
+    act_ref = torch.empty_like(Y)
+    _lib.call("tp3d_bn_act_f32", _lib.ptr(Y), _lib.ptr(mean), _lib.ptr(scale), _lib.ptr(beta), 0.01, M, K, _lib.ptr(act_ref), st)
+    ref = fused.gemm_rows(act_ref, Bt)[0]
+    out = torch.full((M, N), float("nan"), device=DEV)
+    act = torch.full((M, K), float("nan"), device=DEV)
+    part = torch.full((chunks * 4 * N + 64,), float("nan"), device=DEV)
+    _lib.call("tp3d_gemm_rows_bnact_sp_f32", _lib.ptr(Y), _lib.ptr(mean), _lib.ptr(scale), _lib.ptr(beta), 0.01, _lib.ptr(Bt), M, N, K,
+              _lib.ptr(out), _lib.ptr(part), _lib.ptr(act), st)
+    assert torch.equal(act, act_ref)
+    # (close, not equal: the plain kernel is free to pick another tile shape, i.e. another summation grouping)
+    torch.testing.assert_close(out, ref, rtol=1e-5, atol=1e-5 * float(ref.abs().max()))
+    assert bool(torch.isnan(part[chunks * 4 * N:]).all()) and not bool(torch.isnan(part[:chunks * 4 * N]).any())
+    bn = torch.nn.BatchNorm1d(N).to(DEV)
+    stats = fused._finalize_stats(part, M, N, bn.weight.detach(), bn.bias.detach(), bn, Y.device, st, chunks)
+    torch.cuda.synchronize()
+    o64 = out.double()
+    std = o64.std(0, unbiased=False)
+    assert float(((stats[0].double() - o64.mean(0)).abs() / std).max()) < 1e-5
+    torch.testing.assert_close(stats[1].double(), 1.0 / torch.sqrt(o64.var(0, unbiased=False) + bn.eps), rtol=2e-5, atol=0)
+    # without statistics and without the side output: the same product
+    out2 = torch.empty_like(out)
+    _lib.call("tp3d_gemm_rows_bnact_sp_f32", _lib.ptr(Y), _lib.ptr(mean), _lib.ptr(scale), _lib.ptr(beta), 0.01, _lib.ptr(Bt), M, N, K,
+              _lib.ptr(out2), None, None, st)
+    assert torch.equal(out2, out)
+
+
+def test_split_role_gemm_declines_shapes_it_does_not_serve():
+    from torch_points3d_amd import _lib
+    h = _lib.load()
+    for M, N, K in [(4096, 128, 128), (66000, 64, 64), (66000, 320, 64), (66000, 128, 516), (66000, 128, 6), (66000, 384, 64)]:
+        assert h.tp3d_gemm_rows_sp_chunks(M, N, K) == 0, (M, N, K)
+    with pytest.raises(_lib.Tp3dError):
+        t = torch.zeros(4096, 128, device=DEV)
+        _lib.call("tp3d_gemm_rows_bnact_sp_f32", _lib.ptr(t), _lib.ptr(t), _lib.ptr(t), _lib.ptr(t), 0.01, _lib.ptr(t), 4096, 128, 128,
+                  _lib.ptr(t), None, None, _lib.stream_ptr(t.device))

@@ -39,8 +39,42 @@ def build():
     return ctypes.CDLL(out)
 
 
+def prologue_cases(lib):
+    """BatchNorm + LeakyReLU between two layers: separate pass + plain GEMM (shipped), the prologue GEMM of the fused chain
+    (registers of the MFMA waves), the prologue in the loader waves of the split-role kernel."""
+    g = lib.tp3d_gemm_rows_sp_bnact_f32
+    g.restype = ctypes.c_int
+    g.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_float, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_int,
+                                          ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+    for M, N, K in [(524288, 128, 128), (262144, 256, 128), (1048576, 128, 64), (262144, 128, 128), (65536, 512, 256)]:
+        Y = torch.randn(M, K, device=DEV)
+        Bt = torch.randn(N, K, device=DEV) * 0.1
+        mean, scale, beta = torch.randn(K, device=DEV) * 0.1, torch.rand(K, device=DEV) + 0.5, torch.randn(K, device=DEV) * 0.1
+        act = torch.empty_like(Y)
+        C0, C1, C2 = (torch.empty(M, N, device=DEV) for _ in range(3))
+        st = _lib.stream_ptr(Y.device)
+
+        def separate():
+            _lib.call("tp3d_bn_act_f32", Y.data_ptr(), mean.data_ptr(), scale.data_ptr(), beta.data_ptr(), 0.01, M, K, act.data_ptr(), st)
+            _lib.call("tp3d_gemm_rows_f32", act.data_ptr(), Bt.data_ptr(), M, N, K, C0.data_ptr(), None, None, st)
+
+        def chain():
+            _lib.call("tp3d_gemm_rows_bnact_f32", Y.data_ptr(), mean.data_ptr(), scale.data_ptr(), beta.data_ptr(), 0.01, Bt.data_ptr(),
+                      M, N, K, C1.data_ptr(), None, st)
+
+        def split():
+            rc = g(Y.data_ptr(), mean.data_ptr(), scale.data_ptr(), beta.data_ptr(), 0.01, Bt.data_ptr(), M, N, K, C2.data_ptr(), 512, st)
+            assert rc == 0, rc
+        separate(), chain(), split()
+        e1, e2 = float((C1 - C0).abs().max()), float((C2 - C0).abs().max())
+        ts, tc, tp_ = timeit(separate), timeit(chain), timeit(split)
+        print("M=%7d N=%3d K=%3d  pass + GEMM %7.1f us | prologue in the MFMA waves %7.1f us (diff %.1e) | in the loader waves "
+              "%7.1f us (diff %.1e)" % (M, N, K, ts, tc, e1, tp_, e2), flush=True)
+
+
 def main():
-    f = build().tp3d_gemm_rows_sp_f32
+    lib = build()
+    f = lib.tp3d_gemm_rows_sp_f32
     f.restype = ctypes.c_int
     f.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int,
                   ctypes.c_int, ctypes.c_void_p]
@@ -72,11 +106,6 @@ def main():
             t = timeit(run)
             line += "  split grid %d %7.1f us %6.1f TF (max diff %.1e)" % (grid, t, 2.0 * M * N * K / t / 1e6, err)
         print(line, flush=True)
-        line = "    staggered starts (grid 512, eight phases; time, and time less the longest delay):"
-        for ticks in (50, 100, 200, 400):
-            t = timeit(lambda: f(A.data_ptr(), Bt.data_ptr(), M, N, K, C.data_ptr(), 512, ticks << 8, _lib.stream_ptr(A.device)))
-            line += "  %4.1f us/phase %7.1f / %7.1f us" % (ticks * 0.01, t, t - 7 * ticks * 0.01)
-        print(line, flush=True)
         line = "    what bounds it (grid 512):"
         for probe, what in ((1, "input from cache"), (2, "no stores"), (3, "neither")):
             t = timeit(lambda: f(A.data_ptr(), Bt.data_ptr(), M, N, K, C.data_ptr(), 512, probe, _lib.stream_ptr(A.device)))
@@ -86,3 +115,4 @@ def main():
 
 if __name__ == "__main__":
     main()
+    prologue_cases(build())

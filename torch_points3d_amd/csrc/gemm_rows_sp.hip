@@ -1,13 +1,15 @@
-// Rows GEMM with SPLIT ROLES: C[M,N] = A[M,K] * Bt[N,K]^T (fp32 MFMA), the same contraction as gemm_rows.hip.
+// Rows GEMM with SPLIT ROLES and the BatchNorm + LeakyReLU of the PREVIOUS layer applied on the way in:
+//   C[M,N] = leaky((Y[M,K] - mean) * scale + beta) * Bt[N,K]^T      (fp32 MFMA; the contraction of gemm_rows.hip)
 //
 // A workgroup is 8 waves: waves 0-3 only issue MFMAs (2 x 2 waves, each 2 x 2 tiles of 32 x 32: a 128 x 128 output tile),
-// waves 4-7 only move data -- global loads two K-steps ahead into registers, then LDS writes into the buffer the compute
-// waves will read NEXT step.  Two LDS buffers, ONE barrier per K-step, persistent workgroups over (row block, column tile)
-// items.  In gemm_rows.hip every wave does both jobs in turn: all four waves of a workgroup wait for their loads
-// (`vmcnt(0)`), write LDS, meet at a barrier and only then start their MFMAs, so the matrix pipe idles for a third of
-// every step; here a compute wave's step is fragment reads + 64 MFMAs + one barrier that the loader waves have usually
-// reached long before.  (The loaders share the SIMDs with the compute waves: VALU / memory instructions of one wave
-// issue beside the MFMAs of another.)
+// waves 4-7 only move data -- global loads two K-steps ahead into registers, the per-channel affine + activation on those
+// registers, LDS writes into the buffer the compute waves read NEXT step, and (training) the activated rows as a side
+// output for the weight-gradient pass.  Two LDS buffers, ONE barrier per K-step, persistent workgroups over
+// (row block, column tile) items.  As a plain GEMM this layout is on par with gemm_rows.hip (tools/probes/gemm_sp.py);
+// what it buys is that the prologue costs the MFMA waves nothing: in gemm_rows.hip's prologue variants every wave does
+// both jobs, the constants and the second operand push it to 230-256 VGPRs and the MFMA rate drops to 50-67 TFLOP/s,
+// while here the activated layer input is formed in registers the MFMA waves never see (524288 x 128 x 128: separate
+// BatchNorm pass + GEMM 306 us, prologue in the MFMA waves 283 us, in the loader waves 203 us; bit-identical results).
 #include "tp3d_common.h"
 
 namespace tp3d {
@@ -36,8 +38,8 @@ struct SpPro {
 template <int STATS, int PRO>
 __global__ __launch_bounds__(SP_BLOCK, 4) void gemm_rows_sp_kernel(const float *__restrict__ A, const float *__restrict__ Bt,
                                                                 int64_t M, int N, int K, int tiles_n, int64_t items,
-                                                                float *__restrict__ C, float *__restrict__ partial, int probe,
-                                                                SpPro pro)
+                                                                float *__restrict__ C, float *__restrict__ partial,
+                                                                float *__restrict__ act_out, SpPro pro)
 {
     __shared__ __attribute__((aligned(16))) float sK[PRO ? 3 * SP_PRO_KMAX : 4];
     if (PRO) {
@@ -47,9 +49,6 @@ __global__ __launch_bounds__(SP_BLOCK, 4) void gemm_rows_sp_kernel(const float *
             sK[2 * SP_PRO_KMAX + k] = k < K ? pro.beta[k] : 0.0f;
         }
     }
-    // probe (experiments only): bit 0 reads A rows modulo 8192 (cache-resident input), bit 1 skips the stores of C
-    const int64_t a_wrap = (probe & 1) ? 8191 : ~(int64_t)0;
-    const bool put = !(probe & 2);
     __shared__ __attribute__((aligned(16))) float sA[2][SP_TILE];
     __shared__ __attribute__((aligned(16))) float sB[2][SP_TILE];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -92,10 +91,10 @@ __global__ __launch_bounds__(SP_BLOCK, 4) void gemm_rows_sp_kernel(const float *
     do {                                                                                                              \
         m0_##S = f_m0, n0_##S = f_n0, k0_##S = f_ks * SP_BK;                                                          \
         const int kk = min(k0_##S + fk4, K - 4);                                                                      \
-        a0_##S = *reinterpret_cast<const float4 *>(A + (min(f_m0 + frow + 0, M - 1) & a_wrap) * K + kk);                         \
-        a1_##S = *reinterpret_cast<const float4 *>(A + (min(f_m0 + frow + 32, M - 1) & a_wrap) * K + kk);                        \
-        a2_##S = *reinterpret_cast<const float4 *>(A + (min(f_m0 + frow + 64, M - 1) & a_wrap) * K + kk);                        \
-        a3_##S = *reinterpret_cast<const float4 *>(A + (min(f_m0 + frow + 96, M - 1) & a_wrap) * K + kk);                        \
+        a0_##S = *reinterpret_cast<const float4 *>(A + min(f_m0 + frow + 0, M - 1) * K + kk);                         \
+        a1_##S = *reinterpret_cast<const float4 *>(A + min(f_m0 + frow + 32, M - 1) * K + kk);                        \
+        a2_##S = *reinterpret_cast<const float4 *>(A + min(f_m0 + frow + 64, M - 1) * K + kk);                        \
+        a3_##S = *reinterpret_cast<const float4 *>(A + min(f_m0 + frow + 96, M - 1) * K + kk);                        \
         b0_##S = *reinterpret_cast<const float4 *>(Bt + (size_t)min(f_n0 + frow + 0, N - 1) * K + kk);                \
         b1_##S = *reinterpret_cast<const float4 *>(Bt + (size_t)min(f_n0 + frow + 32, N - 1) * K + kk);               \
         b2_##S = *reinterpret_cast<const float4 *>(Bt + (size_t)min(f_n0 + frow + 64, N - 1) * K + kk);               \
@@ -109,18 +108,26 @@ __global__ __launch_bounds__(SP_BLOCK, 4) void gemm_rows_sp_kernel(const float *
             f_n0 = (rem >> 3) * SP_BN;                                                                                \
         }                                                                                                             \
     } while (0)
+#define SP_STASH_A(S, BUF, I)                                                                                         \
+    do {                                                                                                              \
+        const bool in = kin && m0_##S + frow + 32 * I < M;                                                            \
+        const float4 v = sp_keep(in, PRO ? act4(a##I##_##S, k0_##S + fk4) : a##I##_##S);                              \
+        *reinterpret_cast<float4 *>(da + I * 32 * SP_LD) = v;                                                         \
+        if (side && in) *reinterpret_cast<float4 *>(act_out + (m0_##S + frow + 32 * I) * K + k0_##S + fk4) = v;       \
+    } while (0)
 #define SP_STASH(S, BUF)                                                                                              \
     do {                                                                                                              \
         const bool kin = k0_##S + fk4 < K;                                                                            \
+        const bool side = act_out != nullptr && n0_##S == 0; /* one column tile of a row block writes the side rows */ \
         float *da = &sA[BUF][frow * SP_LD + fk4], *db = &sB[BUF][frow * SP_LD + fk4];                                 \
-        *reinterpret_cast<float4 *>(da + 0 * 32 * SP_LD) = sp_keep(kin && m0_##S + frow + 0 < M, PRO ? act4(a0_##S, k0_##S + fk4) : a0_##S);           \
-        *reinterpret_cast<float4 *>(da + 1 * 32 * SP_LD) = sp_keep(kin && m0_##S + frow + 32 < M, PRO ? act4(a1_##S, k0_##S + fk4) : a1_##S);          \
-        *reinterpret_cast<float4 *>(da + 2 * 32 * SP_LD) = sp_keep(kin && m0_##S + frow + 64 < M, PRO ? act4(a2_##S, k0_##S + fk4) : a2_##S);          \
-        *reinterpret_cast<float4 *>(da + 3 * 32 * SP_LD) = sp_keep(kin && m0_##S + frow + 96 < M, PRO ? act4(a3_##S, k0_##S + fk4) : a3_##S);          \
-        *reinterpret_cast<float4 *>(db + 0 * 32 * SP_LD) = sp_keep(kin && n0_##S + frow + 0 < N, b0_##S);           \
-        *reinterpret_cast<float4 *>(db + 1 * 32 * SP_LD) = sp_keep(kin && n0_##S + frow + 32 < N, b1_##S);          \
-        *reinterpret_cast<float4 *>(db + 2 * 32 * SP_LD) = sp_keep(kin && n0_##S + frow + 64 < N, b2_##S);          \
-        *reinterpret_cast<float4 *>(db + 3 * 32 * SP_LD) = sp_keep(kin && n0_##S + frow + 96 < N, b3_##S);          \
+        SP_STASH_A(S, BUF, 0);                                                                                        \
+        SP_STASH_A(S, BUF, 1);                                                                                        \
+        SP_STASH_A(S, BUF, 2);                                                                                        \
+        SP_STASH_A(S, BUF, 3);                                                                                        \
+        *reinterpret_cast<float4 *>(db + 0 * 32 * SP_LD) = sp_keep(kin && n0_##S + frow + 0 < N, b0_##S);             \
+        *reinterpret_cast<float4 *>(db + 1 * 32 * SP_LD) = sp_keep(kin && n0_##S + frow + 32 < N, b1_##S);            \
+        *reinterpret_cast<float4 *>(db + 2 * 32 * SP_LD) = sp_keep(kin && n0_##S + frow + 64 < N, b2_##S);            \
+        *reinterpret_cast<float4 *>(db + 3 * 32 * SP_LD) = sp_keep(kin && n0_##S + frow + 96 < N, b3_##S);            \
     } while (0)
         float4 a0_0, a1_0, a2_0, a3_0, b0_0, b1_0, b2_0, b3_0, a0_1, a1_1, a2_1, a3_1, b0_1, b1_1, b2_1, b3_1;
         int64_t m0_0, m0_1;
@@ -144,6 +151,7 @@ __global__ __launch_bounds__(SP_BLOCK, 4) void gemm_rows_sp_kernel(const float *
         }
 #undef SP_FETCH
 #undef SP_STASH
+#undef SP_STASH_A
         return;
     }
 
@@ -202,7 +210,7 @@ __global__ __launch_bounds__(SP_BLOCK, 4) void gemm_rows_sp_kernel(const float *
 #pragma unroll
                     for (int e = 0; e < 16; ++e) {
                         const int64_t m = m0 + (wr * 2 + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-                        if (put && m < M && n < N) C[m * N + n] = acc[i][j][e];
+                        if (m < M && n < N) C[m * N + n] = acc[i][j][e];
                     }
                 }
             if (STATS != 0) {
@@ -255,32 +263,47 @@ __global__ __launch_bounds__(SP_BLOCK, 4) void gemm_rows_sp_kernel(const float *
 
 }  // namespace tp3d
 
-// Experimental entry (tools/microbench.py): same contract as tp3d_gemm_rows_f32 without statistics; grid workgroups.
-TP3D_EXPORT int tp3d_gemm_rows_sp_f32(const float *A, const float *Bt, int64_t M, int N, int K, float *C, int grid,
-                                      int probe, void *stream)
+constexpr int SP_GRID = 512;  // persistent: two 8-wave workgroups per CU
+
+// The statistics chunks (and the kernel) need every workgroup to stay on one column tile: SP_GRID % (8 * tiles_n) == 0.
+// Not served (0): narrow outputs (a 128-column tile would be half empty -- gemm_rows.hip's 128 x 64 tiles are the better
+// kernel there), fewer items than workgroups, contractions longer than the constants' LDS table.
+static int sp_tiles_n(int64_t M, int N, int K)
 {
-    using namespace tp3d;
-    if (M <= 0 || N <= 0 || K < 4 || (K & 3) || !A || !Bt || !C || grid <= 0 || (grid & 7)) return TP3D_E_BADARG;
-    const int tiles_n = (N + SP_BN - 1) / SP_BN;
-    const int64_t row_blocks = (M + SP_BM - 1) / SP_BM;
-    const int64_t items = (row_blocks + 7) / 8 * 8 * tiles_n;
-    hipLaunchKernelGGL((gemm_rows_sp_kernel<0, 0>), dim3(grid), dim3(SP_BLOCK), 0, (hipStream_t)stream, A, Bt, M, N, K, tiles_n,
-                       items, C, (float *)nullptr, probe, SpPro{});
-    return check_launch();
+    if (M <= 0 || N <= 0 || K < 4 || (K & 3) || K > tp3d::SP_PRO_KMAX) return 0;
+    const int rem = N % tp3d::SP_BN;
+    if (rem > 0 && rem <= 64) return 0;
+    const int tiles_n = (N + tp3d::SP_BN - 1) / tp3d::SP_BN;
+    if (SP_GRID % (8 * tiles_n)) return 0;
+    const int64_t row_blocks = (M + tp3d::SP_BM - 1) / tp3d::SP_BM;
+    if ((row_blocks + 7) / 8 * 8 * tiles_n < SP_GRID) return 0;
+    return tiles_n;
 }
 
-// The same with the BatchNorm + LeakyReLU prologue of tp3d_gemm_rows_bnact_f32 in the loader waves (no statistics).
-TP3D_EXPORT int tp3d_gemm_rows_sp_bnact_f32(const float *Y, const float *mean, const float *scale, const float *beta,
-                                            float slope, const float *Bt, int64_t M, int N, int K, float *C, int grid,
-                                            void *stream)
+// Statistics chunks tp3d_gemm_rows_bnact_sp_f32 writes for (M, N, K) -- stat_partial holds chunks * 4 * N floats in the
+// layout tp3d_bn_finalize_f32 reads -- or 0 when the shape is not served by this kernel.
+TP3D_EXPORT int tp3d_gemm_rows_sp_chunks(int64_t M, int N, int K)
+{
+    const int tiles_n = sp_tiles_n(M, N, K);
+    return tiles_n ? 2 * (SP_GRID / tiles_n) : 0;
+}
+
+TP3D_EXPORT int tp3d_gemm_rows_bnact_sp_f32(const float *Y, const float *mean, const float *scale, const float *beta,
+                                            float slope, const float *Bt, int64_t M, int N, int K, float *C,
+                                            float *stat_partial, float *act_out, void *stream)
 {
     using namespace tp3d;
-    if (M <= 0 || N <= 0 || K < 4 || (K & 3) || K > SP_PRO_KMAX || !Y || !Bt || !C || grid <= 0 || (grid & 7)) return TP3D_E_BADARG;
-    const int tiles_n = (N + SP_BN - 1) / SP_BN;
+    const int tiles_n = sp_tiles_n(M, N, K);
+    if (!tiles_n || !Y || !mean || !scale || !beta || !Bt || !C) return TP3D_E_BADARG;
     const int64_t row_blocks = (M + SP_BM - 1) / SP_BM;
     const int64_t items = (row_blocks + 7) / 8 * 8 * tiles_n;
     SpPro pro{mean, scale, beta, slope};
-    hipLaunchKernelGGL((gemm_rows_sp_kernel<0, 1>), dim3(grid), dim3(SP_BLOCK), 0, (hipStream_t)stream, Y, Bt, M, N, K, tiles_n,
-                       items, C, (float *)nullptr, 0, pro);
+    hipStream_t s = (hipStream_t)stream;
+    if (stat_partial)
+        hipLaunchKernelGGL((gemm_rows_sp_kernel<2, 1>), dim3(SP_GRID), dim3(SP_BLOCK), 0, s, Y, Bt, M, N, K, tiles_n, items, C,
+                           stat_partial, act_out, pro);
+    else
+        hipLaunchKernelGGL((gemm_rows_sp_kernel<0, 1>), dim3(SP_GRID), dim3(SP_BLOCK), 0, s, Y, Bt, M, N, K, tiles_n, items, C,
+                           (float *)nullptr, act_out, pro);
     return check_launch();
 }

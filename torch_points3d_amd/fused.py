@@ -122,10 +122,12 @@ def gemm_rows(A, Bt, want_stats=False):
     return C, part
 
 
-def _finalize_stats(part, M, C, gamma, beta, bn, dev, st):
+def _finalize_stats(part, M, C, gamma, beta, bn, dev, st, chunks=None):
     """(4, C) = mean, invstd, scale, beta from the shifted partial sums a rows GEMM left in `part` (training mode)."""
     stats = torch.empty((4, C), dtype=torch.float32, device=dev)
-    _lib.call("tp3d_bn_finalize_f32", _lib.ptr(part), _lib.load().tp3d_gemm_rows_stat_chunks(M, C), M, C, float(bn.eps),
+    if chunks is None:
+        chunks = _lib.load().tp3d_gemm_rows_stat_chunks(M, C)
+    _lib.call("tp3d_bn_finalize_f32", _lib.ptr(part), chunks, M, C, float(bn.eps),
               float(bn.momentum), _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(bn.running_mean), _lib.ptr(bn.running_var),
               _lib.ptr(bn.num_batches_tracked), _lib.ptr(stats[0]), _lib.ptr(stats[1]), _lib.ptr(stats[2]), _lib.ptr(stats[3]), st)
     _note_training_pass(bn)
@@ -339,8 +341,9 @@ class _MLPChain(torch.autograd.Function):
         M = A0.shape[0]
         st = _lib.stream_ptr(dev)
         L = len(layers)
-        Ys, stats, W2s, cins = [], [], [], []
+        Ys, stats, W2s, cins, acts = [], [], [], [], []
         training = layers[0][0].training
+        keep_acts = CHAIN_LOADER and any(ctx.needs_input_grad)
         h = _lib.load()
         with _lib.on_device(dev):
             for l, (bn, slope) in enumerate(layers):
@@ -353,15 +356,37 @@ class _MLPChain(torch.autograd.Function):
                     W2 = torch.nn.functional.pad(W2, (0, Kp - W2.shape[1]))
                 W2 = W2.contiguous()
                 Y = torch.empty((M, Cout), dtype=torch.float32, device=dev)
-                part = _lib.workspace("gemm_rows_stats", 4 * h.tp3d_gemm_rows_stat_floats(M, Cout), dev) if training else None
+                sp_chunks = h.tp3d_gemm_rows_sp_chunks(M, Cout, Kp) if (l > 0 and CHAIN_LOADER) else 0
+                chunks = None
                 if l == 0:
+                    part = _lib.workspace("gemm_rows_stats", 4 * h.tp3d_gemm_rows_stat_floats(M, Cout), dev) if training else None
                     _lib.call("tp3d_gemm_rows_f32", _lib.ptr(A0), _lib.ptr(W2), M, Cout, Kp, _lib.ptr(Y), _lib.ptr(part), None, st)
+                elif sp_chunks:
+                    # the previous layer's BatchNorm + activation in the loader waves of the split-role kernel; with a
+                    # backward pass to come, the activated rows leave as a side output of the same kernel
+                    ps = stats[-1]
+                    part = _lib.workspace("gemm_rows_stats", 16 * sp_chunks * Cout, dev) if training else None
+                    act = torch.empty((M, Kp), dtype=torch.float32, device=dev) if keep_acts else None
+                    _lib.call("tp3d_gemm_rows_bnact_sp_f32", _lib.ptr(Ys[-1]), _lib.ptr(ps[0]), _lib.ptr(ps[2]), _lib.ptr(ps[3]),
+                              layers[l - 1][1], _lib.ptr(W2), M, Cout, Kp, _lib.ptr(Y), _lib.ptr(part), _lib.ptr(act), st)
+                    chunks = sp_chunks
+                    acts.append(act)
+                elif CHAIN_LOADER:
+                    # a width the split-role kernel does not serve: the separate pass, then the plain rows GEMM
+                    ps = stats[-1]
+                    act = torch.empty((M, Kp), dtype=torch.float32, device=dev)
+                    _lib.call("tp3d_bn_act_f32", _lib.ptr(Ys[-1]), _lib.ptr(ps[0]), _lib.ptr(ps[2]), _lib.ptr(ps[3]), layers[l - 1][1], M,
+                              Kp, _lib.ptr(act), st)
+                    part = _lib.workspace("gemm_rows_stats", 4 * h.tp3d_gemm_rows_stat_floats(M, Cout), dev) if training else None
+                    _lib.call("tp3d_gemm_rows_f32", _lib.ptr(act), _lib.ptr(W2), M, Cout, Kp, _lib.ptr(Y), _lib.ptr(part), None, st)
+                    acts.append(act if keep_acts else None)
                 else:
                     ps = stats[-1]
+                    part = _lib.workspace("gemm_rows_stats", 4 * h.tp3d_gemm_rows_stat_floats(M, Cout), dev) if training else None
                     _lib.call("tp3d_gemm_rows_bnact_f32", _lib.ptr(Ys[-1]), _lib.ptr(ps[0]), _lib.ptr(ps[2]), _lib.ptr(ps[3]),
                               layers[l - 1][1], _lib.ptr(W2), M, Cout, Kp, _lib.ptr(Y), _lib.ptr(part), st)
                 if training:
-                    stats.append(_finalize_stats(part, M, Cout, gamma, beta, bn, dev, st))
+                    stats.append(_finalize_stats(part, M, Cout, gamma, beta, bn, dev, st, chunks))
                 else:
                     stats.append(_bn_stats(Y, M, Cout, gamma, beta, bn, False, dev, st))
                 Ys.append(Y)
@@ -379,8 +404,10 @@ class _MLPChain(torch.autograd.Function):
                 out = torch.empty((M, C), dtype=torch.float32, device=dev)
                 _lib.call("tp3d_bn_act_f32", _lib.ptr(Y), _lib.ptr(ls[0]), _lib.ptr(ls[2]), _lib.ptr(ls[3]), slope, M, C,
                           _lib.ptr(out), st)
-        ctx.save_for_backward(A0, arg, *Ys, *stats, *W2s)
+        layerwise = keep_acts
+        ctx.save_for_backward(A0, arg, *Ys, *stats, *W2s, *(acts if layerwise else []))
         ctx.cfg = (L, pool_ns, training, [s_ for _, s_ in layers], [tuple(params[3 * l].shape) for l in range(L)], cins)
+        ctx.layerwise = layerwise
         return out
 
     @staticmethod
@@ -395,6 +422,28 @@ class _MLPChain(torch.autograd.Function):
         dcur = grad_out.contiguous()
         grads = [None] * (3 * L)
         dA0 = None
+        if ctx.layerwise:
+            # the activated rows were kept (side outputs of the forward kernels): the layer-wise backward passes
+            acts = saved[2 + 3 * L:2 + 3 * L + (L - 1)]
+            with _lib.on_device(dev):
+                for l in range(L - 1, -1, -1):
+                    Y, ls, W2, slope = Ys[l], stats[l], W2s[l], slopes[l]
+                    C, Kp = W2.shape
+                    pooled = bool(pool_ns) and l == L - 1
+                    dY = torch.empty_like(Y)
+                    dgb = torch.empty((2, C), dtype=torch.float32, device=dev)  # dbeta, dgamma
+                    ws = _lib.bn_workspace(M, C, dev)
+                    _lib.call("tp3d_bn_act_bwd_f32", _lib.ptr(dcur), _lib.ptr(arg) if pooled else None, _lib.ptr(Y), _lib.ptr(ls[2]),
+                              _lib.ptr(ls[3]), _lib.ptr(ls[0]), _lib.ptr(ls[1]), slope, M, pool_ns if pooled else 1, C,
+                              int(training), _lib.ptr(dgb[0]), _lib.ptr(dgb[1]), _lib.ptr(dY), _lib.ptr(ws), st)
+                    grads[3 * l + 1], grads[3 * l + 2] = dgb[1], dgb[0]
+                    if ctx.needs_input_grad[3 + 3 * l]:
+                        grads[3 * l] = gemm_tn(dY, A0 if l == 0 else acts[l - 1])[:, :cins[l]].reshape(wshapes[l])
+                    if l > 0 or ctx.needs_input_grad[0]:
+                        dcur = torch.mm(dY, W2)
+                        if l == 0:
+                            dA0 = dcur
+            return (dA0, None, None) + tuple(grads)
         with _lib.on_device(dev):
             for l in range(L - 1, -1, -1):
                 Y, ls, W2, slope = Ys[l], stats[l], W2s[l], slopes[l]
@@ -442,8 +491,12 @@ def _chain_ok(rows, parts):
     return True
 
 
-USE_MLP_CHAIN = False  # measured (tools/exp_r02.sh): 12.0 vs 10.3 ms/step -- the prologue arithmetic and the second operand
-                       # stream push the fused GEMMs to one wave per SIMD; kept for the experiments DESIGN.md records
+CHAIN_LOADER = True    # hidden layers' BatchNorm + activation in the loader waves of the split-role GEMM, activated rows as
+                       # its side output, layer-wise backward (else: the prologue / backward-fused variants in the MFMA waves)
+USE_MLP_CHAIN = True   # loader mode measured (tools/exp_r02c.sh): 8.88 vs 9.08 ms/step, forward 3.61 vs 3.86 ms.  With
+                       # CHAIN_LOADER off the chain is the first design (prologues in the MFMA waves, backward fused as well):
+                       # 12.0 vs 10.3 ms/step -- the prologue arithmetic and the second operand stream push those GEMMs to one
+                       # wave per SIMD; kept for the experiments DESIGN.md records
 
 
 class _BNAct(torch.autograd.Function):
