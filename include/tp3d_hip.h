@@ -209,12 +209,13 @@ int tp3d_gemm_rows_bnact_f32(const float *Y, const float *mean, const float *sca
 /* The same fused contraction on the split-role kernel (csrc/gemm_rows_sp.hip: four MFMA waves fed by four loader waves
  * that apply the prologue on their way into LDS, so it costs the MFMA waves nothing).  act_out != NULL additionally
  * receives the activated rows (M,K) the backward pass of the next layer contracts with (training); stat_partial as for
- * tp3d_gemm_rows_f32 but with tp3d_gemm_rows_sp_chunks(M, N, K) chunks of 4 * N floats.  Shapes: K % 4 == 0,
- * 4 <= K <= 512, N % 128 not in 1..64, N <= 1024 in 1, 2, 4 or 8 column tiles, at least 512 output tiles --
+ * tp3d_gemm_rows_f32 but with tp3d_gemm_rows_sp_chunks(M, N, K, act_out != NULL) chunks of 4 * N floats.  Shapes: K % 4 == 0,
+ * 4 <= K <= 512, N <= 64 or (N % 128 not in 1..64 and N <= 1024 in 1, 2, 4 or 8 column tiles), at least 512 output
+ * tiles --
  * tp3d_gemm_rows_sp_chunks returns 0 for a shape that is not served (TP3D_E_BADARG from the launch).
  * Replaces the Conv2d -> BatchNorm2d -> LeakyReLU hand-over between two layers of MLP2D
  * (core/common_modules/dense_modules.py:25-29). */
-int tp3d_gemm_rows_sp_chunks(int64_t M, int N, int K);
+int tp3d_gemm_rows_sp_chunks(int64_t M, int N, int K, int with_act_out);
 int tp3d_gemm_rows_bnact_sp_f32(const float *Y, const float *mean, const float *scale, const float *beta, float slope,
                                 const float *Bt, int64_t M, int N, int K, float *C, float *stat_partial, float *act_out,
                                 void *stream);

@@ -517,11 +517,12 @@ def test_mlp_chain_matches_layerwise_path(widths, M, loader, pool_ns, train):
         torch.testing.assert_close(a.float(), b.float(), rtol=1e-5, atol=1e-6, msg=lambda m, k=k: k + ": " + m)
 
 
-@pytest.mark.parametrize("M,N,K", [(66000, 128, 128), (65537, 256, 132), (131072, 128, 64), (70000, 512, 36), (66000, 224, 8)])
+@pytest.mark.parametrize("M,N,K", [(66000, 128, 128), (65537, 256, 132), (131072, 128, 64), (70000, 512, 36), (66000, 224, 8), (131077, 64, 64),
+                                   (66000, 48, 132)])
 def test_split_role_gemm_applies_the_previous_layers_batchnorm(M, N, K):
     """tp3d_gemm_rows_bnact_sp_f32 against the two kernels it stands for (tp3d_bn_act_f32, then tp3d_gemm_rows_f32): the
     same output, the activated rows as side output bit for bit, statistics chunks that finalize to the statistics of the
-    output; ragged row counts, a contraction tail, one to four column tiles."""
+    output; ragged row counts, a contraction tail, one to four column tiles, the 64-column tile form."""
     from torch_points3d_amd import _lib, fused
     h = _lib.load()
     g = torch.Generator().manual_seed(M + N + K)
@@ -529,8 +530,8 @@ def test_split_role_gemm_applies_the_previous_layers_batchnorm(M, N, K):
     Bt = (torch.randn(N, K, generator=g) * 0.2).to(DEV)
     mean, scale, beta = (torch.randn(K, generator=g) * 0.2).to(DEV), (torch.rand(K, generator=g) + 0.5).to(DEV), \
         (torch.randn(K, generator=g) * 0.3).to(DEV)
-    chunks = h.tp3d_gemm_rows_sp_chunks(M, N, K)
-    assert chunks == 2 * 512 // ((N + 127) // 128)
+    chunks = h.tp3d_gemm_rows_sp_chunks(M, N, K, 1)
+    assert chunks in (2 * 512 // ((N + 127) // 128), 2 * 1024 // ((N + 127) // 128))
     st = _lib.stream_ptr(Y.device)
     act_ref = torch.empty_like(Y)
     _lib.call("tp3d_bn_act_f32", _lib.ptr(Y), _lib.ptr(mean), _lib.ptr(scale), _lib.ptr(beta), 0.01, M, K, _lib.ptr(act_ref), st)
@@ -556,13 +557,22 @@ def test_split_role_gemm_applies_the_previous_layers_batchnorm(M, N, K):
     _lib.call("tp3d_gemm_rows_bnact_sp_f32", _lib.ptr(Y), _lib.ptr(mean), _lib.ptr(scale), _lib.ptr(beta), 0.01, _lib.ptr(Bt), M, N, K,
               _lib.ptr(out2), None, None, st)
     assert torch.equal(out2, out)
+    # statistics without the side output (another number of workgroups, another partition into chunks)
+    chunks0 = h.tp3d_gemm_rows_sp_chunks(M, N, K, 0)
+    part0 = torch.full((chunks0 * 4 * N,), float("nan"), device=DEV)
+    _lib.call("tp3d_gemm_rows_bnact_sp_f32", _lib.ptr(Y), _lib.ptr(mean), _lib.ptr(scale), _lib.ptr(beta), 0.01, _lib.ptr(Bt), M, N, K,
+              _lib.ptr(out2), _lib.ptr(part0), None, st)
+    stats0 = fused._finalize_stats(part0, M, N, bn.weight.detach(), bn.bias.detach(), bn, Y.device, st, chunks0)
+    assert torch.equal(out2, out)
+    assert float(((stats0[0] - stats[0]).double().abs() / std).max()) < 1e-5
+    torch.testing.assert_close(stats0[1], stats[1], rtol=2e-5, atol=0)
 
 
 def test_split_role_gemm_declines_shapes_it_does_not_serve():
     from torch_points3d_amd import _lib
     h = _lib.load()
-    for M, N, K in [(4096, 128, 128), (66000, 64, 64), (66000, 320, 64), (66000, 128, 516), (66000, 128, 6), (66000, 384, 64)]:
-        assert h.tp3d_gemm_rows_sp_chunks(M, N, K) == 0, (M, N, K)
+    for M, N, K in [(4096, 128, 128), (66000, 192, 64), (66000, 320, 64), (66000, 128, 516), (66000, 128, 6), (66000, 384, 64)]:
+        assert h.tp3d_gemm_rows_sp_chunks(M, N, K, 0) == 0 and h.tp3d_gemm_rows_sp_chunks(M, N, K, 1) == 0, (M, N, K)
     with pytest.raises(_lib.Tp3dError):
         t = torch.zeros(4096, 128, device=DEV)
         _lib.call("tp3d_gemm_rows_bnact_sp_f32", _lib.ptr(t), _lib.ptr(t), _lib.ptr(t), _lib.ptr(t), 0.01, _lib.ptr(t), 4096, 128, 128,

@@ -116,7 +116,7 @@ def load():
     h.tp3d_gemm_rows_stat_chunks.restype = ctypes.c_int
     h.tp3d_gemm_rows_stat_chunks.argtypes = [_l, _i]
     h.tp3d_gemm_rows_sp_chunks.restype = ctypes.c_int
-    h.tp3d_gemm_rows_sp_chunks.argtypes = [_l, _i, _i]
+    h.tp3d_gemm_rows_sp_chunks.argtypes = [_l, _i, _i, _i]
     h.tp3d_gemm_rows_workspace_floats.restype = ctypes.c_size_t
     h.tp3d_gemm_rows_workspace_floats.argtypes = [_l, _i, _i]
     h.tp3d_kpconv_grad_workspace_bytes.restype = ctypes.c_size_t

@@ -35,7 +35,7 @@ struct SpPro {
     float slope;
 };
 
-template <int STATS, int PRO>
+template <int STATS, int PRO, int BN>
 __global__ __launch_bounds__(SP_BLOCK, 4) void gemm_rows_sp_kernel(const float *__restrict__ A, const float *__restrict__ Bt,
                                                                 int64_t M, int N, int K, int tiles_n, int64_t items,
                                                                 float *__restrict__ C, float *__restrict__ partial,
@@ -50,7 +50,8 @@ __global__ __launch_bounds__(SP_BLOCK, 4) void gemm_rows_sp_kernel(const float *
         }
     }
     __shared__ __attribute__((aligned(16))) float sA[2][SP_TILE];
-    __shared__ __attribute__((aligned(16))) float sB[2][SP_TILE];
+    __shared__ __attribute__((aligned(16))) float sB[2][BN * SP_LD];
+    constexpr int TJ = BN / 64;  // 32-column MFMA tiles per compute wave (the wave grid stays 2 x 2)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ksteps = (K + SP_BK - 1) / SP_BK;
     const int tail_groups = (K - (ksteps - 1) * SP_BK + 7) / 8;
@@ -63,7 +64,7 @@ __global__ __launch_bounds__(SP_BLOCK, 4) void gemm_rows_sp_kernel(const float *
         const int64_t grp = item / (8 * tiles_n);
         const int rem = (int)(item % (8 * tiles_n));
         m0 = (grp * 8 + (rem & 7)) * SP_BM;
-        n0 = (rem >> 3) * SP_BN;
+        n0 = (rem >> 3) * BN;
     };
 
     if (wave >= 4) {
@@ -97,8 +98,10 @@ __global__ __launch_bounds__(SP_BLOCK, 4) void gemm_rows_sp_kernel(const float *
         a3_##S = *reinterpret_cast<const float4 *>(A + min(f_m0 + frow + 96, M - 1) * K + kk);                        \
         b0_##S = *reinterpret_cast<const float4 *>(Bt + (size_t)min(f_n0 + frow + 0, N - 1) * K + kk);                \
         b1_##S = *reinterpret_cast<const float4 *>(Bt + (size_t)min(f_n0 + frow + 32, N - 1) * K + kk);               \
-        b2_##S = *reinterpret_cast<const float4 *>(Bt + (size_t)min(f_n0 + frow + 64, N - 1) * K + kk);               \
-        b3_##S = *reinterpret_cast<const float4 *>(Bt + (size_t)min(f_n0 + frow + 96, N - 1) * K + kk);               \
+        if constexpr (BN == 128) {                                                                                    \
+            b2_##S = *reinterpret_cast<const float4 *>(Bt + (size_t)min(f_n0 + frow + 64, N - 1) * K + kk);           \
+            b3_##S = *reinterpret_cast<const float4 *>(Bt + (size_t)min(f_n0 + frow + 96, N - 1) * K + kk);           \
+        }                                                                                                             \
         if (++f_ks == ksteps) {                                                                                       \
             f_ks = 0;                                                                                                 \
             f_item += gridDim.x;                                                                                      \
@@ -126,8 +129,10 @@ __global__ __launch_bounds__(SP_BLOCK, 4) void gemm_rows_sp_kernel(const float *
         SP_STASH_A(S, BUF, 3);                                                                                        \
         *reinterpret_cast<float4 *>(db + 0 * 32 * SP_LD) = sp_keep(kin && n0_##S + frow + 0 < N, b0_##S);             \
         *reinterpret_cast<float4 *>(db + 1 * 32 * SP_LD) = sp_keep(kin && n0_##S + frow + 32 < N, b1_##S);            \
-        *reinterpret_cast<float4 *>(db + 2 * 32 * SP_LD) = sp_keep(kin && n0_##S + frow + 64 < N, b2_##S);            \
-        *reinterpret_cast<float4 *>(db + 3 * 32 * SP_LD) = sp_keep(kin && n0_##S + frow + 96 < N, b3_##S);            \
+        if constexpr (BN == 128) {                                                                                    \
+            *reinterpret_cast<float4 *>(db + 2 * 32 * SP_LD) = sp_keep(kin && n0_##S + frow + 64 < N, b2_##S);        \
+            *reinterpret_cast<float4 *>(db + 3 * 32 * SP_LD) = sp_keep(kin && n0_##S + frow + 96 < N, b3_##S);        \
+        }                                                                                                             \
     } while (0)
         float4 a0_0, a1_0, a2_0, a3_0, b0_0, b1_0, b2_0, b3_0, a0_1, a1_1, a2_1, a3_1, b0_1, b1_1, b2_1, b3_1;
         int64_t m0_0, m0_1;
@@ -162,10 +167,10 @@ __global__ __launch_bounds__(SP_BLOCK, 4) void gemm_rows_sp_kernel(const float *
     int n0, ks = 0;
     decode(item, m0, n0);
     const int n0_first = n0;
-    float run1[2] = {0.0f, 0.0f}, run2[2] = {0.0f, 0.0f}, kshift[2] = {0.0f, 0.0f};
+    float run1[TJ] = {}, run2[TJ] = {}, kshift[TJ] = {};
     bool have_shift = false;
     int run_rows = 0;
-    f32x16 acc[2][2];
+    f32x16 acc[2][TJ];
     __syncthreads();  // B0
     for (int64_t s = 0; s < total; ++s) {
         const float *sa = sA[s & 1], *sb = sB[s & 1];
@@ -173,7 +178,7 @@ __global__ __launch_bounds__(SP_BLOCK, 4) void gemm_rows_sp_kernel(const float *
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
+                for (int j = 0; j < TJ; ++j)
 #pragma unroll
                     for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
         }
@@ -181,17 +186,17 @@ __global__ __launch_bounds__(SP_BLOCK, 4) void gemm_rows_sp_kernel(const float *
 #pragma unroll
         for (int g = 0; g < SP_BK / 8; ++g) {
             if (g < ng) {
-                float4 a[2], b[2];
+                float4 a[2], b[TJ];
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
                     a[i] = *reinterpret_cast<const float4 *>(&sa[((wr * 2 + i) * 32 + l31) * SP_LD + g * 8 + lh * 4]);
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    b[j] = *reinterpret_cast<const float4 *>(&sb[((wc * 2 + j) * 32 + l31) * SP_LD + g * 8 + lh * 4]);
+                for (int j = 0; j < TJ; ++j)
+                    b[j] = *reinterpret_cast<const float4 *>(&sb[((wc * TJ + j) * 32 + l31) * SP_LD + g * 8 + lh * 4]);
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) {
+                    for (int j = 0; j < TJ; ++j) {
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].x, b[j].x, acc[i][j], 0, 0, 0);
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].y, b[j].y, acc[i][j], 0, 0, 0);
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].z, b[j].z, acc[i][j], 0, 0, 0);
@@ -205,8 +210,8 @@ __global__ __launch_bounds__(SP_BLOCK, 4) void gemm_rows_sp_kernel(const float *
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const int n = n0 + (wc * 2 + j) * 32 + l31;
+                for (int j = 0; j < TJ; ++j) {
+                    const int n = n0 + (wc * TJ + j) * 32 + l31;
 #pragma unroll
                     for (int e = 0; e < 16; ++e) {
                         const int64_t m = m0 + (wr * 2 + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
@@ -217,7 +222,7 @@ __global__ __launch_bounds__(SP_BLOCK, 4) void gemm_rows_sp_kernel(const float *
                 const int valid = (int)min((int64_t)64, max((int64_t)0, M - (m0 + wr * 64)));  // wave-uniform
                 const float pad = (float)(64 - valid);
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
+                for (int j = 0; j < TJ; ++j) {
                     if (!have_shift) kshift[j] = __shfl(acc[0][j][0], l31);
                     const float k = kshift[j];
                     float s1 = 0.0f, s2 = 0.0f;
@@ -248,8 +253,8 @@ __global__ __launch_bounds__(SP_BLOCK, 4) void gemm_rows_sp_kernel(const float *
         const int per = 8 * tiles_n;
         const int64_t slot = (int64_t)(blockIdx.x / per) * 8 + (blockIdx.x & 7);
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int n = n0_first + (wc * 2 + j) * 32 + l31;
+        for (int j = 0; j < TJ; ++j) {
+            const int n = n0_first + (wc * TJ + j) * 32 + l31;
             if (lh == 0 && n < N) {
                 float *pr = partial + ((size_t)(slot * 2 + wr) * 4) * N + n;
                 pr[0] = run1[j];
@@ -263,29 +268,36 @@ __global__ __launch_bounds__(SP_BLOCK, 4) void gemm_rows_sp_kernel(const float *
 
 }  // namespace tp3d
 
-constexpr int SP_GRID = 512;  // persistent: two 8-wave workgroups per CU
+// Workgroups of a launch: two resident per CU (512); twice as many for long launches WITH the side output, i.e. inside a
+// training step, so that the dispatcher hands the second half out as slots come free -- the pipelined step runs this
+// kernel beside the next step's furthest-point sampling, whose 32 CUs have room for one workgroup of this kernel
+// instead of two, and a static split over exactly-resident workgroups would wait for those (8.95 -> 8.90 ms/step; alone
+// on the chip the extra pipeline fills cost the forward pass 0.1 ms, hence not for the launches without side output).
+static int sp_grid(int64_t items, bool side) { return (side && items >= 2048) ? 1024 : 512; }
 
-// The statistics chunks (and the kernel) need every workgroup to stay on one column tile: SP_GRID % (8 * tiles_n) == 0.
-// Not served (0): narrow outputs (a 128-column tile would be half empty -- gemm_rows.hip's 128 x 64 tiles are the better
-// kernel there), fewer items than workgroups, contractions longer than the constants' LDS table.
+// The statistics chunks (and the kernel) need every workgroup to stay on one column tile: grid % (8 * tiles_n) == 0.
+// Not served (0): widths that end in a narrow remainder (192, 320 ... columns: gemm_rows.hip mixes tile widths there; up
+// to 64 columns run on this kernel's 128 x 64 tiles), fewer than 512 items, contractions longer than the constants' LDS
+// table.
 static int sp_tiles_n(int64_t M, int N, int K)
 {
     if (M <= 0 || N <= 0 || K < 4 || (K & 3) || K > tp3d::SP_PRO_KMAX) return 0;
     const int rem = N % tp3d::SP_BN;
-    if (rem > 0 && rem <= 64) return 0;
+    if (rem > 0 && rem <= 64 && N > 64) return 0;  // (N <= 64: one 128 x 64 tile per row block)
     const int tiles_n = (N + tp3d::SP_BN - 1) / tp3d::SP_BN;
-    if (SP_GRID % (8 * tiles_n)) return 0;
+    if (512 % (8 * tiles_n)) return 0;
     const int64_t row_blocks = (M + tp3d::SP_BM - 1) / tp3d::SP_BM;
-    if ((row_blocks + 7) / 8 * 8 * tiles_n < SP_GRID) return 0;
+    if ((row_blocks + 7) / 8 * 8 * tiles_n < 512) return 0;
     return tiles_n;
 }
+static int64_t sp_items(int64_t M, int tiles_n) { return ((M + tp3d::SP_BM - 1) / tp3d::SP_BM + 7) / 8 * 8 * tiles_n; }
 
-// Statistics chunks tp3d_gemm_rows_bnact_sp_f32 writes for (M, N, K) -- stat_partial holds chunks * 4 * N floats in the
-// layout tp3d_bn_finalize_f32 reads -- or 0 when the shape is not served by this kernel.
-TP3D_EXPORT int tp3d_gemm_rows_sp_chunks(int64_t M, int N, int K)
+// Statistics chunks tp3d_gemm_rows_bnact_sp_f32 writes for (M, N, K) with / without the side output -- stat_partial holds
+// chunks * 4 * N floats in the layout tp3d_bn_finalize_f32 reads -- or 0 when the shape is not served by this kernel.
+TP3D_EXPORT int tp3d_gemm_rows_sp_chunks(int64_t M, int N, int K, int with_act_out)
 {
     const int tiles_n = sp_tiles_n(M, N, K);
-    return tiles_n ? 2 * (SP_GRID / tiles_n) : 0;
+    return tiles_n ? 2 * (sp_grid(sp_items(M, tiles_n), with_act_out != 0) / tiles_n) : 0;
 }
 
 TP3D_EXPORT int tp3d_gemm_rows_bnact_sp_f32(const float *Y, const float *mean, const float *scale, const float *beta,
@@ -295,15 +307,24 @@ TP3D_EXPORT int tp3d_gemm_rows_bnact_sp_f32(const float *Y, const float *mean, c
     using namespace tp3d;
     const int tiles_n = sp_tiles_n(M, N, K);
     if (!tiles_n || !Y || !mean || !scale || !beta || !Bt || !C) return TP3D_E_BADARG;
-    const int64_t row_blocks = (M + SP_BM - 1) / SP_BM;
-    const int64_t items = (row_blocks + 7) / 8 * 8 * tiles_n;
+    const int64_t items = sp_items(M, tiles_n);
+    const int grid = sp_grid(items, act_out != nullptr);
     SpPro pro{mean, scale, beta, slope};
     hipStream_t s = (hipStream_t)stream;
-    if (stat_partial)
-        hipLaunchKernelGGL((gemm_rows_sp_kernel<2, 1>), dim3(SP_GRID), dim3(SP_BLOCK), 0, s, Y, Bt, M, N, K, tiles_n, items, C,
-                           stat_partial, act_out, pro);
-    else
-        hipLaunchKernelGGL((gemm_rows_sp_kernel<0, 1>), dim3(SP_GRID), dim3(SP_BLOCK), 0, s, Y, Bt, M, N, K, tiles_n, items, C,
-                           (float *)nullptr, act_out, pro);
+#define TP3D_SP_LAUNCH(STATS, BN)                                                                                     \
+    hipLaunchKernelGGL((gemm_rows_sp_kernel<STATS, 1, BN>), dim3(grid), dim3(SP_BLOCK), 0, s, Y, Bt, M, N, K, tiles_n, items, \
+                       C, stat_partial, act_out, pro)
+    if (N <= 64) {
+        if (stat_partial)
+            TP3D_SP_LAUNCH(2, 64);
+        else
+            TP3D_SP_LAUNCH(0, 64);
+    } else {
+        if (stat_partial)
+            TP3D_SP_LAUNCH(2, 128);
+        else
+            TP3D_SP_LAUNCH(0, 128);
+    }
+#undef TP3D_SP_LAUNCH
     return check_launch();
 }

@@ -356,7 +356,7 @@ class _MLPChain(torch.autograd.Function):
                     W2 = torch.nn.functional.pad(W2, (0, Kp - W2.shape[1]))
                 W2 = W2.contiguous()
                 Y = torch.empty((M, Cout), dtype=torch.float32, device=dev)
-                sp_chunks = h.tp3d_gemm_rows_sp_chunks(M, Cout, Kp) if (l > 0 and CHAIN_LOADER) else 0
+                sp_chunks = h.tp3d_gemm_rows_sp_chunks(M, Cout, Kp, int(keep_acts)) if (l > 0 and CHAIN_LOADER) else 0
                 chunks = None
                 if l == 0:
                     part = _lib.workspace("gemm_rows_stats", 4 * h.tp3d_gemm_rows_stat_floats(M, Cout), dev) if training else None
