@@ -577,3 +577,29 @@ def test_split_role_gemm_declines_shapes_it_does_not_serve():
         t = torch.zeros(4096, 128, device=DEV)
         _lib.call("tp3d_gemm_rows_bnact_sp_f32", _lib.ptr(t), _lib.ptr(t), _lib.ptr(t), _lib.ptr(t), 0.01, _lib.ptr(t), 4096, 128, 128,
                   _lib.ptr(t), None, None, _lib.stream_ptr(t.device))
+
+
+def test_split_role_gemm_constants_table_is_ready_before_the_first_tile():
+    """The loader waves read the per-channel constants from LDS for the very first tile they stage.  Alternating launches
+    with different constants leave the other launch's table behind in LDS: every launch must still use its own."""
+    from torch_points3d_amd import _lib
+    M, N, K = 131072, 128, 64
+    g = torch.Generator().manual_seed(9)
+    Y = torch.randn(M, K, generator=g).to(DEV)
+    Bt = (torch.randn(N, K, generator=g) * 0.2).to(DEV)
+    st = _lib.stream_ptr(Y.device)
+    sets = []
+    for i in range(2):
+        mean, scale, beta = (torch.randn(K, generator=g) + 3 * i).to(DEV), (torch.rand(K, generator=g) + 0.5 + i).to(DEV), \
+            (torch.randn(K, generator=g) - 2 * i).to(DEV)
+        ref = torch.empty_like(Y)
+        _lib.call("tp3d_bn_act_f32", _lib.ptr(Y), _lib.ptr(mean), _lib.ptr(scale), _lib.ptr(beta), 0.01, M, K, _lib.ptr(ref), st)
+        sets.append((mean, scale, beta, ref))
+    out = torch.empty(M, N, device=DEV)
+    acts = [torch.empty_like(Y) for _ in range(8)]
+    for i in range(8):
+        mean, scale, beta, _ = sets[i & 1]
+        _lib.call("tp3d_gemm_rows_bnact_sp_f32", _lib.ptr(Y), _lib.ptr(mean), _lib.ptr(scale), _lib.ptr(beta), 0.01, _lib.ptr(Bt), M, N, K,
+                  _lib.ptr(out), None, _lib.ptr(acts[i]), st)
+    for i in range(8):
+        assert torch.equal(acts[i], sets[i & 1][3]), i

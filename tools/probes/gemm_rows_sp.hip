@@ -46,6 +46,7 @@ __global__ __launch_bounds__(SP_BLOCK, 4) void gemm_rows_sp_kernel(const float *
             sK[SP_PRO_KMAX + k] = k < K ? pro.scale[k] : 0.0f;
             sK[2 * SP_PRO_KMAX + k] = k < K ? pro.beta[k] : 0.0f;
         }
+        __syncthreads();  // the loader waves read the table for their first LDS write, before the first barrier of the K walk
     }
     // probe (experiments only): bit 0 reads A rows modulo 8192 (cache-resident input), bit 1 skips the stores of C
     const int64_t a_wrap = (probe & 1) ? 8191 : ~(int64_t)0;

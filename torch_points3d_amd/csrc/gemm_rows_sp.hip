@@ -48,6 +48,7 @@ __global__ __launch_bounds__(SP_BLOCK, 4) void gemm_rows_sp_kernel(const float *
             sK[SP_PRO_KMAX + k] = k < K ? pro.scale[k] : 0.0f;
             sK[2 * SP_PRO_KMAX + k] = k < K ? pro.beta[k] : 0.0f;
         }
+        __syncthreads();  // the loader waves read the table for their first LDS write, before the first barrier of the K walk
     }
     __shared__ __attribute__((aligned(16))) float sA[2][SP_TILE];
     __shared__ __attribute__((aligned(16))) float sB[2][BN * SP_LD];
