@@ -603,3 +603,48 @@ def test_split_role_gemm_constants_table_is_ready_before_the_first_tile():
                   _lib.ptr(out), None, _lib.ptr(acts[i]), st)
     for i in range(8):
         assert torch.equal(acts[i], sets[i & 1][3]), i
+
+
+@pytest.mark.parametrize("M,N,K", [(66000, 128, 128), (65537, 256, 132), (131072, 64, 64), (70000, 12, 64), (66000, 128, 256)])
+def test_split_role_input_gradient_gemm_forms_dy_in_its_loaders(M, N, K):
+    """tp3d_gemm_rows_bnbwd_sp_f32: dY side output against the BatchNorm + LeakyReLU backward formula in float64, the
+    product against dY @ W in float64; the reduction constants come from tp3d_bn_bwd_reduce_f32 as in the chain."""
+    from torch_points3d_amd import _lib
+    h = _lib.load()
+    assert h.tp3d_gemm_rows_bnbwd_sp_serves(M, N, K) == 1
+    g = torch.Generator().manual_seed(M + N + K)
+    Y = (torch.randn(M, K, generator=g) * 1.5 + 0.2).to(DEV)
+    dA = torch.randn(M, K, generator=g).to(DEV)
+    Wt = (torch.randn(N, K, generator=g) * 0.2).to(DEV)  # (input width, output width) = W^T
+    gamma, beta = (torch.rand(K, generator=g) + 0.5).to(DEV), (torch.randn(K, generator=g) * 0.3).to(DEV)
+    mean = Y.double().mean(0)
+    invstd = 1.0 / torch.sqrt(Y.double().var(0, unbiased=False) + 1e-5)
+    mean32, invstd32 = mean.float(), invstd.float()
+    scale = (gamma.double() * invstd).float()
+    st = _lib.stream_ptr(Y.device)
+    red = torch.empty(4, K, device=DEV)
+    ws = _lib.bn_workspace(M, K, Y.device)
+    _lib.call("tp3d_bn_bwd_reduce_f32", _lib.ptr(dA), None, _lib.ptr(Y), _lib.ptr(scale), _lib.ptr(beta), _lib.ptr(mean32),
+              _lib.ptr(invstd32), 0.01, M, 1, K, 1, _lib.ptr(red[0]), _lib.ptr(red[1]), _lib.ptr(red[2]), _lib.ptr(red[3]), _lib.ptr(ws), st)
+    out = torch.full((M, N), float("nan"), device=DEV)
+    dY = torch.full((M, K), float("nan"), device=DEV)
+    _lib.call("tp3d_gemm_rows_bnbwd_sp_f32", _lib.ptr(Y), _lib.ptr(dA), _lib.ptr(mean32), _lib.ptr(scale), _lib.ptr(beta), _lib.ptr(red[2]),
+              _lib.ptr(red[3]), 0.01, _lib.ptr(Wt), M, N, K, _lib.ptr(out), _lib.ptr(dY), st)
+    torch.cuda.synchronize()
+    yc = Y.double() - mean32.double()
+    z = yc * scale.double() + beta.double()
+    dz = dA.double() * torch.where(z > 0, 1.0, 0.01)
+    xhat = yc * invstd32.double()
+    want = scale.double() * (dz - dz.mean(0) - xhat * (dz * xhat).mean(0))
+    near_kink = z.abs() < 1e-5
+    err = (dY.double() - want).abs()
+    err[near_kink] = 0
+    assert float(err.max()) < 2e-5 * float(want.abs().max())
+    ref = dY.double() @ Wt.double().t()
+    assert float((out.double() - ref).abs().max()) < 1e-5 * float(ref.abs().max()) + 1e-6
+    # without the side output: the same product
+    out2 = torch.empty_like(out)
+    _lib.call("tp3d_gemm_rows_bnbwd_sp_f32", _lib.ptr(Y), _lib.ptr(dA), _lib.ptr(mean32), _lib.ptr(scale), _lib.ptr(beta), _lib.ptr(red[2]),
+              _lib.ptr(red[3]), 0.01, _lib.ptr(Wt), M, N, K, _lib.ptr(out2), None, st)
+    assert torch.equal(out2, out)
+    assert h.tp3d_gemm_rows_bnbwd_sp_serves(M, N, 260) == 0 and h.tp3d_gemm_rows_bnbwd_sp_serves(4096, N, K) == 0

@@ -29,10 +29,15 @@ __device__ __forceinline__ float4 sp_keep(bool c, float4 v) {
 // STATS: 0 none, 2 one statistics chunk per (workgroup, wave row) -- shifted sums as in gemm_rows.hip
 // PRO 1: the loader waves turn the staged pre-BatchNorm rows into activated ones, leaky((y - mean) * scale + beta) per
 // contraction channel, on their way into LDS (K <= SP_PRO_KMAX; constants in LDS)
+// PRO 2: the loader waves form dY, the BatchNorm + LeakyReLU BACKWARD of (dA, Y) with the reduction constants c1, c2 of
+// tp3d_bn_bwd_reduce_f32 -- dY = scale * ((dA * act'(z) - c1) - (y - mean) * c2), z = (y - mean) * scale + beta -- stage
+// it as the A operand and write it out as the side output (K <= SP_BWD_KMAX; five constants per channel in LDS)
 constexpr int SP_PRO_KMAX = 512;
+constexpr int SP_BWD_KMAX = 256;
 struct SpPro {
     const float *mean, *scale, *beta;
     float slope;
+    const float *dA, *c1, *c2;  // PRO 2 only
 };
 
 template <int STATS, int PRO, int BN>
@@ -41,12 +46,17 @@ __global__ __launch_bounds__(SP_BLOCK, 4) void gemm_rows_sp_kernel(const float *
                                                                 float *__restrict__ C, float *__restrict__ partial,
                                                                 float *__restrict__ act_out, SpPro pro)
 {
-    __shared__ __attribute__((aligned(16))) float sK[PRO ? 3 * SP_PRO_KMAX : 4];
+    constexpr int KMAX = PRO == 2 ? SP_BWD_KMAX : SP_PRO_KMAX;
+    __shared__ __attribute__((aligned(16))) float sK[PRO == 2 ? 5 * KMAX : (PRO ? 3 * KMAX : 4)];
     if (PRO) {
-        for (int k = threadIdx.x; k < SP_PRO_KMAX; k += SP_BLOCK) {
+        for (int k = threadIdx.x; k < KMAX; k += SP_BLOCK) {
             sK[k] = k < K ? pro.mean[k] : 0.0f;
-            sK[SP_PRO_KMAX + k] = k < K ? pro.scale[k] : 0.0f;
-            sK[2 * SP_PRO_KMAX + k] = k < K ? pro.beta[k] : 0.0f;
+            sK[KMAX + k] = k < K ? pro.scale[k] : 0.0f;
+            sK[2 * KMAX + k] = k < K ? pro.beta[k] : 0.0f;
+            if (PRO == 2) {
+                sK[3 * KMAX + k] = k < K ? pro.c1[k] : 0.0f;
+                sK[4 * KMAX + k] = k < K ? pro.c2[k] : 0.0f;
+            }
         }
         __syncthreads();  // the loader waves read the table for their first LDS write, before the first barrier of the K walk
     }
@@ -76,15 +86,124 @@ __global__ __launch_bounds__(SP_BLOCK, 4) void gemm_rows_sp_kernel(const float *
         int f_n0, f_ks = 0;
         decode(f_item, f_m0, f_n0);
         auto act4 = [&](const float4 raw, int kk) __attribute__((always_inline)) -> float4 {
-            const int kc = min(kk, SP_PRO_KMAX - 4);
+            const int kc = min(kk, KMAX - 4);
             const float4 mu = *reinterpret_cast<const float4 *>(&sK[kc]);
-            const float4 sc = *reinterpret_cast<const float4 *>(&sK[SP_PRO_KMAX + kc]);
-            const float4 be = *reinterpret_cast<const float4 *>(&sK[2 * SP_PRO_KMAX + kc]);
+            const float4 sc = *reinterpret_cast<const float4 *>(&sK[KMAX + kc]);
+            const float4 be = *reinterpret_cast<const float4 *>(&sK[2 * KMAX + kc]);
             const float z0 = (raw.x - mu.x) * sc.x + be.x, z1 = (raw.y - mu.y) * sc.y + be.y;
             const float z2 = (raw.z - mu.z) * sc.z + be.z, z3 = (raw.w - mu.w) * sc.w + be.w;
             return make_float4(z0 > 0.0f ? z0 : z0 * pro.slope, z1 > 0.0f ? z1 : z1 * pro.slope,
                                z2 > 0.0f ? z2 : z2 * pro.slope, z3 > 0.0f ? z3 : z3 * pro.slope);
         };
+        if constexpr (PRO == 2) {
+            // ---- backward prologue: two A streams (Y, dA) two K-steps ahead, the small B operand (L2-resident weights) one
+            // step ahead and issued BEFORE the A loads of its iteration, so that waiting for it leaves the newest A stage
+            // in flight (loads complete in order)
+            auto bwd4 = [&](const float4 raw, const float4 d, int kk) __attribute__((always_inline)) -> float4 {
+                const int kc = min(kk, KMAX - 4);
+                const float4 mu = *reinterpret_cast<const float4 *>(&sK[kc]);
+                const float4 sc = *reinterpret_cast<const float4 *>(&sK[KMAX + kc]);
+                const float4 be = *reinterpret_cast<const float4 *>(&sK[2 * KMAX + kc]);
+                const float4 c1 = *reinterpret_cast<const float4 *>(&sK[3 * KMAX + kc]);
+                const float4 c2 = *reinterpret_cast<const float4 *>(&sK[4 * KMAX + kc]);
+                auto one = [&](float y, float dd, float m, float s_, float b, float k1, float k2) __attribute__((always_inline)) -> float {
+                    const float yc = y - m;
+                    const float z = yc * s_ + b;
+                    const float dz = dd * (z > 0.0f ? 1.0f : pro.slope);
+                    return s_ * ((dz - k1) - yc * k2);
+                };
+                return make_float4(one(raw.x, d.x, mu.x, sc.x, be.x, c1.x, c2.x), one(raw.y, d.y, mu.y, sc.y, be.y, c1.y, c2.y),
+                                   one(raw.z, d.z, mu.z, sc.z, be.z, c1.z, c2.z), one(raw.w, d.w, mu.w, sc.w, be.w, c1.w, c2.w));
+            };
+            const float *dA = pro.dA;
+            int64_t g_item = blockIdx.x;  // the B cursor (one step behind the A cursor)
+            int g_n0 = f_n0, g_ks = 0;
+#define SP_FETCH_A(S)                                                                                                 \
+    do {                                                                                                              \
+        m0_##S = f_m0, n0_##S = f_n0, k0_##S = f_ks * SP_BK;                                                          \
+        const int kk = min(k0_##S + fk4, K - 4);                                                                      \
+        const int64_t o0 = min(f_m0 + frow + 0, M - 1) * K + kk, o1 = min(f_m0 + frow + 32, M - 1) * K + kk;          \
+        const int64_t o2 = min(f_m0 + frow + 64, M - 1) * K + kk, o3 = min(f_m0 + frow + 96, M - 1) * K + kk;         \
+        y0_##S = *reinterpret_cast<const float4 *>(A + o0), d0_##S = *reinterpret_cast<const float4 *>(dA + o0);      \
+        y1_##S = *reinterpret_cast<const float4 *>(A + o1), d1_##S = *reinterpret_cast<const float4 *>(dA + o1);      \
+        y2_##S = *reinterpret_cast<const float4 *>(A + o2), d2_##S = *reinterpret_cast<const float4 *>(dA + o2);      \
+        y3_##S = *reinterpret_cast<const float4 *>(A + o3), d3_##S = *reinterpret_cast<const float4 *>(dA + o3);      \
+        if (++f_ks == ksteps) {                                                                                       \
+            f_ks = 0;                                                                                                 \
+            f_item += gridDim.x;                                                                                      \
+            decode(f_item, f_m0, f_n0);                                                                               \
+        }                                                                                                             \
+    } while (0)
+#define SP_FETCH_B()                                                                                                  \
+    do {                                                                                                              \
+        bn0 = g_n0, bk0 = g_ks * SP_BK;                                                                               \
+        const int kk = min(bk0 + fk4, K - 4);                                                                         \
+        b0 = *reinterpret_cast<const float4 *>(Bt + (size_t)min(g_n0 + frow + 0, N - 1) * K + kk);                    \
+        b1 = *reinterpret_cast<const float4 *>(Bt + (size_t)min(g_n0 + frow + 32, N - 1) * K + kk);                   \
+        if constexpr (BN == 128) {                                                                                    \
+            b2 = *reinterpret_cast<const float4 *>(Bt + (size_t)min(g_n0 + frow + 64, N - 1) * K + kk);               \
+            b3 = *reinterpret_cast<const float4 *>(Bt + (size_t)min(g_n0 + frow + 96, N - 1) * K + kk);               \
+        }                                                                                                             \
+        if (++g_ks == ksteps) {                                                                                       \
+            g_ks = 0;                                                                                                 \
+            g_item += gridDim.x;                                                                                      \
+            int64_t unused_m0;                                                                                        \
+            decode(g_item, unused_m0, g_n0);                                                                          \
+        }                                                                                                             \
+    } while (0)
+#define SP_STASH_D(S, BUF, I)                                                                                         \
+    do {                                                                                                              \
+        const bool in = kin && m0_##S + frow + 32 * I < M;                                                            \
+        const float4 v = sp_keep(in, bwd4(y##I##_##S, d##I##_##S, k0_##S + fk4));                                     \
+        *reinterpret_cast<float4 *>(da + I * 32 * SP_LD) = v;                                                         \
+        if (side && in) *reinterpret_cast<float4 *>(act_out + (m0_##S + frow + 32 * I) * K + k0_##S + fk4) = v;       \
+    } while (0)
+#define SP_STASH2(S, BUF)                                                                                             \
+    do {                                                                                                              \
+        const bool kin = k0_##S + fk4 < K, kinb = bk0 + fk4 < K;                                                      \
+        const bool side = act_out != nullptr && n0_##S == 0;                                                          \
+        float *da = &sA[BUF][frow * SP_LD + fk4], *db = &sB[BUF][frow * SP_LD + fk4];                                 \
+        SP_STASH_D(S, BUF, 0);                                                                                        \
+        SP_STASH_D(S, BUF, 1);                                                                                        \
+        SP_STASH_D(S, BUF, 2);                                                                                        \
+        SP_STASH_D(S, BUF, 3);                                                                                        \
+        *reinterpret_cast<float4 *>(db + 0 * 32 * SP_LD) = sp_keep(kinb && bn0 + frow + 0 < N, b0);                   \
+        *reinterpret_cast<float4 *>(db + 1 * 32 * SP_LD) = sp_keep(kinb && bn0 + frow + 32 < N, b1);                  \
+        if constexpr (BN == 128) {                                                                                    \
+            *reinterpret_cast<float4 *>(db + 2 * 32 * SP_LD) = sp_keep(kinb && bn0 + frow + 64 < N, b2);              \
+            *reinterpret_cast<float4 *>(db + 3 * 32 * SP_LD) = sp_keep(kinb && bn0 + frow + 96 < N, b3);              \
+        }                                                                                                             \
+    } while (0)
+            float4 y0_0, y1_0, y2_0, y3_0, d0_0, d1_0, d2_0, d3_0, y0_1, y1_1, y2_1, y3_1, d0_1, d1_1, d2_1, d3_1;
+            float4 b0, b1, b2, b3;
+            int64_t m0_0, m0_1;
+            int n0_0, n0_1, k0_0, k0_1, bn0, bk0;
+            SP_FETCH_B();   // B of step 0
+            SP_FETCH_A(0);  // A of step 0
+            SP_STASH2(0, 0);
+            SP_FETCH_A(1);  // A of step 1 (older than the B below: the order the loop keeps)
+            SP_FETCH_B();   // B of step 1
+            SP_FETCH_A(0);  // A of step 2
+            __syncthreads();  // B0: buffer 0 holds step 0
+#pragma unroll 1
+            for (int64_t s = 0; s < total; s += 2) {
+                // during compute step s: step s+1 (A stage 1, B registers) into buffer 1; then B of s+2, A of s+3
+                SP_STASH2(1, 1);
+                SP_FETCH_B();
+                SP_FETCH_A(1);
+                __syncthreads();
+                if (s + 1 >= total) break;
+                SP_STASH2(0, 0);
+                SP_FETCH_B();
+                SP_FETCH_A(0);
+                __syncthreads();
+            }
+#undef SP_FETCH_A
+#undef SP_FETCH_B
+#undef SP_STASH2
+#undef SP_STASH_D
+            return;
+        }
         // every fetch issues exactly eight unconditional loads (rows / columns past the matrix read a valid address and
         // are zeroed when they are written to LDS), so the compiler can count them and waits for the older stage only.
         // The two stages are plain named variables filled by macros: arrays or structs handed to lambdas ended up in
@@ -109,7 +228,7 @@ __global__ __launch_bounds__(SP_BLOCK, 4) void gemm_rows_sp_kernel(const float *
             const int64_t grp = f_item / (8 * tiles_n);                                                               \
             const int rem = (int)(f_item % (8 * tiles_n));                                                            \
             f_m0 = (grp * 8 + (rem & 7)) * SP_BM;                                                                     \
-            f_n0 = (rem >> 3) * SP_BN;                                                                                \
+            f_n0 = (rem >> 3) * BN;                                                                                   \
         }                                                                                                             \
     } while (0)
 #define SP_STASH_A(S, BUF, I)                                                                                         \
@@ -280,9 +399,9 @@ static int sp_grid(int64_t items, bool side) { return (side && items >= 2048) ? 
 // Not served (0): widths that end in a narrow remainder (192, 320 ... columns: gemm_rows.hip mixes tile widths there; up
 // to 64 columns run on this kernel's 128 x 64 tiles), fewer than 512 items, contractions longer than the constants' LDS
 // table.
-static int sp_tiles_n(int64_t M, int N, int K)
+static int sp_tiles_n(int64_t M, int N, int K, int kmax = tp3d::SP_PRO_KMAX)
 {
-    if (M <= 0 || N <= 0 || K < 4 || (K & 3) || K > tp3d::SP_PRO_KMAX) return 0;
+    if (M <= 0 || N <= 0 || K < 4 || (K & 3) || K > kmax) return 0;
     const int rem = N % tp3d::SP_BN;
     if (rem > 0 && rem <= 64 && N > 64) return 0;  // (N <= 64: one 128 x 64 tile per row block)
     const int tiles_n = (N + tp3d::SP_BN - 1) / tp3d::SP_BN;
@@ -310,7 +429,7 @@ TP3D_EXPORT int tp3d_gemm_rows_bnact_sp_f32(const float *Y, const float *mean, c
     if (!tiles_n || !Y || !mean || !scale || !beta || !Bt || !C) return TP3D_E_BADARG;
     const int64_t items = sp_items(M, tiles_n);
     const int grid = sp_grid(items, act_out != nullptr);
-    SpPro pro{mean, scale, beta, slope};
+    SpPro pro{mean, scale, beta, slope, nullptr, nullptr, nullptr};
     hipStream_t s = (hipStream_t)stream;
 #define TP3D_SP_LAUNCH(STATS, BN)                                                                                     \
     hipLaunchKernelGGL((gemm_rows_sp_kernel<STATS, 1, BN>), dim3(grid), dim3(SP_BLOCK), 0, s, Y, Bt, M, N, K, tiles_n, items, \
@@ -327,5 +446,28 @@ TP3D_EXPORT int tp3d_gemm_rows_bnact_sp_f32(const float *Y, const float *mean, c
             TP3D_SP_LAUNCH(0, 128);
     }
 #undef TP3D_SP_LAUNCH
+    return check_launch();
+}
+
+// 1 when tp3d_gemm_rows_bnbwd_sp_f32 serves (M, N, K): the shape rule above with K <= 256.
+TP3D_EXPORT int tp3d_gemm_rows_bnbwd_sp_serves(int64_t M, int N, int K) { return sp_tiles_n(M, N, K, tp3d::SP_BWD_KMAX) ? 1 : 0; }
+
+TP3D_EXPORT int tp3d_gemm_rows_bnbwd_sp_f32(const float *Y, const float *dA, const float *mean, const float *scale,
+                                            const float *beta, const float *c1, const float *c2, float slope,
+                                            const float *Bt, int64_t M, int N, int K, float *C, float *dY_out, void *stream)
+{
+    using namespace tp3d;
+    const int tiles_n = sp_tiles_n(M, N, K, SP_BWD_KMAX);
+    if (!tiles_n || !Y || !dA || !mean || !scale || !beta || !c1 || !c2 || !Bt || !C) return TP3D_E_BADARG;
+    const int64_t items = sp_items(M, tiles_n);
+    const int grid = sp_grid(items, true);
+    SpPro pro{mean, scale, beta, slope, dA, c1, c2};
+    hipStream_t s = (hipStream_t)stream;
+    if (N <= 64)
+        hipLaunchKernelGGL((gemm_rows_sp_kernel<0, 2, 64>), dim3(grid), dim3(SP_BLOCK), 0, s, Y, Bt, M, N, K, tiles_n, items, C,
+                           (float *)nullptr, dY_out, pro);
+    else
+        hipLaunchKernelGGL((gemm_rows_sp_kernel<0, 2, 128>), dim3(grid), dim3(SP_BLOCK), 0, s, Y, Bt, M, N, K, tiles_n, items, C,
+                           (float *)nullptr, dY_out, pro);
     return check_launch();
 }

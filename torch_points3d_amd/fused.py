@@ -431,8 +431,28 @@ class _MLPChain(torch.autograd.Function):
                     C, Kp = W2.shape
                     pooled = bool(pool_ns) and l == L - 1
                     dY = torch.empty_like(Y)
-                    dgb = torch.empty((2, C), dtype=torch.float32, device=dev)  # dbeta, dgamma
                     ws = _lib.bn_workspace(M, C, dev)
+                    want_prev = l > 0 or ctx.needs_input_grad[0]
+                    if (CHAIN_BWD_LOADER and not pooled and want_prev
+                            and _lib.load().tp3d_gemm_rows_bnbwd_sp_serves(M, Kp, C)):
+                        # reduction pass, then the input-gradient GEMM whose loader waves form dY (side output for dW)
+                        red = torch.empty((4, C), dtype=torch.float32, device=dev)  # dbeta, dgamma, c1, c2
+                        _lib.call("tp3d_bn_bwd_reduce_f32", _lib.ptr(dcur), None, _lib.ptr(Y), _lib.ptr(ls[2]), _lib.ptr(ls[3]),
+                                  _lib.ptr(ls[0]), _lib.ptr(ls[1]), slope, M, 1, C, int(training), _lib.ptr(red[0]), _lib.ptr(red[1]),
+                                  _lib.ptr(red[2]), _lib.ptr(red[3]), _lib.ptr(ws), st)
+                        grads[3 * l + 1], grads[3 * l + 2] = red[1], red[0]
+                        Wt = W2.t().contiguous()  # (Kp, C): dA_{l-1}[M,Kp] = dY_l[M,C] (W^T)[Kp,C]^T
+                        dprev = torch.empty((M, Kp), dtype=torch.float32, device=dev)
+                        _lib.call("tp3d_gemm_rows_bnbwd_sp_f32", _lib.ptr(Y), _lib.ptr(dcur), _lib.ptr(ls[0]), _lib.ptr(ls[2]),
+                                  _lib.ptr(ls[3]), _lib.ptr(red[2]), _lib.ptr(red[3]), slope, _lib.ptr(Wt), M, Kp, C, _lib.ptr(dprev),
+                                  _lib.ptr(dY) if ctx.needs_input_grad[3 + 3 * l] else None, st)
+                        if ctx.needs_input_grad[3 + 3 * l]:
+                            grads[3 * l] = gemm_tn(dY, A0 if l == 0 else acts[l - 1])[:, :cins[l]].reshape(wshapes[l])
+                        dcur = dprev
+                        if l == 0:
+                            dA0 = dprev
+                        continue
+                    dgb = torch.empty((2, C), dtype=torch.float32, device=dev)  # dbeta, dgamma
                     _lib.call("tp3d_bn_act_bwd_f32", _lib.ptr(dcur), _lib.ptr(arg) if pooled else None, _lib.ptr(Y), _lib.ptr(ls[2]),
                               _lib.ptr(ls[3]), _lib.ptr(ls[0]), _lib.ptr(ls[1]), slope, M, pool_ns if pooled else 1, C,
                               int(training), _lib.ptr(dgb[0]), _lib.ptr(dgb[1]), _lib.ptr(dY), _lib.ptr(ws), st)
@@ -491,6 +511,7 @@ def _chain_ok(rows, parts):
     return True
 
 
+CHAIN_BWD_LOADER = True  # the chain's input-gradient GEMMs form dY in their loader waves (else: apply pass + library GEMM)
 CHAIN_LOADER = True    # hidden layers' BatchNorm + activation in the loader waves of the split-role GEMM, activated rows as
                        # its side output, layer-wise backward (else: the prologue / backward-fused variants in the MFMA waves)
 USE_MLP_CHAIN = True   # loader mode measured (tools/exp_r02c.sh): 8.88 vs 9.08 ms/step, forward 3.61 vs 3.86 ms.  With
