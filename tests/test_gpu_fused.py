@@ -629,7 +629,7 @@ def test_split_role_input_gradient_gemm_forms_dy_in_its_loaders(M, N, K):
     out = torch.full((M, N), float("nan"), device=DEV)
     dY = torch.full((M, K), float("nan"), device=DEV)
     _lib.call("tp3d_gemm_rows_bnbwd_sp_f32", _lib.ptr(Y), _lib.ptr(dA), _lib.ptr(mean32), _lib.ptr(scale), _lib.ptr(beta), _lib.ptr(red[2]),
-              _lib.ptr(red[3]), 0.01, _lib.ptr(Wt), M, N, K, _lib.ptr(out), _lib.ptr(dY), st)
+              _lib.ptr(red[3]), 0.01, _lib.ptr(Wt), M, N, K, _lib.ptr(out), N, _lib.ptr(dY), st)
     torch.cuda.synchronize()
     yc = Y.double() - mean32.double()
     z = yc * scale.double() + beta.double()
@@ -645,6 +645,47 @@ def test_split_role_input_gradient_gemm_forms_dy_in_its_loaders(M, N, K):
     # without the side output: the same product
     out2 = torch.empty_like(out)
     _lib.call("tp3d_gemm_rows_bnbwd_sp_f32", _lib.ptr(Y), _lib.ptr(dA), _lib.ptr(mean32), _lib.ptr(scale), _lib.ptr(beta), _lib.ptr(red[2]),
-              _lib.ptr(red[3]), 0.01, _lib.ptr(Wt), M, N, K, _lib.ptr(out2), None, st)
+              _lib.ptr(red[3]), 0.01, _lib.ptr(Wt), M, N, K, _lib.ptr(out2), N, None, st)
     assert torch.equal(out2, out)
+    # into a column range of wider rows (the feature columns of grouped rows): nothing outside it is touched
+    wide = torch.full((M, N + 8), 7.0, device=DEV)
+    _lib.call("tp3d_gemm_rows_bnbwd_sp_f32", _lib.ptr(Y), _lib.ptr(dA), _lib.ptr(mean32), _lib.ptr(scale), _lib.ptr(beta), _lib.ptr(red[2]),
+              _lib.ptr(red[3]), 0.01, _lib.ptr(Wt), M, N, K, wide.data_ptr() + 12, N + 8, None, st)
+    assert torch.equal(wide[:, 3:3 + N], out) and bool((wide[:, :3] == 7).all()) and bool((wide[:, 3 + N:] == 7).all())
     assert h.tp3d_gemm_rows_bnbwd_sp_serves(M, N, 260) == 0 and h.tp3d_gemm_rows_bnbwd_sp_serves(4096, N, K) == 0
+
+
+def test_chain_contracts_only_the_feature_columns_of_grouped_rows():
+    """Grouped rows are [relative position (3), features (C), padding]; their producer reads the gradient of the feature
+    columns only, and the chain's first input-gradient GEMM computes just those (the rest stays zero): the gradient that
+    reaches the features must not change."""
+    import copy
+    from torch_points3d_amd import fused
+    from torch_points3d_amd import torchpoints as tp
+    from torch_points3d_amd.dense import MLP2D
+    torch.manual_seed(2)
+    B, N, npnt, ns, C = 8, 4096, 256, 32, 128
+    pos = (torch.rand(B, N, 3, device=DEV) * 2 - 1)
+    new_pos = pos[:, :npnt].contiguous()
+    idx = tp.ball_query(0.3, ns, pos, new_pos)[0]
+    mlp = MLP2D([C + 3, 128, 128]).to(DEV).train()
+    twin = copy.deepcopy(mlp)
+    xa = torch.randn(B, N, C, device=DEV).requires_grad_(True)
+    xb = xa.detach().clone().requires_grad_(True)
+    old = fused.CHAIN_MIN_ROWS, fused.USE_MLP_CHAIN, fused.CHAIN_BWD_LOADER
+    try:
+        fused.CHAIN_MIN_ROWS, fused.USE_MLP_CHAIN, fused.CHAIN_BWD_LOADER = 0, True, True
+        rows = fused.group_concat(pos, new_pos, xa, idx, 0.3, True)
+        assert rows._tp3d_grad_cols == (3, C) and rows.shape[1] == 132
+        out = fused.run_mlp(rows, fused.mlp_parts(mlp), ns)
+        fused.CHAIN_BWD_LOADER = False
+        want = fused.run_mlp(fused.group_concat(pos, new_pos, xb, idx, 0.3, True), fused.mlp_parts(twin), ns)
+    finally:
+        fused.CHAIN_MIN_ROWS, fused.USE_MLP_CHAIN, fused.CHAIN_BWD_LOADER = old
+    torch.testing.assert_close(out, want, rtol=1e-5, atol=1e-5)
+    cot = torch.randn_like(out)
+    out.backward(cot)
+    want.backward(cot)
+    assert float((xa.grad - xb.grad).norm() / xb.grad.norm()) < 1e-3
+    for (k, a), (_, b) in zip(mlp.named_parameters(), twin.named_parameters()):
+        assert float((a.grad - b.grad).norm() / (b.grad.norm() + 1e-12)) < 1e-3, k

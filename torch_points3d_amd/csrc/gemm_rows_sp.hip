@@ -43,8 +43,9 @@ struct SpPro {
 template <int STATS, int PRO, int BN>
 __global__ __launch_bounds__(SP_BLOCK, 4) void gemm_rows_sp_kernel(const float *__restrict__ A, const float *__restrict__ Bt,
                                                                 int64_t M, int N, int K, int tiles_n, int64_t items,
-                                                                float *__restrict__ C, float *__restrict__ partial,
-                                                                float *__restrict__ act_out, SpPro pro)
+                                                                float *__restrict__ C, int64_t ldc,
+                                                                float *__restrict__ partial, float *__restrict__ act_out,
+                                                                SpPro pro)
 {
     constexpr int KMAX = PRO == 2 ? SP_BWD_KMAX : SP_PRO_KMAX;
     __shared__ __attribute__((aligned(16))) float sK[PRO == 2 ? 5 * KMAX : (PRO ? 3 * KMAX : 4)];
@@ -335,7 +336,7 @@ __global__ __launch_bounds__(SP_BLOCK, 4) void gemm_rows_sp_kernel(const float *
 #pragma unroll
                     for (int e = 0; e < 16; ++e) {
                         const int64_t m = m0 + (wr * 2 + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-                        if (m < M && n < N) C[m * N + n] = acc[i][j][e];
+                        if (m < M && n < N) C[m * ldc + n] = acc[i][j][e];
                     }
                 }
             if (STATS != 0) {
@@ -433,7 +434,7 @@ TP3D_EXPORT int tp3d_gemm_rows_bnact_sp_f32(const float *Y, const float *mean, c
     hipStream_t s = (hipStream_t)stream;
 #define TP3D_SP_LAUNCH(STATS, BN)                                                                                     \
     hipLaunchKernelGGL((gemm_rows_sp_kernel<STATS, 1, BN>), dim3(grid), dim3(SP_BLOCK), 0, s, Y, Bt, M, N, K, tiles_n, items, \
-                       C, stat_partial, act_out, pro)
+                       C, (int64_t)N, stat_partial, act_out, pro)
     if (N <= 64) {
         if (stat_partial)
             TP3D_SP_LAUNCH(2, 64);
@@ -454,20 +455,21 @@ TP3D_EXPORT int tp3d_gemm_rows_bnbwd_sp_serves(int64_t M, int N, int K) { return
 
 TP3D_EXPORT int tp3d_gemm_rows_bnbwd_sp_f32(const float *Y, const float *dA, const float *mean, const float *scale,
                                             const float *beta, const float *c1, const float *c2, float slope,
-                                            const float *Bt, int64_t M, int N, int K, float *C, float *dY_out, void *stream)
+                                            const float *Bt, int64_t M, int N, int K, float *C, int ldc, float *dY_out,
+                                            void *stream)
 {
     using namespace tp3d;
     const int tiles_n = sp_tiles_n(M, N, K, SP_BWD_KMAX);
-    if (!tiles_n || !Y || !dA || !mean || !scale || !beta || !c1 || !c2 || !Bt || !C) return TP3D_E_BADARG;
+    if (!tiles_n || ldc < N || !Y || !dA || !mean || !scale || !beta || !c1 || !c2 || !Bt || !C) return TP3D_E_BADARG;
     const int64_t items = sp_items(M, tiles_n);
     const int grid = sp_grid(items, true);
     SpPro pro{mean, scale, beta, slope, dA, c1, c2};
     hipStream_t s = (hipStream_t)stream;
     if (N <= 64)
         hipLaunchKernelGGL((gemm_rows_sp_kernel<0, 2, 64>), dim3(grid), dim3(SP_BLOCK), 0, s, Y, Bt, M, N, K, tiles_n, items, C,
-                           (float *)nullptr, dY_out, pro);
+                           (int64_t)ldc, (float *)nullptr, dY_out, pro);
     else
         hipLaunchKernelGGL((gemm_rows_sp_kernel<0, 2, 128>), dim3(grid), dim3(SP_BLOCK), 0, s, Y, Bt, M, N, K, tiles_n, items, C,
-                           (float *)nullptr, dY_out, pro);
+                           (int64_t)ldc, (float *)nullptr, dY_out, pro);
     return check_launch();
 }

@@ -334,8 +334,9 @@ class _MLPChain(torch.autograd.Function):
     the pre-BatchNorm outputs Y_l are kept for the backward pass."""
 
     @staticmethod
-    def forward(ctx, A0, pool_ns, layers, *params):
-        # layers: [(bn module, slope)], params: [weight_0, gamma_0, beta_0, weight_1, ...]
+    def forward(ctx, A0, pool_ns, layers, grad_cols, *params):
+        # layers: [(bn module, slope)], params: [weight_0, gamma_0, beta_0, weight_1, ...]; grad_cols: None or (first, count) --
+        # the only columns of A0 whose gradient the producer of A0 reads (grouped rows: the feature columns)
         dev = A0.device
         A0 = A0.contiguous()
         M = A0.shape[0]
@@ -408,6 +409,7 @@ class _MLPChain(torch.autograd.Function):
         ctx.save_for_backward(A0, arg, *Ys, *stats, *W2s, *(acts if layerwise else []))
         ctx.cfg = (L, pool_ns, training, [s_ for _, s_ in layers], [tuple(params[3 * l].shape) for l in range(L)], cins)
         ctx.layerwise = layerwise
+        ctx.grad_cols = grad_cols
         return out
 
     @staticmethod
@@ -433,20 +435,32 @@ class _MLPChain(torch.autograd.Function):
                     dY = torch.empty_like(Y)
                     ws = _lib.bn_workspace(M, C, dev)
                     want_prev = l > 0 or ctx.needs_input_grad[0]
+                    # the grouped rows' producer reads the gradient of the feature columns only: contract just those
+                    cols = ctx.grad_cols if (l == 0 and ctx.grad_cols is not None and ctx.grad_cols[1] >= ROWS_GEMM_MIN_COLS) else None
+                    ncol = cols[1] if cols else Kp
                     if (CHAIN_BWD_LOADER and not pooled and want_prev
-                            and _lib.load().tp3d_gemm_rows_bnbwd_sp_serves(M, Kp, C)):
+                            and _lib.load().tp3d_gemm_rows_bnbwd_sp_serves(M, ncol, C)):
                         # reduction pass, then the input-gradient GEMM whose loader waves form dY (side output for dW)
                         red = torch.empty((4, C), dtype=torch.float32, device=dev)  # dbeta, dgamma, c1, c2
                         _lib.call("tp3d_bn_bwd_reduce_f32", _lib.ptr(dcur), None, _lib.ptr(Y), _lib.ptr(ls[2]), _lib.ptr(ls[3]),
                                   _lib.ptr(ls[0]), _lib.ptr(ls[1]), slope, M, 1, C, int(training), _lib.ptr(red[0]), _lib.ptr(red[1]),
                                   _lib.ptr(red[2]), _lib.ptr(red[3]), _lib.ptr(ws), st)
                         grads[3 * l + 1], grads[3 * l + 2] = red[1], red[0]
-                        Wt = W2.t().contiguous()  # (Kp, C): dA_{l-1}[M,Kp] = dY_l[M,C] (W^T)[Kp,C]^T
+                        Wt = W2.t()  # (Kp, C): dA_{l-1}[M,Kp] = dY_l[M,C] (W^T)[Kp,C]^T
                         dprev = torch.empty((M, Kp), dtype=torch.float32, device=dev)
+                        c_ptr = _lib.ptr(dprev)
+                        if cols:
+                            Wt = Wt[cols[0]:cols[0] + ncol]
+                            c_ptr += 4 * cols[0]
+                            if cols[0]:
+                                dprev[:, :cols[0]].zero_()  # the columns nobody reads stay defined
+                            if cols[0] + ncol < Kp:
+                                dprev[:, cols[0] + ncol:].zero_()
+                        Wt = Wt.contiguous()
                         _lib.call("tp3d_gemm_rows_bnbwd_sp_f32", _lib.ptr(Y), _lib.ptr(dcur), _lib.ptr(ls[0]), _lib.ptr(ls[2]),
-                                  _lib.ptr(ls[3]), _lib.ptr(red[2]), _lib.ptr(red[3]), slope, _lib.ptr(Wt), M, Kp, C, _lib.ptr(dprev),
-                                  _lib.ptr(dY) if ctx.needs_input_grad[3 + 3 * l] else None, st)
-                        if ctx.needs_input_grad[3 + 3 * l]:
+                                  _lib.ptr(ls[3]), _lib.ptr(red[2]), _lib.ptr(red[3]), slope, _lib.ptr(Wt), M, ncol, C, c_ptr, Kp,
+                                  _lib.ptr(dY) if ctx.needs_input_grad[4 + 3 * l] else None, st)
+                        if ctx.needs_input_grad[4 + 3 * l]:
                             grads[3 * l] = gemm_tn(dY, A0 if l == 0 else acts[l - 1])[:, :cins[l]].reshape(wshapes[l])
                         dcur = dprev
                         if l == 0:
@@ -457,13 +471,13 @@ class _MLPChain(torch.autograd.Function):
                               _lib.ptr(ls[3]), _lib.ptr(ls[0]), _lib.ptr(ls[1]), slope, M, pool_ns if pooled else 1, C,
                               int(training), _lib.ptr(dgb[0]), _lib.ptr(dgb[1]), _lib.ptr(dY), _lib.ptr(ws), st)
                     grads[3 * l + 1], grads[3 * l + 2] = dgb[1], dgb[0]
-                    if ctx.needs_input_grad[3 + 3 * l]:
+                    if ctx.needs_input_grad[4 + 3 * l]:
                         grads[3 * l] = gemm_tn(dY, A0 if l == 0 else acts[l - 1])[:, :cins[l]].reshape(wshapes[l])
                     if l > 0 or ctx.needs_input_grad[0]:
                         dcur = torch.mm(dY, W2)
                         if l == 0:
                             dA0 = dcur
-            return (dA0, None, None) + tuple(grads)
+            return (dA0, None, None, None) + tuple(grads)
         with _lib.on_device(dev):
             for l in range(L - 1, -1, -1):
                 Y, ls, W2, slope = Ys[l], stats[l], W2s[l], slopes[l]
@@ -476,7 +490,7 @@ class _MLPChain(torch.autograd.Function):
                           _lib.ptr(ls[0]), _lib.ptr(ls[1]), slope, M, ns, C, int(training), _lib.ptr(red[0]), _lib.ptr(red[1]),
                           _lib.ptr(red[2]), _lib.ptr(red[3]), _lib.ptr(ws), st)
                 grads[3 * l + 1], grads[3 * l + 2] = red[1], red[0]
-                if ctx.needs_input_grad[3 + 3 * l]:
+                if ctx.needs_input_grad[4 + 3 * l]:
                     dW = torch.empty((C, Kp), dtype=torch.float32, device=dev)
                     tws = _lib.gemm_tn_workspace(M, C, Kp, dev)
                     if l == 0:
@@ -497,7 +511,7 @@ class _MLPChain(torch.autograd.Function):
                     dcur = dprev
                     if l == 0:
                         dA0 = dprev
-        return (dA0, None, None) + tuple(grads)
+        return (dA0, None, None, None) + tuple(grads)
 
 
 def _chain_ok(rows, parts):
@@ -669,7 +683,7 @@ def run_mlp(rows, parts, pool_ns=0):
         flat = []
         for conv, bn, slope in parts:
             flat += [conv.weight, bn.weight, bn.bias]
-        return _MLPChain.apply(rows, pool_ns, [(bn, slope) for _, bn, slope in parts], *flat)
+        return _MLPChain.apply(rows, pool_ns, [(bn, slope) for _, bn, slope in parts], getattr(rows, "_tp3d_grad_cols", None), *flat)
     for i, (conv, bn, slope) in enumerate(parts):
         rows = linear_bn_act(rows, conv, bn, slope, pool_ns if i == len(parts) - 1 else 0)
     return rows
@@ -735,7 +749,10 @@ class _GroupConcat(torch.autograd.Function):
 
 
 def group_concat(pos, new_pos, x_cl, idx, radius, normalize, table=None):
-    return _GroupConcat.apply(pos, new_pos, x_cl, idx, radius, normalize, table)
+    rows = _GroupConcat.apply(pos, new_pos, x_cl, idx, radius, normalize, table)
+    if x_cl is not None:
+        rows._tp3d_grad_cols = (3, x_cl.shape[2])  # _GroupConcat.backward reads these columns of the gradient and no others
+    return rows
 
 
 class _InterpConcat(torch.autograd.Function):
@@ -782,7 +799,12 @@ class _InterpConcat(torch.autograd.Function):
 
 
 def interp_concat(feat_cl, idx, weight, skip_cl, table=None):
-    return _InterpConcat.apply(feat_cl, idx, weight, skip_cl, table)
+    rows = _InterpConcat.apply(feat_cl, idx, weight, skip_cl, table)
+    if skip_cl is not None and not (skip_cl.requires_grad and torch.is_grad_enabled()):
+        # the skip columns carry no gradient (the network's input features): _InterpConcat.backward reads the interpolated
+        # columns of the rows' gradient and no others
+        rows._tp3d_grad_cols = (0, feat_cl.shape[2])
+    return rows
 
 
 def cat_rows(parts):
