@@ -629,7 +629,7 @@ def test_split_role_input_gradient_gemm_forms_dy_in_its_loaders(M, N, K):
     out = torch.full((M, N), float("nan"), device=DEV)
     dY = torch.full((M, K), float("nan"), device=DEV)
     _lib.call("tp3d_gemm_rows_bnbwd_sp_f32", _lib.ptr(Y), _lib.ptr(dA), _lib.ptr(mean32), _lib.ptr(scale), _lib.ptr(beta), _lib.ptr(red[2]),
-              _lib.ptr(red[3]), 0.01, _lib.ptr(Wt), M, N, K, _lib.ptr(out), N, _lib.ptr(dY), st)
+              _lib.ptr(red[3]), 0.01, _lib.ptr(Wt), M, N, K, _lib.ptr(out), N, _lib.ptr(dY), None, 1, st)
     torch.cuda.synchronize()
     yc = Y.double() - mean32.double()
     z = yc * scale.double() + beta.double()
@@ -645,12 +645,12 @@ def test_split_role_input_gradient_gemm_forms_dy_in_its_loaders(M, N, K):
     # without the side output: the same product
     out2 = torch.empty_like(out)
     _lib.call("tp3d_gemm_rows_bnbwd_sp_f32", _lib.ptr(Y), _lib.ptr(dA), _lib.ptr(mean32), _lib.ptr(scale), _lib.ptr(beta), _lib.ptr(red[2]),
-              _lib.ptr(red[3]), 0.01, _lib.ptr(Wt), M, N, K, _lib.ptr(out2), N, None, st)
+              _lib.ptr(red[3]), 0.01, _lib.ptr(Wt), M, N, K, _lib.ptr(out2), N, None, None, 1, st)
     assert torch.equal(out2, out)
     # into a column range of wider rows (the feature columns of grouped rows): nothing outside it is touched
     wide = torch.full((M, N + 8), 7.0, device=DEV)
     _lib.call("tp3d_gemm_rows_bnbwd_sp_f32", _lib.ptr(Y), _lib.ptr(dA), _lib.ptr(mean32), _lib.ptr(scale), _lib.ptr(beta), _lib.ptr(red[2]),
-              _lib.ptr(red[3]), 0.01, _lib.ptr(Wt), M, N, K, wide.data_ptr() + 12, N + 8, None, st)
+              _lib.ptr(red[3]), 0.01, _lib.ptr(Wt), M, N, K, wide.data_ptr() + 12, N + 8, None, None, 1, st)
     assert torch.equal(wide[:, 3:3 + N], out) and bool((wide[:, :3] == 7).all()) and bool((wide[:, 3 + N:] == 7).all())
     assert h.tp3d_gemm_rows_bnbwd_sp_serves(M, N, 260) == 0 and h.tp3d_gemm_rows_bnbwd_sp_serves(4096, N, K) == 0
 
@@ -689,3 +689,32 @@ def test_chain_contracts_only_the_feature_columns_of_grouped_rows():
     assert float((xa.grad - xb.grad).norm() / xb.grad.norm()) < 1e-3
     for (k, a), (_, b) in zip(mlp.named_parameters(), twin.named_parameters()):
         assert float((a.grad - b.grad).norm() / (b.grad.norm() + 1e-12)) < 1e-3, k
+
+
+@pytest.mark.parametrize("M,N,K,ns", [(65536 * 2, 128, 128, 64), (66048, 64, 256, 64), (131072, 128, 64, 128), (67072, 256, 128, 256)])
+def test_split_role_input_gradient_gemm_with_pooled_gradient(M, N, K, ns):
+    """The same kernel fed with the gradient of the max-pooled output and the winning rows: dY side output against the
+    dense form of the same kernel on the scattered gradient (bit for bit), and the product likewise."""
+    from torch_points3d_amd import _lib
+    g = torch.Generator().manual_seed(M + ns)
+    G = M // ns
+    Y = (torch.randn(M, K, generator=g) * 1.5 + 0.2).to(DEV)
+    dP = torch.randn(G, K, generator=g).to(DEV)
+    arg = torch.randint(0, ns, (G, K), generator=g, dtype=torch.int32).to(DEV)
+    dense = torch.zeros(G, ns, K, device=DEV)
+    dense.scatter_(1, arg.long().unsqueeze(1), dP.unsqueeze(1))
+    dense = dense.view(M, K).contiguous()
+    Wt = (torch.randn(N, K, generator=g) * 0.2).to(DEV)
+    mean, scale, beta = (torch.randn(K, generator=g) * 0.2).to(DEV), (torch.rand(K, generator=g) + 0.5).to(DEV), \
+        (torch.randn(K, generator=g) * 0.3).to(DEV)
+    c1, c2 = (torch.randn(K, generator=g) * 0.01).to(DEV), (torch.randn(K, generator=g) * 0.01).to(DEV)
+    st = _lib.stream_ptr(Y.device)
+    outs = []
+    for dA, a_ptr, n_ in ((dense, None, 1), (dP, _lib.ptr(arg), ns)):
+        out = torch.full((M, N), float("nan"), device=DEV)
+        dY = torch.full((M, K), float("nan"), device=DEV)
+        _lib.call("tp3d_gemm_rows_bnbwd_sp_f32", _lib.ptr(Y), _lib.ptr(dA), _lib.ptr(mean), _lib.ptr(scale), _lib.ptr(beta), _lib.ptr(c1),
+                  _lib.ptr(c2), 0.01, _lib.ptr(Wt), M, N, K, _lib.ptr(out), N, _lib.ptr(dY), a_ptr, n_, st)
+        outs.append((out, dY))
+    assert torch.equal(outs[0][1], outs[1][1])
+    assert torch.equal(outs[0][0], outs[1][0])

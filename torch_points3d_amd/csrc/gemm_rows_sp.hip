@@ -37,7 +37,9 @@ constexpr int SP_BWD_KMAX = 256;
 struct SpPro {
     const float *mean, *scale, *beta;
     float slope;
-    const float *dA, *c1, *c2;  // PRO 2 only
+    const float *dA, *c1, *c2;  // PRO 2, 3
+    const int *arg;             // PRO 3: winning row (0 .. ns-1) of every (group, channel)
+    int ns_shift;               //        ns = 1 << ns_shift rows per group
 };
 
 template <int STATS, int PRO, int BN>
@@ -47,14 +49,14 @@ __global__ __launch_bounds__(SP_BLOCK, 4) void gemm_rows_sp_kernel(const float *
                                                                 float *__restrict__ partial, float *__restrict__ act_out,
                                                                 SpPro pro)
 {
-    constexpr int KMAX = PRO == 2 ? SP_BWD_KMAX : SP_PRO_KMAX;
-    __shared__ __attribute__((aligned(16))) float sK[PRO == 2 ? 5 * KMAX : (PRO ? 3 * KMAX : 4)];
+    constexpr int KMAX = PRO >= 2 ? SP_BWD_KMAX : SP_PRO_KMAX;
+    __shared__ __attribute__((aligned(16))) float sK[PRO >= 2 ? 5 * KMAX : (PRO ? 3 * KMAX : 4)];
     if (PRO) {
         for (int k = threadIdx.x; k < KMAX; k += SP_BLOCK) {
             sK[k] = k < K ? pro.mean[k] : 0.0f;
             sK[KMAX + k] = k < K ? pro.scale[k] : 0.0f;
             sK[2 * KMAX + k] = k < K ? pro.beta[k] : 0.0f;
-            if (PRO == 2) {
+            if (PRO >= 2) {
                 sK[3 * KMAX + k] = k < K ? pro.c1[k] : 0.0f;
                 sK[4 * KMAX + k] = k < K ? pro.c2[k] : 0.0f;
             }
@@ -96,7 +98,10 @@ __global__ __launch_bounds__(SP_BLOCK, 4) void gemm_rows_sp_kernel(const float *
             return make_float4(z0 > 0.0f ? z0 : z0 * pro.slope, z1 > 0.0f ? z1 : z1 * pro.slope,
                                z2 > 0.0f ? z2 : z2 * pro.slope, z3 > 0.0f ? z3 : z3 * pro.slope);
         };
-        if constexpr (PRO == 2) {
+        if constexpr (PRO >= 2) {
+            // PRO 3: dA is the gradient of the max-POOLED output (M / ns rows) with the winning row of every group: it is
+            // small and L2-resident like the weights, so it travels with the B operand, one step ahead
+            constexpr bool POOL = PRO == 3;
             // ---- backward prologue: two A streams (Y, dA) two K-steps ahead, the small B operand (L2-resident weights) one
             // step ahead and issued BEFORE the A loads of its iteration, so that waiting for it leaves the newest A stage
             // in flight (loads complete in order)
@@ -117,7 +122,7 @@ __global__ __launch_bounds__(SP_BLOCK, 4) void gemm_rows_sp_kernel(const float *
                                    one(raw.z, d.z, mu.z, sc.z, be.z, c1.z, c2.z), one(raw.w, d.w, mu.w, sc.w, be.w, c1.w, c2.w));
             };
             const float *dA = pro.dA;
-            int64_t g_item = blockIdx.x;  // the B cursor (one step behind the A cursor)
+            int64_t g_item = blockIdx.x, g_m0 = f_m0;  // the B cursor (one step behind the A cursor)
             int g_n0 = f_n0, g_ks = 0;
 #define SP_FETCH_A(S)                                                                                                 \
     do {                                                                                                              \
@@ -125,10 +130,12 @@ __global__ __launch_bounds__(SP_BLOCK, 4) void gemm_rows_sp_kernel(const float *
         const int kk = min(k0_##S + fk4, K - 4);                                                                      \
         const int64_t o0 = min(f_m0 + frow + 0, M - 1) * K + kk, o1 = min(f_m0 + frow + 32, M - 1) * K + kk;          \
         const int64_t o2 = min(f_m0 + frow + 64, M - 1) * K + kk, o3 = min(f_m0 + frow + 96, M - 1) * K + kk;         \
-        y0_##S = *reinterpret_cast<const float4 *>(A + o0), d0_##S = *reinterpret_cast<const float4 *>(dA + o0);      \
-        y1_##S = *reinterpret_cast<const float4 *>(A + o1), d1_##S = *reinterpret_cast<const float4 *>(dA + o1);      \
-        y2_##S = *reinterpret_cast<const float4 *>(A + o2), d2_##S = *reinterpret_cast<const float4 *>(dA + o2);      \
-        y3_##S = *reinterpret_cast<const float4 *>(A + o3), d3_##S = *reinterpret_cast<const float4 *>(dA + o3);      \
+        y0_##S = *reinterpret_cast<const float4 *>(A + o0), y1_##S = *reinterpret_cast<const float4 *>(A + o1);       \
+        y2_##S = *reinterpret_cast<const float4 *>(A + o2), y3_##S = *reinterpret_cast<const float4 *>(A + o3);       \
+        if constexpr (!POOL) {                                                                                        \
+            d0_##S = *reinterpret_cast<const float4 *>(dA + o0), d1_##S = *reinterpret_cast<const float4 *>(dA + o1); \
+            d2_##S = *reinterpret_cast<const float4 *>(dA + o2), d3_##S = *reinterpret_cast<const float4 *>(dA + o3); \
+        }                                                                                                             \
         if (++f_ks == ksteps) {                                                                                       \
             f_ks = 0;                                                                                                 \
             f_item += gridDim.x;                                                                                      \
@@ -145,17 +152,30 @@ __global__ __launch_bounds__(SP_BLOCK, 4) void gemm_rows_sp_kernel(const float *
             b2 = *reinterpret_cast<const float4 *>(Bt + (size_t)min(g_n0 + frow + 64, N - 1) * K + kk);               \
             b3 = *reinterpret_cast<const float4 *>(Bt + (size_t)min(g_n0 + frow + 96, N - 1) * K + kk);               \
         }                                                                                                             \
+        if constexpr (POOL) { /* groups of >= 64 rows: tile rows r and r + 32 share their group */                    \
+            const int64_t g0 = (min(g_m0 + frow + 0, M - 1) >> pro.ns_shift) * K + kk;                                \
+            const int64_t g2 = (min(g_m0 + frow + 64, M - 1) >> pro.ns_shift) * K + kk;                               \
+            p0 = *reinterpret_cast<const float4 *>(dA + g0), q0 = *reinterpret_cast<const int4 *>(pro.arg + g0);      \
+            p2 = *reinterpret_cast<const float4 *>(dA + g2), q2 = *reinterpret_cast<const int4 *>(pro.arg + g2);      \
+        }                                                                                                             \
         if (++g_ks == ksteps) {                                                                                       \
             g_ks = 0;                                                                                                 \
             g_item += gridDim.x;                                                                                      \
-            int64_t unused_m0;                                                                                        \
-            decode(g_item, unused_m0, g_n0);                                                                          \
+            decode(g_item, g_m0, g_n0);                                                                               \
         }                                                                                                             \
     } while (0)
 #define SP_STASH_D(S, BUF, I)                                                                                         \
     do {                                                                                                              \
         const bool in = kin && m0_##S + frow + 32 * I < M;                                                            \
-        const float4 v = sp_keep(in, bwd4(y##I##_##S, d##I##_##S, k0_##S + fk4));                                     \
+        float4 dd;                                                                                                    \
+        if constexpr (POOL) {                                                                                         \
+            const int srow = (int)(m0_##S + frow + 32 * I) & ((1 << pro.ns_shift) - 1);                               \
+            dd = make_float4(q##I.x == srow ? p##I.x : 0.0f, q##I.y == srow ? p##I.y : 0.0f,                          \
+                             q##I.z == srow ? p##I.z : 0.0f, q##I.w == srow ? p##I.w : 0.0f);                         \
+        } else {                                                                                                      \
+            dd = d##I##_##S;                                                                                          \
+        }                                                                                                             \
+        const float4 v = sp_keep(in, bwd4(y##I##_##S, dd, k0_##S + fk4));                                             \
         *reinterpret_cast<float4 *>(da + I * 32 * SP_LD) = v;                                                         \
         if (side && in) *reinterpret_cast<float4 *>(act_out + (m0_##S + frow + 32 * I) * K + k0_##S + fk4) = v;       \
     } while (0)
@@ -176,7 +196,10 @@ __global__ __launch_bounds__(SP_BLOCK, 4) void gemm_rows_sp_kernel(const float *
         }                                                                                                             \
     } while (0)
             float4 y0_0, y1_0, y2_0, y3_0, d0_0, d1_0, d2_0, d3_0, y0_1, y1_1, y2_1, y3_1, d0_1, d1_1, d2_1, d3_1;
-            float4 b0, b1, b2, b3;
+            float4 b0, b1, b2, b3, p0, p2;
+            int4 q0, q2;
+            float4 &p1 = p0, &p3 = p2;  // (tile rows r + 32 and r + 96: the groups of r and r + 64)
+            int4 &q1 = q0, &q3 = q2;
             int64_t m0_0, m0_1;
             int n0_0, n0_1, k0_0, k0_1, bn0, bk0;
             SP_FETCH_B();   // B of step 0
@@ -430,7 +453,7 @@ TP3D_EXPORT int tp3d_gemm_rows_bnact_sp_f32(const float *Y, const float *mean, c
     if (!tiles_n || !Y || !mean || !scale || !beta || !Bt || !C) return TP3D_E_BADARG;
     const int64_t items = sp_items(M, tiles_n);
     const int grid = sp_grid(items, act_out != nullptr);
-    SpPro pro{mean, scale, beta, slope, nullptr, nullptr, nullptr};
+    SpPro pro{mean, scale, beta, slope, nullptr, nullptr, nullptr, nullptr, 0};
     hipStream_t s = (hipStream_t)stream;
 #define TP3D_SP_LAUNCH(STATS, BN)                                                                                     \
     hipLaunchKernelGGL((gemm_rows_sp_kernel<STATS, 1, BN>), dim3(grid), dim3(SP_BLOCK), 0, s, Y, Bt, M, N, K, tiles_n, items, \
@@ -456,20 +479,32 @@ TP3D_EXPORT int tp3d_gemm_rows_bnbwd_sp_serves(int64_t M, int N, int K) { return
 TP3D_EXPORT int tp3d_gemm_rows_bnbwd_sp_f32(const float *Y, const float *dA, const float *mean, const float *scale,
                                             const float *beta, const float *c1, const float *c2, float slope,
                                             const float *Bt, int64_t M, int N, int K, float *C, int ldc, float *dY_out,
-                                            void *stream)
+                                            const int *argmax, int ns, void *stream)
 {
     using namespace tp3d;
     const int tiles_n = sp_tiles_n(M, N, K, SP_BWD_KMAX);
     if (!tiles_n || ldc < N || !Y || !dA || !mean || !scale || !beta || !c1 || !c2 || !Bt || !C) return TP3D_E_BADARG;
+    if (argmax && (ns < 64 || (ns & (ns - 1)) || M % ns)) return TP3D_E_BADARG;  // groups of 64, 128, ... rows
+    int ns_shift = 0;
+    while (argmax && (1 << ns_shift) < ns) ++ns_shift;
     const int64_t items = sp_items(M, tiles_n);
     const int grid = sp_grid(items, true);
-    SpPro pro{mean, scale, beta, slope, dA, c1, c2};
+    SpPro pro{mean, scale, beta, slope, dA, c1, c2, argmax, ns_shift};
     hipStream_t s = (hipStream_t)stream;
-    if (N <= 64)
-        hipLaunchKernelGGL((gemm_rows_sp_kernel<0, 2, 64>), dim3(grid), dim3(SP_BLOCK), 0, s, Y, Bt, M, N, K, tiles_n, items, C,
-                           (int64_t)ldc, (float *)nullptr, dY_out, pro);
-    else
-        hipLaunchKernelGGL((gemm_rows_sp_kernel<0, 2, 128>), dim3(grid), dim3(SP_BLOCK), 0, s, Y, Bt, M, N, K, tiles_n, items, C,
-                           (int64_t)ldc, (float *)nullptr, dY_out, pro);
+#define TP3D_SP_BWD(PRO, BN)                                                                                          \
+    hipLaunchKernelGGL((gemm_rows_sp_kernel<0, PRO, BN>), dim3(grid), dim3(SP_BLOCK), 0, s, Y, Bt, M, N, K, tiles_n, items, C, \
+                       (int64_t)ldc, (float *)nullptr, dY_out, pro)
+    if (argmax) {
+        if (N <= 64)
+            TP3D_SP_BWD(3, 64);
+        else
+            TP3D_SP_BWD(3, 128);
+    } else {
+        if (N <= 64)
+            TP3D_SP_BWD(2, 64);
+        else
+            TP3D_SP_BWD(2, 128);
+    }
+#undef TP3D_SP_BWD
     return check_launch();
 }

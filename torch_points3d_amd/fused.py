@@ -438,12 +438,14 @@ class _MLPChain(torch.autograd.Function):
                     # the grouped rows' producer reads the gradient of the feature columns only: contract just those
                     cols = ctx.grad_cols if (l == 0 and ctx.grad_cols is not None and ctx.grad_cols[1] >= ROWS_GEMM_MIN_COLS) else None
                     ncol = cols[1] if cols else Kp
-                    if (CHAIN_BWD_LOADER and not pooled and want_prev
+                    pool_pow2 = pooled and pool_ns >= 64 and (pool_ns & (pool_ns - 1)) == 0
+                    if (CHAIN_BWD_LOADER and (not pooled or (CHAIN_BWD_POOLED and pool_pow2)) and want_prev
                             and _lib.load().tp3d_gemm_rows_bnbwd_sp_serves(M, ncol, C)):
                         # reduction pass, then the input-gradient GEMM whose loader waves form dY (side output for dW)
                         red = torch.empty((4, C), dtype=torch.float32, device=dev)  # dbeta, dgamma, c1, c2
-                        _lib.call("tp3d_bn_bwd_reduce_f32", _lib.ptr(dcur), None, _lib.ptr(Y), _lib.ptr(ls[2]), _lib.ptr(ls[3]),
-                                  _lib.ptr(ls[0]), _lib.ptr(ls[1]), slope, M, 1, C, int(training), _lib.ptr(red[0]), _lib.ptr(red[1]),
+                        a_ptr, ns = (_lib.ptr(arg), pool_ns) if pooled else (None, 1)
+                        _lib.call("tp3d_bn_bwd_reduce_f32", _lib.ptr(dcur), a_ptr, _lib.ptr(Y), _lib.ptr(ls[2]), _lib.ptr(ls[3]),
+                                  _lib.ptr(ls[0]), _lib.ptr(ls[1]), slope, M, ns, C, int(training), _lib.ptr(red[0]), _lib.ptr(red[1]),
                                   _lib.ptr(red[2]), _lib.ptr(red[3]), _lib.ptr(ws), st)
                         grads[3 * l + 1], grads[3 * l + 2] = red[1], red[0]
                         Wt = W2.t()  # (Kp, C): dA_{l-1}[M,Kp] = dY_l[M,C] (W^T)[Kp,C]^T
@@ -459,7 +461,7 @@ class _MLPChain(torch.autograd.Function):
                         Wt = Wt.contiguous()
                         _lib.call("tp3d_gemm_rows_bnbwd_sp_f32", _lib.ptr(Y), _lib.ptr(dcur), _lib.ptr(ls[0]), _lib.ptr(ls[2]),
                                   _lib.ptr(ls[3]), _lib.ptr(red[2]), _lib.ptr(red[3]), slope, _lib.ptr(Wt), M, ncol, C, c_ptr, Kp,
-                                  _lib.ptr(dY) if ctx.needs_input_grad[4 + 3 * l] else None, st)
+                                  _lib.ptr(dY) if ctx.needs_input_grad[4 + 3 * l] else None, a_ptr, ns, st)
                         if ctx.needs_input_grad[4 + 3 * l]:
                             grads[3 * l] = gemm_tn(dY, A0 if l == 0 else acts[l - 1])[:, :cins[l]].reshape(wshapes[l])
                         dcur = dprev
@@ -525,6 +527,7 @@ def _chain_ok(rows, parts):
     return True
 
 
+CHAIN_BWD_POOLED = True  # ... also for the max-pooled last layer of a set-abstraction MLP (groups of 64, 128 ... rows)
 CHAIN_BWD_LOADER = True  # the chain's input-gradient GEMMs form dY in their loader waves (else: apply pass + library GEMM)
 CHAIN_LOADER = True    # hidden layers' BatchNorm + activation in the loader waves of the split-role GEMM, activated rows as
                        # its side output, layer-wise backward (else: the prologue / backward-fused variants in the MFMA waves)
