@@ -165,6 +165,12 @@ def algorithmic_bytes(name, a):
     if name in ("tp3d_gemm_tn_f32", "tp3d_gemm_rows_f32", "tp3d_gemm_rows_bnact_f32"):  # M, N, K
         M, N, K = a[:3]
         return (M * (N + K) + N * K) * 4
+    if name == "tp3d_gemm_rows_bnact_sp_f32":  # M, N, K (the side output of the training launches, M * K more, not counted)
+        M, N, K = a[:3]
+        return (M * (N + K) + N * K) * 4
+    if name == "tp3d_gemm_rows_bnbwd_sp_f32":  # M, N, K, ldc, ns: Y and dA (dense, or pooled + winning rows) in, dY and C out
+        M, N, K, _, ns = a[:5]
+        return (2 * M * K + (M // ns) * K * (1 if ns == 1 else 2) + M * N + N * K) * 4
     if name == "tp3d_gemm_rows_bnbwd_f32":  # ns, M, N, K: Y and dA (dense, or pooled M/ns rows + argmax) in, C out
         ns, M, N, K = a[:4]
         return (M * K + (M // ns) * K * (1 if ns == 1 else 2) + M * N + N * K) * 4
@@ -189,6 +195,9 @@ def algorithmic_flops(name, a):
         return 2 * M * N * K
     if name in ("tp3d_gemm_rows_bnbwd_f32", "tp3d_gemm_tn_bn_f32"):  # ns, M, N, K
         ns, M, N, K = a[:4]
+        return 2 * M * N * K
+    if name in ("tp3d_gemm_rows_bnact_sp_f32", "tp3d_gemm_rows_bnbwd_sp_f32"):  # M, N, K
+        M, N, K = a[:3]
         return 2 * M * N * K
     return 0
 
