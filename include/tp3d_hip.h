@@ -255,6 +255,7 @@ int tp3d_gemm_tn_f32(const float *dY, const float *A, int64_t M, int N, int K, f
  * result dY nor the activated layer input has to exist in HBM (autograd of dense_modules.py:25-29):
  *   dY = scale_n*(dZ - c1_n - (Y - mean_n)*c2_n), dZ = dA * act'((Y - mean_n)*scale_n + beta_n)
  *        Y (M,N) pre-BatchNorm output, dA (M,N) -- or (M/ns,N) with argmax (M/ns,N) != NULL for a max-pooled output;
+ *        dA == NULL: Y is dY itself (only the A operand is formed on the fly);
  *   A  = LeakyReLU_slope_k((A - mean_k)*scale_k + beta_k) when mean_k != NULL (A = the previous layer's pre-BatchNorm
  *        output), else A as it is.
  * N % 4 == 0, K % 4 == 0; workspace as for tp3d_gemm_tn_f32. */

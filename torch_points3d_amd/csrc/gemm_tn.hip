@@ -372,9 +372,10 @@ TP3D_EXPORT int tp3d_gemm_tn_bn_f32(const float *Y, const float *dA, const int *
     if (M < 0 || N <= 0 || K <= 0 || !out || ns <= 0) return TP3D_E_BADARG;
     hipStream_t s = (hipStream_t)stream;
     if (M == 0) return zero_async(out, (size_t)N * K * sizeof(float), s);
-    if (!Y || !dA || !A || !workspace || !mean_n || !scale_n || !beta_n || !c1_n || !c2_n) return TP3D_E_BADARG;
+    if (!Y || !A || !workspace) return TP3D_E_BADARG;
+    if (dA && (!mean_n || !scale_n || !beta_n || !c1_n || !c2_n)) return TP3D_E_BADARG;  // dA == NULL: Y is dY itself
     if (mean_k && (!scale_k || !beta_k)) return TP3D_E_BADARG;
-    if (argmax && M % ns) return TP3D_E_BADARG;
+    if (argmax && (!dA || M % ns)) return TP3D_E_BADARG;
     TnPrologue pro = {};
     pro.dA = dA, pro.argmax = argmax, pro.mean_n = mean_n, pro.scale_n = scale_n, pro.beta_n = beta_n, pro.c1_n = c1_n;
     pro.c2_n = c2_n, pro.slope_n = slope_n, pro.ns = ns;
