@@ -1,13 +1,12 @@
+// EXPERIMENT (tools/probes/gemm_sp.py builds it into /tmp on the GPU box; the product form is csrc/gemm_rows_sp.hip).
 // Rows GEMM with SPLIT ROLES: C[M,N] = A[M,K] * Bt[N,K]^T (fp32 MFMA), the same contraction as gemm_rows.hip.
 //
 // A workgroup is 8 waves: waves 0-3 only issue MFMAs (2 x 2 waves, each 2 x 2 tiles of 32 x 32: a 128 x 128 output tile),
 // waves 4-7 only move data -- global loads two K-steps ahead into registers, then LDS writes into the buffer the compute
 // waves will read NEXT step.  Two LDS buffers, ONE barrier per K-step, persistent workgroups over (row block, column tile)
-// items.  In gemm_rows.hip every wave does both jobs in turn: all four waves of a workgroup wait for their loads
-// (`vmcnt(0)`), write LDS, meet at a barrier and only then start their MFMAs, so the matrix pipe idles for a third of
-// every step; here a compute wave's step is fragment reads + 64 MFMAs + one barrier that the loader waves have usually
-// reached long before.  (The loaders share the SIMDs with the compute waves: VALU / memory instructions of one wave
-// issue beside the MFMAs of another.)
+// items.  Measured as a plain GEMM it is on par with gemm_rows.hip (where every wave does both jobs in turn); probe bit 0
+// serves the input from cache and bit 1 skips the stores, to see what bounds it; PRO 1 puts a BatchNorm + LeakyReLU
+// prologue into the loader waves (free there -- DESIGN.md section 5).
 #include "tp3d_common.h"
 
 namespace tp3d {
