@@ -423,13 +423,15 @@ static int sp_grid(int64_t items, bool side) { return (side && items >= 2048) ? 
 // Not served (0): widths that end in a narrow remainder (192, 320 ... columns: gemm_rows.hip mixes tile widths there; up
 // to 64 columns run on this kernel's 128 x 64 tiles), fewer than 512 items, contractions longer than the constants' LDS
 // table.
-static int sp_tiles_n(int64_t M, int N, int K, int kmax = tp3d::SP_PRO_KMAX)
+static int sp_tiles_n(int64_t M, int N, int K, int kmax = tp3d::SP_PRO_KMAX, bool fixed_tile = true)
 {
     if (M <= 0 || N <= 0 || K < 4 || (K & 3) || K > kmax) return 0;
     const int rem = N % tp3d::SP_BN;
-    if (rem > 0 && rem <= 64 && N > 64) return 0;  // (N <= 64: one 128 x 64 tile per row block)
     const int tiles_n = (N + tp3d::SP_BN - 1) / tp3d::SP_BN;
-    if (512 % (8 * tiles_n)) return 0;
+    if (fixed_tile) {  // (the forward form: statistics per workgroup; a narrow remainder tile is gemm_rows.hip's case)
+        if (rem > 0 && rem <= 64 && N > 64) return 0;  // (N <= 64: one 128 x 64 tile per row block)
+        if (512 % (8 * tiles_n)) return 0;
+    }
     const int64_t row_blocks = (M + tp3d::SP_BM - 1) / tp3d::SP_BM;
     if ((row_blocks + 7) / 8 * 8 * tiles_n < 512) return 0;
     return tiles_n;
@@ -473,8 +475,11 @@ TP3D_EXPORT int tp3d_gemm_rows_bnact_sp_f32(const float *Y, const float *mean, c
     return check_launch();
 }
 
-// 1 when tp3d_gemm_rows_bnbwd_sp_f32 serves (M, N, K): the shape rule above with K <= 256.
-TP3D_EXPORT int tp3d_gemm_rows_bnbwd_sp_serves(int64_t M, int N, int K) { return sp_tiles_n(M, N, K, tp3d::SP_BWD_KMAX) ? 1 : 0; }
+// 1 when tp3d_gemm_rows_bnbwd_sp_f32 serves (M, N, K): K % 4 == 0, 4 <= K <= 256, any N, at least 512 output tiles.
+TP3D_EXPORT int tp3d_gemm_rows_bnbwd_sp_serves(int64_t M, int N, int K)
+{
+    return sp_tiles_n(M, N, K, tp3d::SP_BWD_KMAX, false) ? 1 : 0;
+}
 
 TP3D_EXPORT int tp3d_gemm_rows_bnbwd_sp_f32(const float *Y, const float *dA, const float *mean, const float *scale,
                                             const float *beta, const float *c1, const float *c2, float slope,
@@ -482,7 +487,7 @@ TP3D_EXPORT int tp3d_gemm_rows_bnbwd_sp_f32(const float *Y, const float *dA, con
                                             const int *argmax, int ns, void *stream)
 {
     using namespace tp3d;
-    const int tiles_n = sp_tiles_n(M, N, K, SP_BWD_KMAX);
+    const int tiles_n = sp_tiles_n(M, N, K, SP_BWD_KMAX, false);  // no statistics: any number of column tiles
     if (!tiles_n || ldc < N || !Y || !dA || !mean || !scale || !beta || !c1 || !c2 || !Bt || !C) return TP3D_E_BADARG;
     if (argmax && (ns < 64 || (ns & (ns - 1)) || M % ns)) return TP3D_E_BADARG;  // groups of 64, 128, ... rows
     int ns_shift = 0;
