@@ -163,7 +163,8 @@ def test_fused_model_equals_unfused_model():
 
 
 @pytest.mark.parametrize("M,N,K", [(1000, 64, 6), (4096, 128, 131), (70000, 10, 128), (33, 7, 5), (20000, 256, 259),
-                                   (5000, 1024, 512), (262144, 128, 128), (17, 130, 70), (3000, 64, 150), (9000, 128, 384)])
+                                   (5000, 1024, 512), (262144, 128, 128), (17, 130, 70), (3000, 64, 150), (9000, 128, 384),
+                                   (40000, 32, 128), (6000, 7, 260), (524288, 10, 128), (3000, 12, 131)])
 def test_gemm_tn_matches_fp64(M, N, K):
     """split-K MFMA weight-gradient kernel vs an fp64 evaluation (and vs torch.mm's fp32 for scale)."""
     from torch_points3d_amd import fused

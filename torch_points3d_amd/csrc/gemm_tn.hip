@@ -39,15 +39,18 @@ struct TnPrologue {
     float slope_k;
 };
 
-// Each wave owns WM x WN MFMA tiles of 32x32; the workgroup tile is (2*WM*32) x (2*WN*32).
-template <int WM, int WN, bool VECY, bool VECA, bool FUSED>
+// Each wave owns WM x WN MFMA tiles of 32x32; the four waves form a GN x (4/GN) grid, so the workgroup tile is
+// (GN*WM*32) x ((4/GN)*WN*32): 2 x 2 waves normally, 1 x 4 for a handful of output rows (the class-score layer: N = 10
+// would fill 10 of 64 tile rows otherwise, and the contraction is then bound by wasted MFMA work, not by HBM).
+template <int WM, int WN, bool VECY, bool VECA, bool FUSED, int GN = 2>
 __global__ __launch_bounds__(TN_BLOCK) void gemm_tn_partial_kernel(const float *__restrict__ dY,
                                                                     const float *__restrict__ A, int64_t M, int N,
                                                                     int K, int64_t rows_per_split, int tiles_k,
                                                                     float *__restrict__ partial /*[S][N][K]*/,
                                                                     TnPrologue pro)
 {
-    constexpr int TN = 2 * WM * 32, TK = 2 * WN * 32;
+    constexpr int GK = 4 / GN;
+    constexpr int TN = GN * WM * 32, TK = GK * WN * 32;
     // ~16-32 KiB staged per step whatever the tile shape (three-tile-wide shapes: 16 rows, so that every thread
     // owns whole float4 slots of both operands)
     constexpr int TN_BR = (WM * WN) % 3 == 0 ? 16 : 64 / (WM * WN);
@@ -63,7 +66,7 @@ __global__ __launch_bounds__(TN_BLOCK) void gemm_tn_partial_kernel(const float *
     const int64_t r_begin = (int64_t)split * rows_per_split;
     const int64_t r_end = min(r_begin + rows_per_split, M);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wr = wave >> 1, wc = wave & 1;
+    const int wr = wave / GK, wc = wave % GK;
     const int l31 = lane & 31, lh = lane >> 5;
     const bool proY = FUSED && pro.dA != nullptr, proA = FUSED && pro.mean_k != nullptr;
     const bool pooled = FUSED && pro.argmax != nullptr;
@@ -254,7 +257,7 @@ __global__ __launch_bounds__(RD_E *RD_S) void gemm_tn_reduce_kernel(const float 
 }
 
 struct TnPlan {
-    int wm, wn, tn, tk, tiles_n, tiles_k, splits;
+    int wm, wn, gn, tn, tk, tiles_n, tiles_k, splits;
     int64_t rows_per_split;
 };
 
@@ -268,8 +271,14 @@ static TnPlan plan_tn(int64_t M, int N, int K)
     else if (K <= 128) p.wn = 2;
     else if (K <= 192) p.wn = 3;
     else p.wn = ((K + 191) / 192) * 192 < ((K + 127) / 128) * 128 ? 3 : 2;
-    p.tn = 64 * p.wm;
-    p.tk = 64 * p.wn;
+    p.gn = 2;
+    if (N <= 32 && K >= 128) {  // a handful of output rows: one wave row, four wave columns (32 x 128 tiles)
+        p.gn = 1;
+        p.wm = 1;
+        p.wn = 1;
+    }
+    p.tn = 32 * p.gn * p.wm;
+    p.tk = 32 * (4 / p.gn) * p.wn;
     p.tiles_n = (N + p.tn - 1) / p.tn;
     p.tiles_k = (K + p.tk - 1) / p.tk;
     const int tiles = p.tiles_n * p.tiles_k;
@@ -306,7 +315,17 @@ static int launch_tn(const float *dY, const float *A, int64_t M, int N, int K, f
         else if (va) TP3D_TN_LAUNCH(WM_, WN_, false, true, false);                                                  \
         else TP3D_TN_LAUNCH(WM_, WN_, false, false, false);                                                         \
     } while (0)
-    if (p.wm == 2 && p.wn == 3) TP3D_TN_ALIGN(2, 3);
+    if (p.gn == 1) {
+        if (pro) return TP3D_E_BADARG;  // (the fused operands are not instantiated for the 1 x 4 wave grid)
+        if (vy && va) hipLaunchKernelGGL((gemm_tn_partial_kernel<1, 1, true, true, false, 1>), grid, dim3(TN_BLOCK), 0, s, dY, A, M, N,
+                                         K, p.rows_per_split, p.tiles_k, workspace, none);
+        else if (va) hipLaunchKernelGGL((gemm_tn_partial_kernel<1, 1, false, true, false, 1>), grid, dim3(TN_BLOCK), 0, s, dY, A, M,
+                                        N, K, p.rows_per_split, p.tiles_k, workspace, none);
+        else if (vy) hipLaunchKernelGGL((gemm_tn_partial_kernel<1, 1, true, false, false, 1>), grid, dim3(TN_BLOCK), 0, s, dY, A, M,
+                                        N, K, p.rows_per_split, p.tiles_k, workspace, none);
+        else hipLaunchKernelGGL((gemm_tn_partial_kernel<1, 1, false, false, false, 1>), grid, dim3(TN_BLOCK), 0, s, dY, A, M, N, K,
+                                p.rows_per_split, p.tiles_k, workspace, none);
+    } else if (p.wm == 2 && p.wn == 3) TP3D_TN_ALIGN(2, 3);
     else if (p.wn == 3) TP3D_TN_ALIGN(1, 3);
     else if (p.wm == 2 && p.wn == 2) TP3D_TN_ALIGN(2, 2);
     else if (p.wm == 2) TP3D_TN_ALIGN(2, 1);
