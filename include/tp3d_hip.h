@@ -225,7 +225,7 @@ int tp3d_gemm_rows_bnact_sp_f32(const float *Y, const float *mean, const float *
  * gradient (M/ns, K) of its max-pooled output and the winning rows (tp3d_bn_act_maxpool_f32; ns a power of two >= 64) --, c1 / c2 (K) from
  * tp3d_bn_bwd_reduce_f32, Bt (N,K) = W^T of the layer (N = its input width); dY_out (M,K), if not NULL, receives dY for
  * the weight-gradient contraction; ldc >= N is the row stride of C in floats (the gradient of a column range of wider
- * rows: the grouped rows' feature columns).  Shapes: K % 4 == 0, 4 <= K <= 256, any N, at least 512 output tiles
+ * rows: the grouped rows' feature columns).  Shapes: as tp3d_gemm_rows_bnact_sp_f32 with K <= 256
  * (tp3d_gemm_rows_bnbwd_sp_serves).  Autograd of Conv2d -> BatchNorm2d -> LeakyReLU
  * (core/common_modules/dense_modules.py:25-29). */
 int tp3d_gemm_rows_bnbwd_sp_serves(int64_t M, int N, int K);
