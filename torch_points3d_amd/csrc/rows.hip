@@ -619,54 +619,6 @@ __global__ __launch_bounds__(RW_BLOCK) void bn_act_maxpool_kernel(const float *_
     }
 }
 
-// The same for C % 4 == 0: four channels per thread, 16-byte loads (eight rows = 128 bytes per thread in flight); per
-// channel the same values compared in the same row order.
-__global__ __launch_bounds__(RW_BLOCK) void bn_act_maxpool4_kernel(const float *__restrict__ Y, const float *__restrict__ mean,
-                                                                    const float *__restrict__ scale,
-                                                                    const float *__restrict__ shift, float slope, int64_t G,
-                                                                    int ns, int C, float *__restrict__ out,
-                                                                    int *__restrict__ arg)
-{
-    const int C4 = C >> 2;
-    const int64_t total = G * C4;
-    for (int64_t e = (int64_t)blockIdx.x * RW_BLOCK + threadIdx.x; e < total; e += (int64_t)gridDim.x * RW_BLOCK) {
-        const int64_t g = e / C4;
-        const int c = (int)(e - g * C4) * 4;
-        const float4 mu = *reinterpret_cast<const float4 *>(mean + c), sc = *reinterpret_cast<const float4 *>(scale + c);
-        const float4 sh = *reinterpret_cast<const float4 *>(shift + c);
-        const float *y = Y + (size_t)g * ns * C + c;
-        float best[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-        int bs[4] = {0, 0, 0, 0};
-        auto take = [&](int v, float a, int row) {  // a NaN wins and stays; tested on the bit pattern (-fno-honor-nans)
-            const bool is_nan = (__float_as_uint(a) & 0x7fffffffu) > 0x7f800000u;
-            const bool have_nan = (__float_as_uint(best[v]) & 0x7fffffffu) > 0x7f800000u;
-            if (!have_nan && (is_nan || a > best[v])) {
-                best[v] = a;
-                bs[v] = row;
-            }
-        };
-        auto row4 = [&](const float4 q, int row) {
-            const float z0 = (q.x - mu.x) * sc.x + sh.x, z1 = (q.y - mu.y) * sc.y + sh.y;
-            const float z2 = (q.z - mu.z) * sc.z + sh.z, z3 = (q.w - mu.w) * sc.w + sh.w;
-            take(0, z0 > 0.0f ? z0 : z0 * slope, row);
-            take(1, z1 > 0.0f ? z1 : z1 * slope, row);
-            take(2, z2 > 0.0f ? z2 : z2 * slope, row);
-            take(3, z3 > 0.0f ? z3 : z3 * slope, row);
-        };
-        int s = 0;
-        for (; s + 8 <= ns; s += 8) {
-            float4 q[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) q[u] = *reinterpret_cast<const float4 *>(y + (size_t)(s + u) * C);
-#pragma unroll
-            for (int u = 0; u < 8; ++u) row4(q[u], s + u);
-        }
-        for (; s < ns; ++s) row4(*reinterpret_cast<const float4 *>(y + (size_t)s * C), s);
-        *reinterpret_cast<float4 *>(out + g * C + c) = make_float4(best[0], best[1], best[2], best[3]);
-        *reinterpret_cast<int4 *>(arg + g * C + c) = make_int4(bs[0], bs[1], bs[2], bs[3]);
-    }
-}
-
 // -------------------------------------------------------------------------------------------------
 // backward of  A = act(BN_train(Y)):  dZ = dA * act'(z);  dbeta = sum dZ;  dgamma = sum dZ * yhat
 //   pass 1: per-chunk partial sums of dZ and dZ*yhat (colreduce_partial_kernel<V, 1> above; pooled form below)
@@ -1194,14 +1146,8 @@ TP3D_EXPORT int tp3d_bn_act_maxpool_f32(const float *Y, const float *mean, const
     if (G < 0 || ns <= 0 || C <= 0) return TP3D_E_BADARG;
     if (G == 0) return TP3D_OK;
     if (!Y || !mean || !scale || !shift || !out || !argmax) return TP3D_E_BADARG;
-    const bool vec = (C & 3) == 0 && (((uintptr_t)Y | (uintptr_t)out | (uintptr_t)argmax | (uintptr_t)mean | (uintptr_t)scale |
-                                        (uintptr_t)shift) & 15) == 0;
-    if (vec)
-        hipLaunchKernelGGL(bn_act_maxpool4_kernel, dim3(grid_for(G * (C / 4))), dim3(RW_BLOCK), 0, (hipStream_t)stream, Y, mean,
-                           scale, shift, slope, G, ns, C, out, argmax);
-    else
-        hipLaunchKernelGGL(bn_act_maxpool_kernel, dim3(grid_for(G * C)), dim3(RW_BLOCK), 0, (hipStream_t)stream, Y, mean, scale,
-                           shift, slope, G, ns, C, out, argmax);
+    hipLaunchKernelGGL(bn_act_maxpool_kernel, dim3(grid_for(G * C)), dim3(RW_BLOCK), 0, (hipStream_t)stream, Y, mean, scale,
+                       shift, slope, G, ns, C, out, argmax);
     return check_launch();
 }
 
