@@ -168,8 +168,8 @@ def algorithmic_bytes(name, a):
     if name == "tp3d_gemm_rows_bnact_sp_f32":  # M, N, K (the side output of the training launches, M * K more, not counted)
         M, N, K = a[:3]
         return (M * (N + K) + N * K) * 4
-    if name == "tp3d_gemm_rows_bnbwd_sp_f32":  # M, N, K, ldc, ns: Y and dA (dense, or pooled + winning rows) in, dY and C out
-        M, N, K, _, ns = a[:5]
+    if name == "tp3d_gemm_rows_bnbwd_sp_f32":  # M, N, K, ldc, pad_lo, pad_hi, ns: Y and dA (dense, or pooled + winners) in, dY and C out
+        M, N, K, _, _, _, ns = a[:7]
         return (2 * M * K + (M // ns) * K * (1 if ns == 1 else 2) + M * N + N * K) * 4
     if name == "tp3d_gemm_rows_bnbwd_f32":  # ns, M, N, K: Y and dA (dense, or pooled M/ns rows + argmax) in, C out
         ns, M, N, K = a[:4]

@@ -223,15 +223,16 @@ int tp3d_gemm_rows_bnact_sp_f32(const float *Y, const float *mean, const float *
  * loader waves:  C[M,N] = dY[M,K] * Bt[N,K]^T,  dY = scale*((dA*act'(z) - c1) - (Y - mean)*c2),  z = (Y - mean)*scale + beta.
  * Y (M,K) pre-BatchNorm output of the layer, dA (M,K) gradient of its activated output -- or, with argmax != NULL, the
  * gradient (M/ns, K) of its max-pooled output and the winning rows (tp3d_bn_act_maxpool_f32; ns a power of two >= 64) --, c1 / c2 (K) from
- * tp3d_bn_bwd_reduce_f32, Bt (N,K) = W^T of the layer (N = its input width); dY_out (M,K), if not NULL, receives dY for
- * the weight-gradient contraction; ldc >= N is the row stride of C in floats (the gradient of a column range of wider
- * rows: the grouped rows' feature columns).  Shapes: as tp3d_gemm_rows_bnact_sp_f32 with K <= 256
+ * tp3d_bn_bwd_reduce_f32, Bt (N,K) = W^T of the layer (N = its input width).  dY_out (M,K), if not NULL, receives dY for the weight-gradient contraction; ldc >= N is the row stride of C in
+ * floats (the gradient of a column range of wider rows: the grouped rows' feature columns) and the pad_lo <= 32 columns
+ * in front of / pad_hi <= 32 behind that range are written as zeros.  Shapes: as tp3d_gemm_rows_bnact_sp_f32 with K <= 256
  * (tp3d_gemm_rows_bnbwd_sp_serves).  Autograd of Conv2d -> BatchNorm2d -> LeakyReLU
  * (core/common_modules/dense_modules.py:25-29). */
 int tp3d_gemm_rows_bnbwd_sp_serves(int64_t M, int N, int K);
 int tp3d_gemm_rows_bnbwd_sp_f32(const float *Y, const float *dA, const float *mean, const float *scale, const float *beta,
                                 const float *c1, const float *c2, float slope, const float *Bt, int64_t M, int N, int K,
-                                float *C, int ldc, float *dY_out, const int *argmax, int ns, void *stream);
+                                float *C, int ldc, int pad_lo, int pad_hi, float *dY_out, const int *argmax, int ns,
+                                void *stream);
 /* Input-gradient GEMM of a layer with its BatchNorm + activation BACKWARD applied to the A operand while it is staged:
  *   C[M,N] = dY[M,K] * Bt[N,K]^T,  dY = scale*(dZ - c1 - (Y - mean)*c2),  dZ = dA * act'((Y - mean)*scale + beta)
  * Y (M,K) pre-BatchNorm output of the layer, dA (M,K) gradient of its activated output -- or, with argmax != NULL, the

@@ -630,7 +630,7 @@ def test_split_role_input_gradient_gemm_forms_dy_in_its_loaders(M, N, K):
     out = torch.full((M, N), float("nan"), device=DEV)
     dY = torch.full((M, K), float("nan"), device=DEV)
     _lib.call("tp3d_gemm_rows_bnbwd_sp_f32", _lib.ptr(Y), _lib.ptr(dA), _lib.ptr(mean32), _lib.ptr(scale), _lib.ptr(beta), _lib.ptr(red[2]),
-              _lib.ptr(red[3]), 0.01, _lib.ptr(Wt), M, N, K, _lib.ptr(out), N, _lib.ptr(dY), None, 1, st)
+              _lib.ptr(red[3]), 0.01, _lib.ptr(Wt), M, N, K, _lib.ptr(out), N, 0, 0, _lib.ptr(dY), None, 1, st)
     torch.cuda.synchronize()
     yc = Y.double() - mean32.double()
     z = yc * scale.double() + beta.double()
@@ -646,13 +646,18 @@ def test_split_role_input_gradient_gemm_forms_dy_in_its_loaders(M, N, K):
     # without the side output: the same product
     out2 = torch.empty_like(out)
     _lib.call("tp3d_gemm_rows_bnbwd_sp_f32", _lib.ptr(Y), _lib.ptr(dA), _lib.ptr(mean32), _lib.ptr(scale), _lib.ptr(beta), _lib.ptr(red[2]),
-              _lib.ptr(red[3]), 0.01, _lib.ptr(Wt), M, N, K, _lib.ptr(out2), N, None, None, 1, st)
+              _lib.ptr(red[3]), 0.01, _lib.ptr(Wt), M, N, K, _lib.ptr(out2), N, 0, 0, None, None, 1, st)
     assert torch.equal(out2, out)
     # into a column range of wider rows (the feature columns of grouped rows): nothing outside it is touched
     wide = torch.full((M, N + 8), 7.0, device=DEV)
     _lib.call("tp3d_gemm_rows_bnbwd_sp_f32", _lib.ptr(Y), _lib.ptr(dA), _lib.ptr(mean32), _lib.ptr(scale), _lib.ptr(beta), _lib.ptr(red[2]),
-              _lib.ptr(red[3]), 0.01, _lib.ptr(Wt), M, N, K, wide.data_ptr() + 12, N + 8, None, None, 1, st)
+              _lib.ptr(red[3]), 0.01, _lib.ptr(Wt), M, N, K, wide.data_ptr() + 12, N + 8, 0, 0, None, None, 1, st)
     assert torch.equal(wide[:, 3:3 + N], out) and bool((wide[:, :3] == 7).all()) and bool((wide[:, 3 + N:] == 7).all())
+    # the three columns in front of the range and four of the five behind it written as zeros by the kernel
+    _lib.call("tp3d_gemm_rows_bnbwd_sp_f32", _lib.ptr(Y), _lib.ptr(dA), _lib.ptr(mean32), _lib.ptr(scale), _lib.ptr(beta), _lib.ptr(red[2]),
+              _lib.ptr(red[3]), 0.01, _lib.ptr(Wt), M, N, K, wide.data_ptr() + 12, N + 8, 3, 4, None, None, 1, st)
+    assert torch.equal(wide[:, 3:3 + N], out) and bool((wide[:, :3] == 0).all()) and bool((wide[:, 3 + N:3 + N + 4] == 0).all())
+    assert bool((wide[:, 3 + N + 4:] == 7).all())
     assert h.tp3d_gemm_rows_bnbwd_sp_serves(M, N, 260) == 0 and h.tp3d_gemm_rows_bnbwd_sp_serves(4096, N, K) == 0
 
 
@@ -715,7 +720,7 @@ def test_split_role_input_gradient_gemm_with_pooled_gradient(M, N, K, ns):
         out = torch.full((M, N), float("nan"), device=DEV)
         dY = torch.full((M, K), float("nan"), device=DEV)
         _lib.call("tp3d_gemm_rows_bnbwd_sp_f32", _lib.ptr(Y), _lib.ptr(dA), _lib.ptr(mean), _lib.ptr(scale), _lib.ptr(beta), _lib.ptr(c1),
-                  _lib.ptr(c2), 0.01, _lib.ptr(Wt), M, N, K, _lib.ptr(out), N, _lib.ptr(dY), a_ptr, n_, st)
+                  _lib.ptr(c2), 0.01, _lib.ptr(Wt), M, N, K, _lib.ptr(out), N, 0, 0, _lib.ptr(dY), a_ptr, n_, st)
         outs.append((out, dY))
     assert torch.equal(outs[0][1], outs[1][1])
     assert torch.equal(outs[0][0], outs[1][0])

@@ -42,7 +42,7 @@ SIGNATURES = {
     "tp3d_gemm_rows_f32": [_p, _p, _l, _i, _i, _p, _p, _p, _p],
     "tp3d_gemm_rows_bnact_f32": [_p, _p, _p, _p, _f, _p, _l, _i, _i, _p, _p, _p],
     "tp3d_gemm_rows_bnact_sp_f32": [_p, _p, _p, _p, _f, _p, _l, _i, _i, _p, _p, _p, _p],
-    "tp3d_gemm_rows_bnbwd_sp_f32": [_p, _p, _p, _p, _p, _p, _p, _f, _p, _l, _i, _i, _p, _i, _p, _p, _i, _p],
+    "tp3d_gemm_rows_bnbwd_sp_f32": [_p, _p, _p, _p, _p, _p, _p, _f, _p, _l, _i, _i, _p, _i, _i, _i, _p, _p, _i, _p],
     "tp3d_gemm_rows_bnbwd_f32": [_p, _p, _p, _i, _p, _p, _p, _p, _p, _f, _p, _l, _i, _i, _p, _p],
     "tp3d_bn_finalize_f32": [_p, _i, _l, _i, _f, _f, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p],
     "tp3d_kpconv_bwd_features_f32": [_p, _p, _p, _p, _p, _l, _l, _i, _i, _i, _f, _i, _i, _p, _p, ctypes.c_size_t, _i, _p,

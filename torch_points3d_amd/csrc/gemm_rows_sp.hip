@@ -40,6 +40,7 @@ struct SpPro {
     const float *dA, *c1, *c2;  // PRO 2, 3
     const int *arg;             // PRO 3: winning row (0 .. ns-1) of every (group, channel)
     int ns_shift;               //        ns = 1 << ns_shift rows per group
+    int pad_lo, pad_hi;         // PRO 2, 3: columns in front of / behind C's N columns in its rows, to be zeroed
 };
 
 template <int STATS, int PRO, int BN>
@@ -146,12 +147,12 @@ __global__ __launch_bounds__(SP_BLOCK, 4) void gemm_rows_sp_kernel(const float *
     do {                                                                                                              \
         bn0 = g_n0, bk0 = g_ks * SP_BK;                                                                               \
         const int kk = min(bk0 + fk4, K - 4);                                                                         \
-        b0 = *reinterpret_cast<const float4 *>(Bt + (size_t)min(g_n0 + frow + 0, N - 1) * K + kk);                    \
-        b1 = *reinterpret_cast<const float4 *>(Bt + (size_t)min(g_n0 + frow + 32, N - 1) * K + kk);                   \
-        if constexpr (BN == 128) {                                                                                    \
-            b2 = *reinterpret_cast<const float4 *>(Bt + (size_t)min(g_n0 + frow + 64, N - 1) * K + kk);               \
-            b3 = *reinterpret_cast<const float4 *>(Bt + (size_t)min(g_n0 + frow + 96, N - 1) * K + kk);               \
-        }                                                                                                             \
+            b0 = *reinterpret_cast<const float4 *>(Bt + (size_t)min(g_n0 + frow + 0, N - 1) * K + kk);                \
+            b1 = *reinterpret_cast<const float4 *>(Bt + (size_t)min(g_n0 + frow + 32, N - 1) * K + kk);               \
+            if constexpr (BN == 128) {                                                                                \
+                b2 = *reinterpret_cast<const float4 *>(Bt + (size_t)min(g_n0 + frow + 64, N - 1) * K + kk);           \
+                b3 = *reinterpret_cast<const float4 *>(Bt + (size_t)min(g_n0 + frow + 96, N - 1) * K + kk);           \
+            }                                                                                                         \
         if constexpr (POOL) { /* groups of >= 64 rows: tile rows r and r + 32 share their group */                    \
             const int64_t g0 = (min(g_m0 + frow + 0, M - 1) >> pro.ns_shift) * K + kk;                                \
             const int64_t g2 = (min(g_m0 + frow + 64, M - 1) >> pro.ns_shift) * K + kk;                               \
@@ -360,6 +361,10 @@ __global__ __launch_bounds__(SP_BLOCK, 4) void gemm_rows_sp_kernel(const float *
                     for (int e = 0; e < 16; ++e) {
                         const int64_t m = m0 + (wr * 2 + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
                         if (m < M && n < N) C[m * ldc + n] = acc[i][j][e];
+                        if (PRO >= 2 && j == 0 && wc == 0 && n0 == 0 && m < M) {  // the columns nobody computes stay defined
+                            if (l31 < pro.pad_lo) C[m * ldc - pro.pad_lo + l31] = 0.0f;
+                            if (l31 < pro.pad_hi) C[m * ldc + N + l31] = 0.0f;
+                        }
                     }
                 }
             if (STATS != 0) {
@@ -455,7 +460,7 @@ TP3D_EXPORT int tp3d_gemm_rows_bnact_sp_f32(const float *Y, const float *mean, c
     if (!tiles_n || !Y || !mean || !scale || !beta || !Bt || !C) return TP3D_E_BADARG;
     const int64_t items = sp_items(M, tiles_n);
     const int grid = sp_grid(items, act_out != nullptr);
-    SpPro pro{mean, scale, beta, slope, nullptr, nullptr, nullptr, nullptr, 0};
+    SpPro pro{mean, scale, beta, slope, nullptr, nullptr, nullptr, nullptr, 0, 0, 0};
     hipStream_t s = (hipStream_t)stream;
 #define TP3D_SP_LAUNCH(STATS, BN)                                                                                     \
     hipLaunchKernelGGL((gemm_rows_sp_kernel<STATS, 1, BN>), dim3(grid), dim3(SP_BLOCK), 0, s, Y, Bt, M, N, K, tiles_n, items, \
@@ -483,35 +488,37 @@ TP3D_EXPORT int tp3d_gemm_rows_bnbwd_sp_serves(int64_t M, int N, int K)
 
 TP3D_EXPORT int tp3d_gemm_rows_bnbwd_sp_f32(const float *Y, const float *dA, const float *mean, const float *scale,
                                             const float *beta, const float *c1, const float *c2, float slope,
-                                            const float *Bt, int64_t M, int N, int K, float *C, int ldc, float *dY_out,
-                                            const int *argmax, int ns, void *stream)
+                                            const float *Bt, int64_t M, int N, int K, float *C, int ldc, int pad_lo,
+                                            int pad_hi, float *dY_out, const int *argmax, int ns, void *stream)
 {
     using namespace tp3d;
     // (no statistics here, so any number of column tiles would work -- but every column tile re-reads BOTH operand
     // streams: with three tiles (N = 320) the library GEMM behind the apply pass is faster, 0.76 vs 0.55 ms on config 3)
     const int tiles_n = sp_tiles_n(M, N, K, SP_BWD_KMAX, true);
     if (!tiles_n || ldc < N || !Y || !dA || !mean || !scale || !beta || !c1 || !c2 || !Bt || !C) return TP3D_E_BADARG;
+    if (pad_lo < 0 || pad_hi < 0 || pad_lo > 32 || pad_hi > 32 || pad_lo + N + pad_hi > ldc)
+        return TP3D_E_BADARG;
     if (argmax && (ns < 64 || (ns & (ns - 1)) || M % ns)) return TP3D_E_BADARG;  // groups of 64, 128, ... rows
     int ns_shift = 0;
     while (argmax && (1 << ns_shift) < ns) ++ns_shift;
     const int64_t items = sp_items(M, tiles_n);
     const int grid = sp_grid(items, true);
-    SpPro pro{mean, scale, beta, slope, dA, c1, c2, argmax, ns_shift};
+    SpPro pro{mean, scale, beta, slope, dA, c1, c2, argmax, ns_shift, pad_lo, pad_hi};
     hipStream_t s = (hipStream_t)stream;
-#define TP3D_SP_BWD(PRO, BN)                                                                                          \
+#define TP3D_SP_BWD2(PRO, BN)                                                                                         \
     hipLaunchKernelGGL((gemm_rows_sp_kernel<0, PRO, BN>), dim3(grid), dim3(SP_BLOCK), 0, s, Y, Bt, M, N, K, tiles_n, items, C, \
                        (int64_t)ldc, (float *)nullptr, dY_out, pro)
     if (argmax) {
         if (N <= 64)
-            TP3D_SP_BWD(3, 64);
+            TP3D_SP_BWD2(3, 64);
         else
-            TP3D_SP_BWD(3, 128);
+            TP3D_SP_BWD2(3, 128);
     } else {
         if (N <= 64)
-            TP3D_SP_BWD(2, 64);
+            TP3D_SP_BWD2(2, 64);
         else
-            TP3D_SP_BWD(2, 128);
+            TP3D_SP_BWD2(2, 128);
     }
-#undef TP3D_SP_BWD
+#undef TP3D_SP_BWD2
     return check_launch();
 }
