@@ -113,3 +113,25 @@ def test_scatter_plan_carves_disjoint_ranges_large_enough():
         if flat:
             assert flat_ints <= B * L, (B, L, nbins)        # histogram + cursors live in `scratch`
             assert B * nbins + 1 <= B * (nbins + 1)          # flat start table inside `start`
+
+
+def test_split_role_gemm_shape_rules():
+    """tp3d_gemm_rows_sp_chunks / tp3d_gemm_rows_bnbwd_sp_serves (host arithmetic): which (M, N, K) the split-role GEMMs
+    take, and that the statistics chunk count is what the launch writes -- 2 wave rows x workgroups per column tile, with
+    every workgroup staying on one column tile (workgroups % (8 * column tiles) == 0)."""
+    h = _lib.load()
+    for M in ROWS:
+        for N, K in itertools.product(CHANNELS, CHANNELS):
+            row_blocks = (M + 127) // 128
+            tiles_n = 1 if N <= 64 else (N + 127) // 128
+            rem = N % 128
+            items = (row_blocks + 7) // 8 * 8 * tiles_n
+            fits = (K >= 4 and K % 4 == 0 and not (N > 64 and 0 < rem <= 64) and 512 % (8 * tiles_n) == 0 and items >= 512)
+            for side in (0, 1):
+                chunks = h.tp3d_gemm_rows_sp_chunks(M, N, K, side)
+                if not (fits and K <= 512):
+                    assert chunks == 0, (M, N, K, side, chunks)
+                    continue
+                grid = 1024 if (side and items >= 2048) else 512
+                assert chunks == 2 * grid // tiles_n and grid % (8 * tiles_n) == 0 and grid <= items, (M, N, K, side, chunks)
+            assert h.tp3d_gemm_rows_bnbwd_sp_serves(M, N, K) == int(fits and K <= 256), (M, N, K)
