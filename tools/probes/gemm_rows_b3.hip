@@ -1,0 +1,248 @@
+// EXPERIMENT (tools/probes/gemm_b3.py builds it into /tmp on the GPU box): the split-role rows GEMM of
+// csrc/gemm_rows_sp.hip with the fp32 contraction carried by the bf16 matrix pipe.
+//
+//   C[M,N] = A[M,K] * Bt[N,K]^T,  every fp32 operand value x written as hi + mid + lo with three bf16 terms
+//   (hi = bf16(x), mid = bf16(x - hi), lo = bf16(x - hi - mid): 24 mantissa bits), and the product as the six
+//   term pairs of weight >= 2^-16:  hh + hm + mh + mm + hl + lh, each one v_mfma_f32_32x32x16_bf16 with fp32
+//   accumulation (products of two bf16 values are exact in fp32).  tools/probes/bf16x3_accuracy.py: 2.4e-7 max error on
+//   a 128-deep contraction, against 4.9e-7 for an fp32 matmul.
+//
+// The loader waves do the split (VALU work beside the MFMA waves) and write three bf16 planes per operand tile; the MFMA
+// waves issue 48 MFMAs of 32 cycles per 32-deep K-step instead of 64 of 64 cycles.  One 8-wave workgroup per CU (the six
+// planes of two buffers take 120 KB of LDS).
+#include <hip/hip_runtime.h>
+
+#include "tp3d_common.h"
+
+namespace tp3d {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int B3_BLOCK = 512;
+constexpr int B3_BM = 128, B3_BN = 128, B3_BK = 32;
+constexpr int B3_PITCH = 40;                  // halfwords per tile row: 32 k + 8 pad = 80 bytes (16-byte aligned rows)
+constexpr int B3_PLANE = B3_BM * B3_PITCH;    // halfwords per plane
+constexpr int B3_LDS_BYTES = 2 /*buffers*/ * 2 /*operands*/ * 3 /*planes*/ * B3_PLANE * 2;
+
+__device__ __forceinline__ float4 b3_keep(bool c, float4 v)
+{
+    return make_float4(c ? v.x : 0.0f, c ? v.y : 0.0f, c ? v.z : 0.0f, c ? v.w : 0.0f);
+}
+
+__device__ __forceinline__ unsigned short b3_bits(__bf16 b) { return __builtin_bit_cast(unsigned short, b); }
+
+// x = hi + mid + lo (three bf16 terms); the four values of a float4 packed as four halfwords per plane
+__device__ __forceinline__ void b3_split(float4 v, uint2 &hi, uint2 &mid, uint2 &lo)
+{
+    const float x[4] = {v.x, v.y, v.z, v.w};
+    unsigned short h[4], m[4], l[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const __bf16 bh = (__bf16)x[c];
+        const float r1 = x[c] - (float)bh;
+        const __bf16 bm = (__bf16)r1;
+        const float r2 = r1 - (float)bm;
+        const __bf16 bl = (__bf16)r2;
+        h[c] = b3_bits(bh), m[c] = b3_bits(bm), l[c] = b3_bits(bl);
+    }
+    hi = make_uint2(h[0] | ((unsigned)h[1] << 16), h[2] | ((unsigned)h[3] << 16));
+    mid = make_uint2(m[0] | ((unsigned)m[1] << 16), m[2] | ((unsigned)m[3] << 16));
+    lo = make_uint2(l[0] | ((unsigned)l[1] << 16), l[2] | ((unsigned)l[3] << 16));
+}
+
+__global__ __launch_bounds__(B3_BLOCK) void gemm_rows_b3_kernel(const float *__restrict__ A, const float *__restrict__ Bt,
+                                                                int64_t M, int N, int K, int tiles_n, int64_t items,
+                                                                float *__restrict__ C, const float *__restrict__ mean,
+                                                                const float *__restrict__ scale, const float *__restrict__ beta,
+                                                                float slope)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned short smem[];
+    // optional prologue (mean != NULL): A = leaky((Y - mean) * scale + beta) per contraction channel, K <= 512, applied by
+    // the loader waves in front of the split
+    __shared__ __attribute__((aligned(16))) float sK[3 * 512];
+    const bool pro = mean != nullptr;
+    if (pro) {
+        for (int k = threadIdx.x; k < 512; k += B3_BLOCK) {
+            sK[k] = k < K ? mean[k] : 0.0f;
+            sK[512 + k] = k < K ? scale[k] : 0.0f;
+            sK[1024 + k] = k < K ? beta[k] : 0.0f;
+        }
+        __syncthreads();
+    }
+    // plane p of operand o (0 = A, 1 = B) in buffer u: smem + ((u * 2 + o) * 3 + p) * B3_PLANE
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ksteps = (K + B3_BK - 1) / B3_BK;
+    if ((int64_t)blockIdx.x >= items) return;
+    const int64_t my_items = (items - blockIdx.x + gridDim.x - 1) / gridDim.x;
+    const int64_t total = my_items * ksteps;
+
+    auto decode = [&](int64_t item, int64_t &m0, int &n0) {
+        const int64_t grp = item / (8 * tiles_n);
+        const int rem = (int)(item % (8 * tiles_n));
+        m0 = (grp * 8 + (rem & 7)) * B3_BM;
+        n0 = (rem >> 3) * B3_BN;
+    };
+
+    if (wave >= 4) {
+        // ------------------------------------------------------------------ loader waves
+        const int lt = tid - 256;
+        const int frow = lt >> 3, fk4 = (lt & 7) * 4;
+        int64_t f_item = blockIdx.x, f_m0;
+        int f_n0, f_ks = 0;
+        decode(f_item, f_m0, f_n0);
+        auto act4 = [&](const float4 raw, int kk) __attribute__((always_inline)) -> float4 {
+            if (!pro) return raw;
+            const int kc = min(kk, 512 - 4);
+            const float4 mu = *reinterpret_cast<const float4 *>(&sK[kc]);
+            const float4 sc = *reinterpret_cast<const float4 *>(&sK[512 + kc]);
+            const float4 be = *reinterpret_cast<const float4 *>(&sK[1024 + kc]);
+            const float z0 = (raw.x - mu.x) * sc.x + be.x, z1 = (raw.y - mu.y) * sc.y + be.y;
+            const float z2 = (raw.z - mu.z) * sc.z + be.z, z3 = (raw.w - mu.w) * sc.w + be.w;
+            return make_float4(z0 > 0.0f ? z0 : z0 * slope, z1 > 0.0f ? z1 : z1 * slope, z2 > 0.0f ? z2 : z2 * slope,
+                               z3 > 0.0f ? z3 : z3 * slope);
+        };
+#define B3_FETCH(S)                                                                                                   \
+    do {                                                                                                              \
+        m0_##S = f_m0, n0_##S = f_n0, k0_##S = f_ks * B3_BK;                                                          \
+        const int kk = min(k0_##S + fk4, K - 4);                                                                      \
+        a0_##S = *reinterpret_cast<const float4 *>(A + min(f_m0 + frow + 0, M - 1) * K + kk);                         \
+        a1_##S = *reinterpret_cast<const float4 *>(A + min(f_m0 + frow + 32, M - 1) * K + kk);                        \
+        a2_##S = *reinterpret_cast<const float4 *>(A + min(f_m0 + frow + 64, M - 1) * K + kk);                        \
+        a3_##S = *reinterpret_cast<const float4 *>(A + min(f_m0 + frow + 96, M - 1) * K + kk);                        \
+        b0_##S = *reinterpret_cast<const float4 *>(Bt + (size_t)min(f_n0 + frow + 0, N - 1) * K + kk);                \
+        b1_##S = *reinterpret_cast<const float4 *>(Bt + (size_t)min(f_n0 + frow + 32, N - 1) * K + kk);               \
+        b2_##S = *reinterpret_cast<const float4 *>(Bt + (size_t)min(f_n0 + frow + 64, N - 1) * K + kk);               \
+        b3_##S = *reinterpret_cast<const float4 *>(Bt + (size_t)min(f_n0 + frow + 96, N - 1) * K + kk);               \
+        if (++f_ks == ksteps) {                                                                                       \
+            f_ks = 0;                                                                                                 \
+            f_item += gridDim.x;                                                                                      \
+            decode(f_item, f_m0, f_n0);                                                                               \
+        }                                                                                                             \
+    } while (0)
+#define B3_PUT(BUF, O, I, V, IN)                                                                                      \
+    do {                                                                                                              \
+        uint2 hi, mid, lo;                                                                                            \
+        b3_split(b3_keep(IN, V), hi, mid, lo);                                                                        \
+        unsigned short *d = smem + ((BUF * 2 + O) * 3) * B3_PLANE + (frow + 32 * I) * B3_PITCH + fk4;                  \
+        *reinterpret_cast<uint2 *>(d) = hi;                                                                           \
+        *reinterpret_cast<uint2 *>(d + B3_PLANE) = mid;                                                               \
+        *reinterpret_cast<uint2 *>(d + 2 * B3_PLANE) = lo;                                                            \
+    } while (0)
+#define B3_STASH(S, BUF)                                                                                              \
+    do {                                                                                                              \
+        const bool kin = k0_##S + fk4 < K;                                                                            \
+        B3_PUT(BUF, 0, 0, act4(a0_##S, k0_##S + fk4), kin && m0_##S + frow + 0 < M);                                                      \
+        B3_PUT(BUF, 0, 1, act4(a1_##S, k0_##S + fk4), kin && m0_##S + frow + 32 < M);                                                     \
+        B3_PUT(BUF, 0, 2, act4(a2_##S, k0_##S + fk4), kin && m0_##S + frow + 64 < M);                                                     \
+        B3_PUT(BUF, 0, 3, act4(a3_##S, k0_##S + fk4), kin && m0_##S + frow + 96 < M);                                                     \
+        B3_PUT(BUF, 1, 0, b0_##S, kin && n0_##S + frow + 0 < N);                                                      \
+        B3_PUT(BUF, 1, 1, b1_##S, kin && n0_##S + frow + 32 < N);                                                     \
+        B3_PUT(BUF, 1, 2, b2_##S, kin && n0_##S + frow + 64 < N);                                                     \
+        B3_PUT(BUF, 1, 3, b3_##S, kin && n0_##S + frow + 96 < N);                                                     \
+    } while (0)
+        float4 a0_0, a1_0, a2_0, a3_0, b0_0, b1_0, b2_0, b3_0, a0_1, a1_1, a2_1, a3_1, b0_1, b1_1, b2_1, b3_1;
+        int64_t m0_0, m0_1;
+        int n0_0, n0_1, k0_0, k0_1;
+        B3_FETCH(0);
+        B3_FETCH(1);
+        B3_STASH(0, 0);
+        B3_FETCH(0);
+        __syncthreads();
+#pragma unroll 1
+        for (int64_t s = 0; s < total; s += 2) {
+            B3_STASH(1, 1);
+            B3_FETCH(1);
+            __syncthreads();
+            if (s + 1 >= total) break;
+            B3_STASH(0, 0);
+            B3_FETCH(0);
+            __syncthreads();
+        }
+#undef B3_FETCH
+#undef B3_PUT
+#undef B3_STASH
+        return;
+    }
+
+    // ---------------------------------------------------------------------- MFMA waves
+    const int wr = wave >> 1, wc = wave & 1;
+    const int l31 = lane & 31, lh = lane >> 5;
+    int64_t item = blockIdx.x, m0;
+    int n0, ks = 0;
+    decode(item, m0, n0);
+    f32x16 acc[2][2];
+    __syncthreads();
+    for (int64_t s = 0; s < total; ++s) {
+        const unsigned short *pa = smem + (((s & 1) * 2 + 0) * 3) * B3_PLANE;
+        const unsigned short *pb = smem + (((s & 1) * 2 + 1) * 3) * B3_PLANE;
+        if (ks == 0) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+        }
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {  // two 16-deep blocks per K-step: lane (r, h) holds k = 16 kb + 8 h + 0..7
+            bf16x8 a[2][3], b[2][3];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int p = 0; p < 3; ++p)
+                    a[i][p] = *reinterpret_cast<const bf16x8 *>(pa + p * B3_PLANE + ((wr * 2 + i) * 32 + l31) * B3_PITCH + kb * 16 + lh * 8);
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int p = 0; p < 3; ++p)
+                    b[j][p] = *reinterpret_cast<const bf16x8 *>(pb + p * B3_PLANE + ((wc * 2 + j) * 32 + l31) * B3_PITCH + kb * 16 + lh * 8);
+            // small terms first; four accumulators interleaved under every term pair
+#define B3_TERM(PA, PB)                                                                                               \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j)                       \
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][PA], b[j][PB], acc[i][j], 0, 0, 0)
+            B3_TERM(2, 0);
+            B3_TERM(0, 2);
+            B3_TERM(1, 1);
+            B3_TERM(1, 0);
+            B3_TERM(0, 1);
+            B3_TERM(0, 0);
+#undef B3_TERM
+        }
+        if (++ks == ksteps) {
+            ks = 0;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int n = n0 + (wc * 2 + j) * 32 + l31;
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int64_t m = m0 + (wr * 2 + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                        if (m < M && n < N) C[m * N + n] = acc[i][j][e];
+                    }
+                }
+            item += gridDim.x;
+            decode(item, m0, n0);
+        }
+        __syncthreads();
+    }
+}
+
+}  // namespace tp3d
+
+TP3D_EXPORT int tp3d_gemm_rows_b3_f32(const float *A, const float *Bt, int64_t M, int N, int K, float *C, int grid,
+                                      const float *mean, const float *scale, const float *beta, float slope, void *stream)
+{
+    using namespace tp3d;
+    if (M <= 0 || N <= 0 || K < 4 || (K & 3) || !A || !Bt || !C || grid <= 0 || (grid & 7) || (mean && K > 512))
+        return TP3D_E_BADARG;
+    const int tiles_n = (N + B3_BN - 1) / B3_BN;
+    const int64_t row_blocks = (M + B3_BM - 1) / B3_BM;
+    const int64_t items = (row_blocks + 7) / 8 * 8 * tiles_n;
+    static bool set[64] = {false};
+    allow_large_dynamic_lds(reinterpret_cast<const void *>(&gemm_rows_b3_kernel), B3_LDS_BYTES, set);
+    hipLaunchKernelGGL(gemm_rows_b3_kernel, dim3(grid), dim3(B3_BLOCK), B3_LDS_BYTES, (hipStream_t)stream, A, Bt, M, N, K, tiles_n,
+                       items, C, mean, scale, beta, slope);
+    return check_launch();
+}
