@@ -20,10 +20,11 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int B3_BLOCK = 512;
-constexpr int B3_BM = 128, B3_BN = 128, B3_BK = 32;
-constexpr int B3_PITCH = 40;                  // halfwords per tile row: 32 k + 8 pad = 80 bytes (16-byte aligned rows)
-constexpr int B3_PLANE = B3_BM * B3_PITCH;    // halfwords per plane
-constexpr int B3_LDS_BYTES = 2 /*buffers*/ * 2 /*operands*/ * 3 /*planes*/ * B3_PLANE * 2;
+constexpr int B3_BM = 128, B3_BN = 128;
+// B3_BK-deep K-steps (template): 32 -> 120 KB of planes, one workgroup per CU; 16 -> 72 KB, two workgroups per CU
+#define B3_PITCH (B3_BK + 8)                  /* halfwords per tile row: the k's + 8 pad (16-byte aligned rows) */
+#define B3_PLANE (B3_BM * B3_PITCH)           /* halfwords per plane */
+#define B3_LDS_BYTES (2 /*buffers*/ * 2 /*operands*/ * 3 /*planes*/ * B3_PLANE * 2)
 
 __device__ __forceinline__ float4 b3_keep(bool c, float4 v)
 {
@@ -51,6 +52,7 @@ __device__ __forceinline__ void b3_split(float4 v, uint2 &hi, uint2 &mid, uint2 
     lo = make_uint2(l[0] | ((unsigned)l[1] << 16), l[2] | ((unsigned)l[3] << 16));
 }
 
+template <int B3_BK>
 __global__ __launch_bounds__(B3_BLOCK) void gemm_rows_b3_kernel(const float *__restrict__ A, const float *__restrict__ Bt,
                                                                 int64_t M, int N, int K, int tiles_n, int64_t items,
                                                                 float *__restrict__ C, const float *__restrict__ mean,
@@ -87,7 +89,9 @@ __global__ __launch_bounds__(B3_BLOCK) void gemm_rows_b3_kernel(const float *__r
     if (wave >= 4) {
         // ------------------------------------------------------------------ loader waves
         const int lt = tid - 256;
-        const int frow = lt >> 3, fk4 = (lt & 7) * 4;
+        constexpr int TPR = B3_BK / 4, RPP = 256 / TPR;  // threads per tile row, rows per pass (32 or 64)
+        constexpr int NS = 128 / RPP;                    // float4 slots per thread and operand (4 or 2)
+        const int frow = lt / TPR, fk4 = (lt % TPR) * 4;
         int64_t f_item = blockIdx.x, f_m0;
         int f_n0, f_ks = 0;
         decode(f_item, f_m0, f_n0);
@@ -107,13 +111,15 @@ __global__ __launch_bounds__(B3_BLOCK) void gemm_rows_b3_kernel(const float *__r
         m0_##S = f_m0, n0_##S = f_n0, k0_##S = f_ks * B3_BK;                                                          \
         const int kk = min(k0_##S + fk4, K - 4);                                                                      \
         a0_##S = *reinterpret_cast<const float4 *>(A + min(f_m0 + frow + 0, M - 1) * K + kk);                         \
-        a1_##S = *reinterpret_cast<const float4 *>(A + min(f_m0 + frow + 32, M - 1) * K + kk);                        \
-        a2_##S = *reinterpret_cast<const float4 *>(A + min(f_m0 + frow + 64, M - 1) * K + kk);                        \
-        a3_##S = *reinterpret_cast<const float4 *>(A + min(f_m0 + frow + 96, M - 1) * K + kk);                        \
+        a1_##S = *reinterpret_cast<const float4 *>(A + min(f_m0 + frow + RPP, M - 1) * K + kk);                       \
         b0_##S = *reinterpret_cast<const float4 *>(Bt + (size_t)min(f_n0 + frow + 0, N - 1) * K + kk);                \
-        b1_##S = *reinterpret_cast<const float4 *>(Bt + (size_t)min(f_n0 + frow + 32, N - 1) * K + kk);               \
-        b2_##S = *reinterpret_cast<const float4 *>(Bt + (size_t)min(f_n0 + frow + 64, N - 1) * K + kk);               \
-        b3_##S = *reinterpret_cast<const float4 *>(Bt + (size_t)min(f_n0 + frow + 96, N - 1) * K + kk);               \
+        b1_##S = *reinterpret_cast<const float4 *>(Bt + (size_t)min(f_n0 + frow + RPP, N - 1) * K + kk);              \
+        if constexpr (NS == 4) {                                                                                      \
+            a2_##S = *reinterpret_cast<const float4 *>(A + min(f_m0 + frow + 2 * RPP, M - 1) * K + kk);               \
+            a3_##S = *reinterpret_cast<const float4 *>(A + min(f_m0 + frow + 3 * RPP, M - 1) * K + kk);               \
+            b2_##S = *reinterpret_cast<const float4 *>(Bt + (size_t)min(f_n0 + frow + 2 * RPP, N - 1) * K + kk);      \
+            b3_##S = *reinterpret_cast<const float4 *>(Bt + (size_t)min(f_n0 + frow + 3 * RPP, N - 1) * K + kk);      \
+        }                                                                                                             \
         if (++f_ks == ksteps) {                                                                                       \
             f_ks = 0;                                                                                                 \
             f_item += gridDim.x;                                                                                      \
@@ -124,7 +130,7 @@ __global__ __launch_bounds__(B3_BLOCK) void gemm_rows_b3_kernel(const float *__r
     do {                                                                                                              \
         uint2 hi, mid, lo;                                                                                            \
         b3_split(b3_keep(IN, V), hi, mid, lo);                                                                        \
-        unsigned short *d = smem + ((BUF * 2 + O) * 3) * B3_PLANE + (frow + 32 * I) * B3_PITCH + fk4;                  \
+        unsigned short *d = smem + ((BUF * 2 + O) * 3) * B3_PLANE + (frow + RPP * I) * B3_PITCH + fk4;                 \
         *reinterpret_cast<uint2 *>(d) = hi;                                                                           \
         *reinterpret_cast<uint2 *>(d + B3_PLANE) = mid;                                                               \
         *reinterpret_cast<uint2 *>(d + 2 * B3_PLANE) = lo;                                                            \
@@ -132,14 +138,16 @@ __global__ __launch_bounds__(B3_BLOCK) void gemm_rows_b3_kernel(const float *__r
 #define B3_STASH(S, BUF)                                                                                              \
     do {                                                                                                              \
         const bool kin = k0_##S + fk4 < K;                                                                            \
-        B3_PUT(BUF, 0, 0, act4(a0_##S, k0_##S + fk4), kin && m0_##S + frow + 0 < M);                                                      \
-        B3_PUT(BUF, 0, 1, act4(a1_##S, k0_##S + fk4), kin && m0_##S + frow + 32 < M);                                                     \
-        B3_PUT(BUF, 0, 2, act4(a2_##S, k0_##S + fk4), kin && m0_##S + frow + 64 < M);                                                     \
-        B3_PUT(BUF, 0, 3, act4(a3_##S, k0_##S + fk4), kin && m0_##S + frow + 96 < M);                                                     \
+        B3_PUT(BUF, 0, 0, act4(a0_##S, k0_##S + fk4), kin && m0_##S + frow + 0 < M);                                  \
+        B3_PUT(BUF, 0, 1, act4(a1_##S, k0_##S + fk4), kin && m0_##S + frow + RPP < M);                                \
         B3_PUT(BUF, 1, 0, b0_##S, kin && n0_##S + frow + 0 < N);                                                      \
-        B3_PUT(BUF, 1, 1, b1_##S, kin && n0_##S + frow + 32 < N);                                                     \
-        B3_PUT(BUF, 1, 2, b2_##S, kin && n0_##S + frow + 64 < N);                                                     \
-        B3_PUT(BUF, 1, 3, b3_##S, kin && n0_##S + frow + 96 < N);                                                     \
+        B3_PUT(BUF, 1, 1, b1_##S, kin && n0_##S + frow + RPP < N);                                                    \
+        if constexpr (NS == 4) {                                                                                      \
+            B3_PUT(BUF, 0, 2, act4(a2_##S, k0_##S + fk4), kin && m0_##S + frow + 2 * RPP < M);                        \
+            B3_PUT(BUF, 0, 3, act4(a3_##S, k0_##S + fk4), kin && m0_##S + frow + 3 * RPP < M);                        \
+            B3_PUT(BUF, 1, 2, b2_##S, kin && n0_##S + frow + 2 * RPP < N);                                            \
+            B3_PUT(BUF, 1, 3, b3_##S, kin && n0_##S + frow + 3 * RPP < N);                                            \
+        }                                                                                                             \
     } while (0)
         float4 a0_0, a1_0, a2_0, a3_0, b0_0, b1_0, b2_0, b3_0, a0_1, a1_1, a2_1, a3_1, b0_1, b1_1, b2_1, b3_1;
         int64_t m0_0, m0_1;
@@ -185,7 +193,7 @@ __global__ __launch_bounds__(B3_BLOCK) void gemm_rows_b3_kernel(const float *__r
                     for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
         }
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {  // two 16-deep blocks per K-step: lane (r, h) holds k = 16 kb + 8 h + 0..7
+        for (int kb = 0; kb < B3_BK / 16; ++kb) {  // 16-deep blocks of the K-step: lane (r, h) holds k = 16 kb + 8 h + 0..7
             bf16x8 a[2][3], b[2][3];
 #pragma unroll
             for (int i = 0; i < 2; ++i)
@@ -240,9 +248,17 @@ TP3D_EXPORT int tp3d_gemm_rows_b3_f32(const float *A, const float *Bt, int64_t M
     const int tiles_n = (N + B3_BN - 1) / B3_BN;
     const int64_t row_blocks = (M + B3_BM - 1) / B3_BM;
     const int64_t items = (row_blocks + 7) / 8 * 8 * tiles_n;
-    static bool set[64] = {false};
-    allow_large_dynamic_lds(reinterpret_cast<const void *>(&gemm_rows_b3_kernel), B3_LDS_BYTES, set);
-    hipLaunchKernelGGL(gemm_rows_b3_kernel, dim3(grid), dim3(B3_BLOCK), B3_LDS_BYTES, (hipStream_t)stream, A, Bt, M, N, K, tiles_n,
-                       items, C, mean, scale, beta, slope);
+    static bool set32[64] = {false}, set16[64] = {false};
+    if (grid <= 256) {  // one workgroup per CU: 32-deep K-steps
+        constexpr int B3_BK = 32;
+        allow_large_dynamic_lds(reinterpret_cast<const void *>(&gemm_rows_b3_kernel<32>), B3_LDS_BYTES, set32);
+        hipLaunchKernelGGL(gemm_rows_b3_kernel<32>, dim3(grid), dim3(B3_BLOCK), B3_LDS_BYTES, (hipStream_t)stream, A, Bt, M, N, K,
+                           tiles_n, items, C, mean, scale, beta, slope);
+    } else {  // two per CU: 16-deep K-steps
+        constexpr int B3_BK = 16;
+        allow_large_dynamic_lds(reinterpret_cast<const void *>(&gemm_rows_b3_kernel<16>), B3_LDS_BYTES, set16);
+        hipLaunchKernelGGL(gemm_rows_b3_kernel<16>, dim3(grid), dim3(B3_BLOCK), B3_LDS_BYTES, (hipStream_t)stream, A, Bt, M, N, K,
+                           tiles_n, items, C, mean, scale, beta, slope);
+    }
     return check_launch();
 }
