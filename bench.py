@@ -186,6 +186,35 @@ def algorithmic_bytes(name, a):
     if name == "tp3d_relation_rows_f32":  # B, N, np, ns, ld
         B, N, npnt, ns, ld = a[:5]
         return B * (N * 12 + npnt * 12 + npnt * ns * (8 + ld * 4))
+    # ---- partial-dense (KPConv / RandLA) entry points
+    if name == "tp3d_kpconv_weighted_f32":  # Nq, M, Mn, Cin, KP: neighbour ids + their rows once, weighted rows once
+        Nq, M, Mn, Cin, KP = a[:5]
+        return Nq * Mn * (8 + 4 * Cin) + Nq * KP * Cin * 4
+    if name == "tp3d_knn_partial_dense_f32":  # num_clouds, max_cloud_points, M, Nq, k
+        _, _, M, Nq, k = a[:5]
+        return M * 12 + Nq * 20 + Nq * k * 12
+    if name == "tp3d_knn_interpolate_fwd_f32":  # Nq, k, C, C2, ld
+        Nq, k, C, C2, ld = a[:5]
+        return Nq * (k * (12 + C * 4) + C2 * 4 + ld * 4)
+    if name == "tp3d_nbr_maxpool_fwd_f32":  # Nq, M, Mn, C
+        Nq, M, Mn, C = a[:4]
+        return Nq * Mn * 8 + M * C * 4 + Nq * C * 8
+    if name == "tp3d_voxel_cluster_f32":  # N: pos + batch in, cluster / order / start / last out
+        return a[0] * (12 + 8 + 4 * 8)
+    if name == "tp3d_voxel_bounds_f32":
+        return a[0] * 20
+    if name == "tp3d_cluster_mean_f32":  # K, C (rows read once through `order`; N unknown here: K clusters out)
+        K, C = a[:2]
+        return K * C * 8
+    if name in ("tp3d_gemm_skinny_f32", "tp3d_gemm_skinny_bnact_f32"):  # M, N, K, lda
+        M, N, K, lda = a[:4]
+        return M * (lda + N) * 4
+    if name == "tp3d_randla_relpos_f32":  # Nq, k, M
+        Nq, k, M = a[:3]
+        return Nq * 12 + Nq * k * (8 + 12 + 48)
+    if name == "tp3d_attn_pool_fwd_f32":  # Nq, k, C, ldg, ldf
+        Nq, k, C, ldg, ldf = a[:5]
+        return Nq * k * (ldg + ldf) * 4 + Nq * C * 4
     return 0
 
 
@@ -202,12 +231,116 @@ def algorithmic_flops(name, a):
     return 0
 
 
+def entry_sums(summ):
+    """{entry point: ms, launches, algorithmic bytes, flops} over all its launch shapes (KernelTimer.summary() in)."""
+    per_entry = {}
+    for (name, a), (launches, total_ms) in summ.items():
+        e = per_entry.setdefault(name, {"ms": 0.0, "launches": 0, "bytes": 0, "flops": 0})
+        e["ms"] += total_ms
+        e["launches"] += launches
+        e["bytes"] += launches * algorithmic_bytes(name, a)
+        e["flops"] += launches * algorithmic_flops(name, a)
+    return per_entry
+
+
+def entry_table(per_entry, steps):
+    return [{"entry": n, "ms_per_step": round(v["ms"] / steps, 4), "launches_per_step": v["launches"] / steps,
+             "GBps": round(v["bytes"] / 1e9 / (v["ms"] / 1e3), 1) if v["ms"] > 0 and v["bytes"] else None,
+             "TFLOPs": round(v["flops"] / 1e12 / (v["ms"] / 1e3), 2) if v["flops"] and v["ms"] > 0 else None}
+            for n, v in sorted(per_entry.items(), key=lambda kv: -kv[1]["ms"])]
+
+
+def load_traffic(entry):
+    """HBM bytes per launch of `entry` from the committed rocprofv3 --pmc passes (the profiler cannot run inside this
+    process); (bytes or None, short source tag).  profiles/traffic.json names the round and the command."""
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        tj = json.load(open(tpath))
+    except (OSError, ValueError):
+        return None, None
+    return tj.get(entry), tj.get("_tag", "profiles/traffic.json")
+
+
+def dominant_roofline(per_entry, steps):
+    """`roofline` block for the entry point with the largest share of device time (all its launch shapes together,
+    which is also how the rocprofv3 --stats summary groups them): a dense contraction is priced against the fp32 MFMA
+    peak, everything else against the HBM peak, from ALGORITHMIC flops / bytes and live HIP-event durations."""
+    if not per_entry:
+        return None
+    dom = max(per_entry, key=lambda n: per_entry[n]["ms"])
+    e = per_entry[dom]
+    traffic, source = load_traffic(dom)
+    sec = e["ms"] / 1e3
+    if e["flops"]:
+        achieved = e["flops"] / 1e12 / sec
+        roof = {"kernel": dom, "bound": "mfma", "achieved": round(achieved, 2), "peak": MFMA_F32_PEAK_TFLOPS,
+                "unit": "TFLOP/s", "frac": round(achieved / MFMA_F32_PEAK_TFLOPS, 4), "traffic": traffic,
+                "algorithmic_flops_per_launch": int(e["flops"] / e["launches"])}
+    else:
+        achieved = e["bytes"] / 1e9 / sec
+        roof = {"kernel": dom, "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic}
+    roof["algorithmic_bytes_per_launch"] = int(e["bytes"] / e["launches"])
+    roof.update({"avg_launch_ms": round(e["ms"] / e["launches"], 4), "launches": e["launches"],
+                 "ms_per_step": round(e["ms"] / steps, 4)})
+    if traffic is not None:
+        roof["traffic_source"] = source
+    return roof
+
+
 def log(msg):
     sys.stderr.write("[bench %.1fs] %s\n" % (time.perf_counter() - T_START, msg))
     sys.stderr.flush()
 
 
 T_START = time.perf_counter()
+
+HEADLINE_LIMIT = 4096  # bytes: the driver parses the LAST stdout line; a 28 KB line (round 2) did not reach it
+
+
+def _short(obj, limit=400):
+    """strings of the headline are capped so that no block can blow the line up again"""
+    if isinstance(obj, str):
+        return obj if len(obj) <= limit else obj[:limit - 3] + "..."
+    if isinstance(obj, dict):
+        return {k: _short(v, limit) for k, v in obj.items()}
+    if isinstance(obj, (list, tuple)):
+        return [_short(v, limit) for v in obj]
+    return obj
+
+
+def headline_json(line):
+    """The one stdout line: compact separators, strings capped, and a hard size check (tests/test_bench_line_cpu.py)."""
+    text = json.dumps(_short(line), separators=(",", ":"))
+    if len(text) >= HEADLINE_LIMIT:
+        # drop optional blocks, least important first, rather than print a line the driver cannot parse
+        slim = dict(line)
+        for key in ("north_star", "collective", "experiment_switches", "forward_only"):
+            if key in slim and len(text) >= HEADLINE_LIMIT:
+                slim.pop(key)
+                text = json.dumps(_short(slim, 200), separators=(",", ":"))
+    if len(text) >= HEADLINE_LIMIT:
+        raise RuntimeError("bench headline is %d bytes (limit %d)" % (len(text), HEADLINE_LIMIT))
+    json.loads(text)
+    return text
+
+
+def emit(line, detail, args):
+    """Heavy tables (per-shape kernels, per-entry sums, north-star rows with their counters) go to a side file; the
+    headline object is the LAST stdout line."""
+    path = getattr(args, "details_out", None) or os.path.join(ROOT, "gpurun_out", "bench_detail_%s.json" % args.workload)
+    if detail is not None:
+        try:
+            os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+            with open(path, "w") as f:
+                json.dump({"headline": line, **detail}, f, indent=1)
+            line = dict(line, details=os.path.relpath(path, ROOT))
+            log("details written to %s" % path)
+        except OSError as exc:
+            log("details not written (%s)" % exc)
+    sys.stdout.flush()
+    sys.stdout.write(headline_json(line) + "\n")
+    sys.stdout.flush()
 
 
 def cpu_share():
@@ -309,18 +442,23 @@ def cpu_forward_baseline(sample_b, iters):
             "seconds": cdt}
 
 
+def shape_key(entry, sizes):
+    """key of profiles/pmc_north_star.json: one counter row per (entry point, launch shape)"""
+    return "%s|%s" % (entry, ",".join(str(int(v)) for v in list(sizes)[:4]))
+
+
 def north_star_kernels(summ):
     """BASELINE.json's north-star kernels with their algorithmic-bytes rate against the HBM peak (SURVEY 8d formulas)
-    and, where a committed rocprofv3 --pmc pass holds them, VALU / occupancy counters (profiles/r02_pmc_spatial.json)."""
+    and, where a committed rocprofv3 --pmc pass holds that very (entry point, shape), its VALU / occupancy counters
+    (profiles/pmc_north_star.json, written by tools/pmc_north_star.py: one process per shape, so a row's counters belong
+    to its shape only)."""
     wanted = ("tp3d_fps_f32", "tp3d_ball_query_dense_f32", "tp3d_three_nn_f32", "tp3d_group_concat_fwd_f32",
               "tp3d_interp_concat_fwd_f32")
     pmc = {}
-    ppath = os.path.join(ROOT, "profiles", "r02_pmc_spatial.json")
-    if os.path.exists(ppath):
-        try:
-            pmc = json.load(open(ppath))
-        except (OSError, ValueError):
-            pmc = {}
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_north_star.json"))).get("rows", {})
+    except (OSError, ValueError):
+        pmc = {}
     out = []
     for (name, a), (launches, total_ms) in sorted(summ.items(), key=lambda kv: -kv[1][1]):
         if name not in wanted:
@@ -330,10 +468,20 @@ def north_star_kernels(summ):
         gbs = nbytes / 1e9 / (avg_ms / 1e3)
         row = {"entry": name, "sizes": list(a)[:5], "avg_ms": round(avg_ms, 4), "algorithmic_MB": round(nbytes / 1e6, 3),
                "GBps": round(gbs, 1), "frac_of_hbm_peak": round(gbs / HBM_PEAK_GBS, 5)}
-        if name in pmc.get("kernels", {}):
-            row["counters"] = pmc["kernels"][name]
-            row["counters_source"] = pmc.get("source")
+        if shape_key(name, a) in pmc:
+            row["counters"] = pmc[shape_key(name, a)]
         out.append(row)
+    return out
+
+
+def north_star_summary(rows):
+    """the headline's short form of north_star_kernels: the largest shape of each spatial kernel"""
+    short = {"tp3d_fps_f32": "fps", "tp3d_ball_query_dense_f32": "ball_query", "tp3d_three_nn_f32": "three_nn"}
+    out = {}
+    for r in rows:  # rows are sorted by total time: the first row of an entry point is its largest shape
+        k = short.get(r["entry"])
+        if k and k not in out:
+            out[k] = {"sizes": r["sizes"], "us": round(r["avg_ms"] * 1e3, 1), "hbm_frac": r["frac_of_hbm_peak"]}
     return out
 
 
@@ -361,28 +509,9 @@ def run_forward(args):
             model(pos, x)
         torch.cuda.synchronize()
         _lib.set_timer(None)
-    per_entry = {}
-    for (name, a), (launches, total_ms) in timer.summary().items():
-        e = per_entry.setdefault(name, {"ms": 0.0, "launches": 0, "bytes": 0, "flops": 0})
-        e["ms"] += total_ms
-        e["launches"] += launches
-        e["bytes"] += launches * algorithmic_bytes(name, a)
-        e["flops"] += launches * algorithmic_flops(name, a)
-    entries = [{"entry": n, "ms_per_step": round(v["ms"] / args.steps, 4), "launches_per_step": v["launches"] // args.steps,
-                "GBps": round(v["bytes"] / 1e9 / (v["ms"] / 1e3), 1) if v["ms"] > 0 else None,
-                "TFLOPs": round(v["flops"] / 1e12 / (v["ms"] / 1e3), 2) if v["flops"] else None}
-               for n, v in sorted(per_entry.items(), key=lambda kv: -kv[1]["ms"])]
-    dom = max(per_entry, key=lambda n: per_entry[n]["ms"])
-    e = per_entry[dom]
-    if e["flops"]:  # a dense contraction: priced against the fp32 MFMA peak
-        achieved = e["flops"] / 1e12 / (e["ms"] / 1e3)
-        roofline = {"kernel": dom, "bound": "mfma", "achieved": round(achieved, 2), "peak": MFMA_F32_PEAK_TFLOPS,
-                    "unit": "TFLOP/s", "frac": round(achieved / MFMA_F32_PEAK_TFLOPS, 4), "traffic": None}
-    else:
-        achieved = e["bytes"] / 1e9 / (e["ms"] / 1e3)
-        roofline = {"kernel": dom, "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None}
-    roofline.update({"avg_launch_ms": round(e["ms"] / e["launches"], 4), "launches": e["launches"]})
+    per_entry = entry_sums(timer.summary())
+    entries = entry_table(per_entry, args.steps)
+    roofline = dominant_roofline(per_entry, args.steps)
     cpu = None
     if not args.no_cpu_baseline:
         from oracle import tpk_ref
@@ -411,10 +540,10 @@ def run_forward(args):
             "config": {"workload": "PointNet++ SSG (%s) forward, train-mode BatchNorm, B=32, N=16384, FEAT=3, 10 classes, "
                                    "pos~U[-1,1]^3 (BASELINE configs[1])" % MODEL_CONFIG,
                        "launch": "hip-graph replay" if graphed else "eager"},
-            "roofline": roofline, "cpu_baseline": cpu, "entry_points": entries}
+            "roofline": roofline, "cpu_baseline": cpu}
     if cpu:
         line["gpu_over_cpu"] = round(value / cpu["value"], 1)
-    print(json.dumps(line))
+    emit(line, {"entry_points": entries, "north_star_kernels": north_star_kernels(timer.summary())}, args)
 
 
 def run_kpconv(args):
@@ -457,21 +586,8 @@ def run_kpconv(args):
         step()
     torch.cuda.synchronize()
     _lib.set_timer(None)
-    per = {}
-    for (name, a), (cnt, tot) in timer.summary().items():
-        c, t = per.get(name, (0, 0.0))
-        per[name] = (c + cnt, t + tot)
-    dom, (dcnt, dtot) = max(per.items(), key=lambda kv: kv[1][1])
-    # algorithmic bytes of the dominant entry point (stage 1 of the convolution: neighbour ids + rows once, wf once),
-    # summed over its launches of one forward pass from the recorded sizes
-    alg = 0.0
-    for (name, a), (cnt, tot) in timer.summary().items():
-        if name == dom and name == "tp3d_kpconv_weighted_f32":
-            Nq, M, Mn, Cin, KP = a[0], a[1], a[2], a[3], a[4]
-            alg += cnt * (Nq * Mn * (8 + 4 * Cin) + Nq * KP * Cin * 4.0)
-    roof = {"kernel": dom, "bound": "hbm", "achieved": round(alg / 1e9 / (dtot / 1e3), 2) if alg else None, "peak": 8000.0,
-            "unit": "GB/s", "frac": round(alg / 1e9 / (dtot / 1e3) / 8000.0, 5) if alg else None, "traffic": None,
-            "launches": dcnt, "ms_per_step": round(dtot / args.steps, 4)}
+    per_entry = entry_sums(timer.summary())
+    roof = dominant_roofline(per_entry, args.steps)
     base = None
     if not args.no_cpu_baseline:
         from oracle import tpk_ref
@@ -491,16 +607,15 @@ def run_kpconv(args):
                 "sample": "1 forward of the same model on the same cloud: reference block logic mirrored on the CPU with "
                           "oracle/tpk_ref_cpu.c radius search + kNN, oracle/voxel_ref.py grid sampling, PyTorch-CPU "
                           "KPConv_ops / Linear / BatchNorm", "seconds": sec, "max_rel_diff_vs_gpu": err}
-    print(json.dumps({
+    emit({
         "metric": "points/sec KPConv unet_4 forward N=65536", "value": round(n * args.steps / dt, 1), "unit": "points/s",
         "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "KPConv rigid segmentation forward (applications/kpconv.py unet_4, in_feat 64, grid 0.02, 25 "
                                "neighbours, 13 classes), one cloud of 65536 points (BASELINE configs[3]); sampling and "
                                "searches inside the timed region", "launch": "eager"},
-        "roofline": roof, "cpu_baseline": base,
-        "entry_points": [{"entry": k, "launches_per_step": v[0] / args.steps, "ms_per_step": round(v[1] / args.steps, 4)}
-                         for k, v in sorted(per.items(), key=lambda kv: -kv[1][1])]}))
+        "roofline": roof, "cpu_baseline": base},
+        {"entry_points": entry_table(per_entry, args.steps)}, args)
 
 
 def run_knn(args):
@@ -565,14 +680,14 @@ def run_knn(args):
         base = {"value": sel.numel() / sec, "unit": "queries/s", "cores": threads, "kind": "port",
                 "sample": "%d of the %d queries, brute force over the 10^6 points (oracle/tpk_ref_cpu.c, OpenMP over "
                           "queries)" % (sel.numel(), nq), "seconds": sec, "gpu_result_identical_on_sample": same}
-    print(json.dumps({
+    emit({
         "metric": "queries/sec random-subsample + exact 16-NN, N=10^6", "value": round(nq * args.steps / dt, 1),
         "unit": "queries/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": "RandLA-Net sampling + neighbour search leg (BASELINE configs[4]): one room-shaped scene of "
                                "10^6 surface points, 250000 queries drawn with replacement, k = 16", "launch": "eager"},
-        "roofline": roof, "cpu_baseline": base}))
+        "roofline": roof, "cpu_baseline": base}, {}, args)
 
 
 def main():
@@ -614,6 +729,9 @@ def main():
                     help="cross entropy on the (B, classes, N) scores (default; PyTorch's spatial soft-max kernels) or on "
                          "their (B*N, classes) view (no transposing copies, but PyTorch's row soft-max is 0.7 ms slower on "
                          "10-wide rows -- measured, kept as a switch)")
+    ap.add_argument("--details-out", default=None, metavar="PATH",
+                    help="side file for the heavy tables (per-shape kernels, per-entry sums, north-star rows); default "
+                         "gpurun_out/bench_detail_<workload>.json.  The headline stays the last stdout line, < 4 KB")
     ap.add_argument("--set", action="append", default=[], metavar="NAME=VALUE",
                     help="experiment switch: set an attribute of torch_points3d_amd.fused (e.g. USE_MLP_CHAIN=0) before the "
                          "run; recorded in the JSON line")
@@ -758,52 +876,9 @@ def main():
                 "ms_per_step": round(total_ms / args.steps, 4), "algorithmic_MB": round(nbytes / 1e6, 3),
                 "GBps": round(nbytes / 1e9 / (avg_ms / 1e3), 2) if avg_ms > 0 else None,
             })
-        # dominant HIP kernel = the entry point with the largest share of device time over the timed region
-        # (all its launch shapes together, which is also how the rocprofv3 --stats summary groups them)
-        per_entry = {}
-        for (name, a), (launches, total_ms) in summ.items():
-            e = per_entry.setdefault(name, {"ms": 0.0, "launches": 0, "bytes": 0, "flops": 0})
-            e["ms"] += total_ms
-            e["launches"] += launches
-            e["bytes"] += launches * algorithmic_bytes(name, a)
-            e["flops"] += launches * algorithmic_flops(name, a)
-        roofline = None
-        if per_entry:
-            dom = max(per_entry, key=lambda n: per_entry[n]["ms"])
-            e = per_entry[dom]
-            avg_ms = e["ms"] / e["launches"]
-            # HBM bytes per launch of the dominant kernel come from separate rocprofv3 --pmc passes (the profiler cannot
-            # run inside this process): the committed summary names the round and command it was taken with
-            traffic, traffic_source = None, None
-            tpath = os.path.join(ROOT, "profiles", "traffic.json")
-            if os.path.exists(tpath):
-                try:
-                    tj = json.load(open(tpath))
-                    traffic = tj.get(dom)
-                    traffic_source = tj.get("_source", "profiles/traffic.json (earlier rocprofv3 --pmc FETCH_SIZE / "
-                                                       "WRITE_SIZE passes, not this run)")
-                except (OSError, ValueError):
-                    traffic = None
-            if e["flops"]:  # a dense contraction: priced against the fp32 MFMA peak
-                achieved = e["flops"] / 1e12 / (e["ms"] / 1e3)
-                roofline = {"kernel": dom, "bound": "mfma", "achieved": round(achieved, 2),
-                            "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                            "frac": round(achieved / MFMA_F32_PEAK_TFLOPS, 4), "traffic": traffic,
-                            "algorithmic_flops_per_launch": int(e["flops"] / e["launches"])}
-            else:
-                achieved = e["bytes"] / 1e9 / (e["ms"] / 1e3)
-                roofline = {"kernel": dom, "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-                            "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                            "algorithmic_bytes_per_launch": int(e["bytes"] / e["launches"])}
-            roofline.update({"avg_launch_ms": round(avg_ms, 4), "launches": e["launches"],
-                             "ms_per_step": round(e["ms"] / args.steps, 4)})
-            if traffic is not None:
-                roofline["traffic_source"] = traffic_source
-        entries = [{"entry": n, "ms_per_step": round(v["ms"] / args.steps, 4), "launches_per_step":
-                    v["launches"] // args.steps,
-                    "GBps": round(v["bytes"] / 1e9 / (v["ms"] / 1e3), 1) if v["ms"] > 0 else None,
-                    "TFLOPs": round(v["flops"] / 1e12 / (v["ms"] / 1e3), 2) if v["flops"] else None}
-                   for n, v in sorted(per_entry.items(), key=lambda kv: -kv[1]["ms"])]
+        per_entry = entry_sums(summ)
+        roofline = dominant_roofline(per_entry, args.steps)
+        entries = entry_table(per_entry, args.steps)
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline(args.cpu_sample_clouds, args.cpu_sample_iters)
@@ -818,9 +893,9 @@ def main():
                 fcpu = cpu_forward_baseline(args.cpu_sample_clouds, max(args.cpu_sample_iters // 2, 2))
                 forward_only["cpu_baseline"] = fcpu
                 forward_only["gpu_over_cpu"] = round(forward_only["value"] / fcpu["value"], 1)
-        ns_summ = summ  # the per-kernel pass runs on one stream: the spatial kernels are timed on their own
         value = world * b_rank * args.steps / dt
         grouping = "MSG" if (MODEL_CONFIG.endswith("_ms") or args.workload == "msg_c3") else "SSG"
+        ns_rows = north_star_kernels(summ)  # the per-kernel pass runs on one stream: spatial kernels timed on their own
         line = {
             "metric": "point-clouds/sec fwd+bwd PointNet++%s B=32 N=%d" % (grouping, N_POINTS),
             "value": round(value, 2),
@@ -834,30 +909,26 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": "PointNet++ %s (%s) train step fwd+bwd+Adam, B=%d per GPU, N=%d, "
-                                   "FEAT=3, %d classes, pos~U[-1,1]^3 (BASELINE configs[%d])"
+            "config": {"workload": "PointNet++ %s (%s) train step fwd+bwd+Adam, B=%d per GPU, N=%d, FEAT=3, %d classes, "
+                                   "pos~U[-1,1]^3 (BASELINE configs[%d])"
                                    % (grouping, MODEL_CONFIG, b_rank, N_POINTS, NUM_CLASSES, 2 if grouping == "MSG" else 1),
                        "launch": ("hip-graph replay" if graphed else "eager") + (
-                           "" if args.no_geometry_prefetch else
-                           "; sampling + searches of step i+1 on a second stream during step i (every step does both)"),
+                           "" if args.no_geometry_prefetch else "; geometry of step i+1 on a 2nd stream during step i"),
                        "global_batch": world * b_rank, "points": N_POINTS,
-                       "parallelism": "dp%d (whole clouds per rank, one flat gradient all-reduce over RCCL "
-                                      "per step)" % world},
+                       "parallelism": "dp%d, whole clouds per rank, one flat gradient all-reduce (RCCL) per step" % world},
             "roofline": roofline,
             "cpu_baseline": cpu,
             "forward_only": forward_only,
-            "north_star_kernels": north_star_kernels(ns_summ),
-            "entry_points": entries,
-            "kernels": kernels,
+            "north_star": north_star_summary(ns_rows),
         }
         if multi:
-            line["collective"] = {"what": "one flat fp32 gradient all-reduce (sum) + divide per step over RCCL",
+            line["collective"] = {"what": "flat fp32 gradient all-reduce + divide per step (RCCL)",
                                   "bytes": int(trainer.flat.numel() * 4), "ms_per_step": coll_ms}
         if args.set:
             line["experiment_switches"] = args.set
         if cpu:
             line["gpu_over_cpu"] = round(value / cpu["value"], 1)
-        print(json.dumps(line))
+        emit(line, {"north_star_kernels": ns_rows, "entry_points": entries, "kernels": kernels}, args)
     if multi:
         dist.barrier()
         dist.destroy_process_group()

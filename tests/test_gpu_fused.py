@@ -832,3 +832,72 @@ def test_bf16_terms_gemm_is_as_accurate_as_the_fp32_mfma_form(M, N, K):
     assert float(((s_b3[0].double() - ref.mean(0)).abs() / std).max()) < 1e-5
     torch.testing.assert_close(s_b3[1], s_sp[1], rtol=2e-5, atol=0)
     assert h.tp3d_gemm_rows_b3_chunks(M, 64, K, 1) == 0 and h.tp3d_gemm_rows_b3_chunks(4096, N, K, 1) == 0
+
+
+def test_eval_statistics_follow_a_replayed_training_graph():
+    """eval-mode BatchNorm statistics are cached per module; a HIP-graph replay of the training step runs no
+    Python and moves no version counter, so the cache must be invalidated by the stepper -- validate, replay, validate."""
+    from torch_points3d_amd.dense import Data
+    from torch_points3d_amd.dp import ShardedStep
+    from torch_points3d_amd.pointnet2 import PointNet2Unet
+    torch.manual_seed(3)
+    net = PointNet2Unet(3, output_nc=6, config="unet_3_ss").to(DEV).train()
+    g = torch.Generator().manual_seed(5)
+    pos = (torch.rand(2, 1024, 3, generator=g) * 2 - 1).to(DEV)
+    x = torch.randn(2, 1024, 3, generator=g).to(DEV)
+    y = torch.randint(0, 6, (2, 1024), generator=g).to(DEV)
+    stepper = ShardedStep(net, lambda ps: torch.optim.Adam(ps, lr=1e-2, capturable=True),
+                          lambda: F.cross_entropy(net(Data(pos=pos, x=x)).x, y), world_size=1, use_graph=True)
+    graphed = stepper.warmup_and_capture(2)
+
+    def validate():
+        net.eval()
+        with torch.no_grad():
+            out = net(Data(pos=pos, x=x)).x.clone()
+        net.train()
+        return out
+
+    def validate_uncached():
+        for m in net.modules():
+            if hasattr(m, "_tp3d_eval_stats"):
+                del m._tp3d_eval_stats
+        return validate()
+
+    first = validate()
+    for _ in range(3):
+        stepper.step()
+    torch.cuda.synchronize()
+    second = validate()
+    fresh = validate_uncached()
+    assert graphed, "the test is about graph replay"
+    assert torch.equal(second, fresh), "validation after replayed training used stale BatchNorm statistics"
+    assert not torch.equal(first, second)  # three Adam steps at lr 1e-2 move the scores
+
+
+def test_no_grad_forward_keeps_no_side_outputs():
+    """under torch.no_grad() the parameters still report requires_grad inside Function.forward; the chain
+    must not allocate / write the activated side outputs then, and must give the same scores as the grad-mode pass."""
+    from torch_points3d_amd import _lib, fused
+    from torch_points3d_amd.dense import Data
+    from torch_points3d_amd.pointnet2 import PointNet2Unet
+    torch.manual_seed(4)
+    net = PointNet2Unet(3, output_nc=6, config="unet_3_ss").to(DEV).train()
+    g = torch.Generator().manual_seed(6)
+    pos = (torch.rand(4, 4096, 3, generator=g) * 2 - 1).to(DEV)
+    x = torch.randn(4, 4096, 3, generator=g).to(DEV)
+    seen = []
+    prev = _lib.set_post_call_hook(lambda name, args: seen.append((name, args)))
+    try:
+        with torch.no_grad():
+            a = net(Data(pos=pos, x=x)).x
+        # argument 12 of the split-role forward GEMM is the side output (include/tp3d_hip.h)
+        sp = [args for name, args in seen if name == "tp3d_gemm_rows_bnact_sp_f32"]
+        assert sp and all(args[11] is None for args in sp)
+        del seen[:]
+        b = net(Data(pos=pos, x=x)).x
+        sp = [args for name, args in seen if name == "tp3d_gemm_rows_bnact_sp_f32"]
+        assert sp and all(args[11] is not None for args in sp)
+    finally:
+        _lib.set_post_call_hook(prev)
+    assert fused._outer_grad is True
+    torch.testing.assert_close(a, b.detach(), rtol=1e-5, atol=1e-5)

@@ -145,3 +145,23 @@ def test_library_has_no_gpu_or_openmp_dependency():
 def test_gpu_tensors_are_refused():
     with pytest.raises(RuntimeError):
         points_cpu.ball_query(torch.zeros(2, 3, device="meta"), torch.zeros(1, 3), radius=1.0, max_num=1)
+
+
+@pytest.mark.parametrize("bad", [float("nan"), float("inf"), -float("inf")])
+def test_non_finite_coordinates_raise_instead_of_hanging(bad):
+    """one NaN / Inf point made the grid's cell-coarsening loop spin forever inside a DataLoader worker."""
+    import ctypes
+    from torch_points_kernels import points_cpu
+    pts = torch.rand(100, 3)
+    pts[17, 1] = bad
+    q = torch.rand(5, 3)
+    with pytest.raises(ValueError):
+        points_cpu.ball_query(pts, q, radius=0.2, max_num=8)
+    with pytest.raises(ValueError):
+        points_cpu.dense_knn(pts.unsqueeze(0), q.unsqueeze(0), 3)
+    # the C entry point itself refuses (NULL), whatever the caller checked
+    h = points_cpu._lib()
+    assert not h.tp3d_cpu_grid_build(pts.data_ptr(), pts.shape[0], ctypes.c_float(0.2))
+    # finite ends whose extent overflows float
+    far = torch.tensor([[3e38, 0.0, 0.0], [-3e38, 0.0, 0.0]])
+    assert not h.tp3d_cpu_grid_build(far.data_ptr(), 2, ctypes.c_float(0.2))

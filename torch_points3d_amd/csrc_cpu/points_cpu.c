@@ -56,9 +56,24 @@ void *tp3d_cpu_grid_build(const float *points, int64_t n, float cell)
                 if (v > hi[a]) hi[a] = v;
             }
     }
+    /* a NaN / Inf coordinate has no cell (and would keep the coarsening loop below from ever ending): refuse */
+    for (int64_t i = 0; i < 3 * n; ++i)
+        if (!isfinite(points[i])) {
+            free(g);
+            return NULL;
+        }
+    for (int a = 0; a < 3; ++a)
+        if (!isfinite(hi[a] - g->lo[a])) { /* finite ends whose difference overflows */
+            free(g);
+            return NULL;
+        }
     /* at most ~4 cells per point and 512 per axis: coarsen the cells of a sparse / huge box */
     float c = cell;
-    for (;;) {
+    for (int round = 0;; ++round) {
+        if (round > 512 || !isfinite(c)) { /* 1.5^512 overflows float long before: cannot happen with finite bounds */
+            free(g);
+            return NULL;
+        }
         double total = 1.0;
         int ok = 1;
         for (int a = 0; a < 3; ++a) {

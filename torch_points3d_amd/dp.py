@@ -144,6 +144,8 @@ class ShardedStep(object):
 
     def step(self):
         if self.graphed:
+            if self._fused is not None:
+                self._fused.note_graph_replay()  # eval-mode BatchNorm caches must not outlive a replayed update
             self.graph_fb.replay()
             self._reduce()
             self.graph_opt.replay()
@@ -221,7 +223,10 @@ class PipelinedStep(ShardedStep):
             torch.cuda.synchronize()
             for slot in (0, 1):  # geometry graphs first: their outputs are the training graphs' static inputs
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                # captured ON the stream they are replayed on: scratch buffers are keyed by (device, stream, purpose)
+                # (_lib.workspace), so the geometry graphs and the training graphs, which run concurrently, can never
+                # bake in the same buffer -- whatever tags either side uses
+                with torch.cuda.graph(g, stream=self._side, capture_error_mode="thread_local"):
                     self._slots[slot] = self._geometry_fn(slot)
                 self.graph_geo[slot] = g
             for slot in (0, 1):
@@ -254,6 +259,8 @@ class PipelinedStep(ShardedStep):
         if not self.graphed:
             return self._eager_step()
         cur, nxt = self._cur, self._cur ^ 1
+        if self._fused is not None:
+            self._fused.note_graph_replay()
         main = torch.cuda.current_stream()
         # geometry of the next batch: may start as soon as the training pass that last read slot `nxt` is done
         if self._slot_free[nxt] is not None:

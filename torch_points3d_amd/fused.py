@@ -140,6 +140,31 @@ def _note_training_pass(bn):
     bn._tp3d_train_passes = getattr(bn, "_tp3d_train_passes", 0) + 1
 
 
+_replay_epoch = 0
+_outer_grad = True  # grad mode at the call site of the autograd Functions below (inside Function.forward it is always off)
+
+
+def _apply(fn, *args):
+    """fn.apply(*args) with the caller's grad mode recorded: under torch.no_grad() the parameters still report
+    requires_grad through ctx.needs_input_grad, and the forward passes would keep side outputs for a backward that
+    cannot come"""
+    global _outer_grad
+    _outer_grad = torch.is_grad_enabled()
+    try:
+        return fn.apply(*args)
+    finally:
+        _outer_grad = True
+
+
+def note_graph_replay():
+    """A captured training step was replayed: parameters and running statistics of every module may have changed
+    without any Python running (no version counter moves, _note_training_pass does not fire, and with flattened
+    parameters the optimizer only touches the flat tensor).  dp.ShardedStep / PipelinedStep call this on every replay;
+    the count is part of the eval-statistics cache key, so a validation pass after replayed training recomputes them."""
+    global _replay_epoch
+    _replay_epoch += 1
+
+
 ROWS_GEMM_MIN_COLS = 32   # narrower outputs (class scores, edge MLPs) stay on the library / skinny kernels
 ROWS_GEMM_NARROW = True   # widths served by the 128 x 64 tiles (N % 128 in 1..64) on the rows kernel (else library GEMM)
 ROWS_GEMM_DX = False      # input-gradient contractions on the rows kernel; measured 0.22 ms/step slower than the
@@ -188,7 +213,7 @@ def _bn_stats(Y, M, C, gamma, beta, bn, training, dev, st, bias=None):
     key = None
     if not training:
         key = tuple((t.data_ptr(), t._version) for t in (gamma, beta, bn.running_mean, bn.running_var)
-                    + ((bias,) if bias is not None else ())) + (getattr(bn, "_tp3d_train_passes", 0),)
+                    + ((bias,) if bias is not None else ())) + (getattr(bn, "_tp3d_train_passes", 0), _replay_epoch)
         hit = getattr(bn, "_tp3d_eval_stats", None)
         if hit is not None and hit[0] == key:
             return hit[1]
@@ -227,7 +252,7 @@ class _LinearBNAct(torch.autograd.Function):
         # the dense contraction on the fp32 MFMA rows kernel (128- or 64-column tiles); BatchNorm statistics come out of
         # its epilogue, except for the long contractions with few output tiles (the 4096-row global / decoder layers),
         # which run as a K-split launch followed by the separate statistics pass over their small output
-        if (not training and _is_skinny(M, Kp, Cout) and not any(ctx.needs_input_grad)):
+        if (not training and _is_skinny(M, Kp, Cout) and not (_outer_grad and any(ctx.needs_input_grad))):
             # eval-mode edge MLP layer, no gradient wanted: Linear + BatchNorm (running statistics) + activation in ONE
             # pass over the rows (tp3d_gemm_skinny_bnact_f32) instead of GEMM, statistics lookup and affine pass
             with _lib.on_device(dev):
@@ -344,7 +369,8 @@ class _MLPChain(torch.autograd.Function):
         L = len(layers)
         Ys, stats, W2s, cins, acts = [], [], [], [], []
         training = layers[0][0].training
-        keep_acts = CHAIN_LOADER and any(ctx.needs_input_grad)
+        # under torch.no_grad() the parameters still report requires_grad: no side outputs for a backward that cannot come
+        keep_acts = CHAIN_LOADER and _outer_grad and any(ctx.needs_input_grad)
         h = _lib.load()
         with _lib.on_device(dev):
             for l, (bn, slope) in enumerate(layers):
@@ -647,7 +673,7 @@ def nbr_maxpool(x, nbr):
 
 
 def linear_bn_act(A, conv, bn, slope, pool_ns=0):
-    return _LinearBNAct.apply(A, conv.weight, bn.weight, bn.bias, bn, slope, pool_ns, getattr(conv, "bias", None))
+    return _apply(_LinearBNAct, A, conv.weight, bn.weight, bn.bias, bn, slope, pool_ns, getattr(conv, "bias", None))
 
 
 
@@ -694,7 +720,7 @@ def run_mlp(rows, parts, pool_ns=0):
         flat = []
         for conv, bn, slope in parts:
             flat += [conv.weight, bn.weight, bn.bias]
-        return _MLPChain.apply(rows, pool_ns, [(bn, slope) for _, bn, slope in parts], getattr(rows, "_tp3d_grad_cols", None), *flat)
+        return _apply(_MLPChain, rows, pool_ns, [(bn, slope) for _, bn, slope in parts], getattr(rows, "_tp3d_grad_cols", None), *flat)
     for i, (conv, bn, slope) in enumerate(parts):
         rows = linear_bn_act(rows, conv, bn, slope, pool_ns if i == len(parts) - 1 else 0)
     return rows

@@ -69,6 +69,8 @@ def _xyz(t, name):
 class _Grid(object):
     def __init__(self, pts, cell):
         self.pts = pts  # keeps the borrowed coordinates alive
+        if pts.numel() and not bool(torch.isfinite(pts).all()):
+            raise ValueError("points_cpu: the support cloud holds NaN or Inf coordinates")
         self.h = _lib().tp3d_cpu_grid_build(pts.data_ptr(), pts.shape[0], float(cell))
         if not self.h:
             raise MemoryError("points_cpu: grid build failed")
