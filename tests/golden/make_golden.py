@@ -851,6 +851,194 @@ def make_rsconv_case():
     print("wrote %s (%.1f KiB)" % (path, os.path.getsize(path) / 1024.0))
 
 
+def make_randla_case():
+    """RandLA-Net local feature aggregation through the REFERENCE's own classes (modules/RandLANet/modules.py:
+    RandlaKernel :9-54, RandlaConv :57-67, DilatedResidualBlock :70-101, RandLANetRes :104-123;
+    core/base_conv/message_passing.py: BaseConvolutionDown :35-58, BaseResnetBlock :212-255; base_modules.MLP /
+    FastBatchNorm1d), loaded from the reference tree.  What is not installed is bound as follows:
+
+    * torch_geometric.nn.MessagePassing -> a stand-in whose propagate() does what PyG documents for aggr="add",
+      flow="source_to_target": `<arg>_j` = arg[edge_index[0]] (source), `<arg>_i` = arg[edge_index[1]] (target),
+      out = scatter-add of message(...) over edge_index[1], then update(out).  For a TUPLE argument PyG takes
+      element 0 for `_j` and element 1 for `_i` (`tuple_order = "pyg"`; used for the kernel-level fixtures, which call
+      RandlaKernel.forward directly with pos = (support positions, query positions)).
+    * BaseConvolutionDown.forward (:55) hands the kernel `(pos[idx], pos)` -- target FIRST.  Under PyG's rule that reads
+      pos_j = pos[idx][support index] and PyG's size check rejects it with a ValueError whenever the sample count
+      differs from the cloud size (ratio < 1), which is every RandLA-Net level but the first; the reference's own model
+      test skips randlanet (test/test_models.py:116-125).  The block-level fixtures therefore evaluate that tuple the
+      way the call site evidently means it (`tuple_order = "callsite"`: element 0 = targets, element 1 = sources), which
+      is also the paper's definition (pos_i = the sampled point, pos_j = its neighbour) and what torch_points3d_amd/randla.py
+      computes.  Nothing else of the arithmetic is touched.
+    * torch_geometric.nn.knn -> oracle/tpk_ref_cpu.c exact kNN as (row = query, col = support), query-major, closest
+      first.  torch_cluster is absent, so the EDGE ORDER is unpinned; the sum over a query's 16 edges runs in that order
+      on both sides.
+    * RandomSampler draws with torch.randint: the drawn indices are stored and replayed by the GPU test.
+
+    Every fixture: train-mode fp32 pass (+ running statistics after it), the same pass in float64, the eval-mode pass
+    after it, one backward (input and parameter gradients)."""
+    import copy
+    import importlib.util
+    import inspect
+
+    class MessagePassing(torch.nn.Module):
+        tuple_order = "pyg"
+
+        def __init__(self, aggr="add", flow="source_to_target", node_dim=0):
+            super().__init__()
+            assert aggr == "add" and flow == "source_to_target" and node_dim == 0
+
+        def propagate(self, edge_index, size=None, **kwargs):
+            src, dst = edge_index[0], edge_index[1]
+            n_dst = None
+            feed = {}
+            for name in inspect.signature(self.message).parameters:
+                value, is_j = kwargs.get(name[:-2]), name.endswith("_j")
+                if isinstance(value, (tuple, list)):
+                    j_elem = 0 if self.tuple_order == "pyg" else 1
+                    n_dst = value[1 - j_elem].shape[0]
+                    value = value[j_elem if is_j else 1 - j_elem]
+                feed[name] = None if value is None else value[src if is_j else dst]
+            msg = self.message(**feed)
+            if n_dst is None:
+                n_dst = int(dst.max()) + 1
+            out = torch.zeros(n_dst, msg.shape[1], dtype=msg.dtype).index_add_(0, dst, msg)
+            return self.update(out)
+
+    def knn_edges(x, y, k, batch_x=None, batch_y=None, **kw):
+        idx, _ = tpk_ref.knn(k, x.float(), y.float(), batch_x, batch_y)
+        row = torch.arange(y.shape[0]).repeat_interleave(k)
+        col = idx.reshape(-1)
+        keep = col >= 0
+        return torch.stack([row[keep], col[keep]], 0)
+
+    sys.modules["torch_geometric.nn"].MessagePassing = MessagePassing
+    sys.modules["torch_geometric.nn"].knn = knn_edges
+    import torch_points3d.core.spatial_ops.neighbour_finder as ref_nf
+    ref_nf.knn = knn_edges  # bound by name at import
+    spec = importlib.util.spec_from_file_location("_ref_randla", os.path.join(REF, "torch_points3d/modules/RandLANet/modules.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    import torch_points3d.core.base_conv.message_passing as ref_mp
+
+    class _Data(_Bag):
+        pass
+
+    ref_mp.Batch = _Data
+    rec = {}
+
+    def put_state(prefix, m):
+        for k, v in m.state_dict().items():
+            rec["%s/sd/%s" % (prefix, k)] = v.detach().clone()
+
+    def put_after(prefix, m):
+        for k, v in m.state_dict().items():
+            if "running_" in k:
+                rec["%s/after/%s" % (prefix, k)] = v.detach().clone()
+
+    def put_grads(prefix, m):
+        for k, p in m.named_parameters():
+            if p.grad is not None:
+                rec["%s/grad/%s" % (prefix, k)] = p.grad.detach().clone()
+
+    # ---- (1) kernel level: RandlaKernel.forward / message / update on a fixed edge list, PyG tuple order
+    g = torch.Generator().manual_seed(515)
+    M, Nq, k, F = 900, 300, 16, 6
+    pos_s = torch.rand(M, 3, generator=g) * 2 - 1
+    batch_s = torch.sort(torch.randint(0, 2, (M,), generator=g))[0]
+    qsel = torch.randint(0, M, (Nq,), generator=g)
+    pos_q, batch_q = pos_s[qsel], batch_s[qsel]
+    edges = knn_edges(pos_s, pos_q, k, batch_s, batch_q)
+    edge_index = torch.stack([edges[1], edges[0]], 0)  # message_passing.py:50: [col (support), row (query)]
+    rec.update({"k/pos_s": pos_s, "k/batch_s": batch_s, "k/qsel": qsel, "k/nbr": edges[1].view(Nq, k)})
+    MessagePassing.tuple_order = "pyg"
+    for tag, with_x in (("kx", True), ("kpos", False)):
+        cin = F if with_x else 3
+        torch.manual_seed(31 if with_x else 32)
+        ker = mod.RandlaKernel(point_pos_nn=[10, 8, F], attention_nn=[cin + F, 8, cin + F], global_nn=[cin + F, 8, 16])
+        ker.train()
+        put_state(tag, ker)
+        x = torch.randn(M, F, generator=g) if with_x else None
+        cot = torch.randn(Nq, 16, generator=g)
+        ker64 = copy.deepcopy(ker).double()
+        xin = x.clone().requires_grad_(True) if with_x else None
+        out = ker(xin, (pos_s, pos_q), edge_index)
+        (out * cot).sum().backward()
+        out64 = ker64(None if x is None else x.double(), (pos_s.double(), pos_q.double()), edge_index)
+        put_after(tag, ker)
+        put_grads(tag, ker)
+        ker.eval()
+        with torch.no_grad():
+            out_eval = ker(x, (pos_s, pos_q), edge_index)
+        rec.update({tag + "/out": out, tag + "/out64": out64.detach().numpy(), tag + "/out_eval": out_eval, tag + "/cot": cot})
+        if with_x:
+            rec.update({tag + "/x": x, tag + "/grad_x": xin.grad})
+
+    # ---- (2) block level: the two RandLANetRes down modules of conf/models/segmentation/randlanet.yaml Randlanet_Res
+    #          (ratio [1,1] then [0.5,0.5], FEAT = 6), call-site tuple order (see the docstring)
+    MessagePassing.tuple_order = "callsite"
+    N = 1200
+    pos = torch.rand(N, 3, generator=g) * 2 - 1
+    # ONE cloud: RandomSampler's indices are unsorted, so from the second convolution on `batch[idx]` of a multi-cloud
+    # batch is unsorted, which torch_cluster's knn (and the oracle) do not accept as batch_x
+    batch = torch.zeros(N, dtype=torch.long)
+    x = torch.randn(N, F, generator=g)
+    torch.manual_seed(41)
+    b0 = mod.RandLANetRes(indim=3, outdim=32, ratio=[1, 1], point_pos_nn=[[10, 8, F], [10, 16, 16]],
+                          attention_nn=[[2 * F, 8, 2 * F], [32, 64, 32]], down_conv_nn=[[2 * F, 8, 16], [32, 64, 32]],
+                          index=0, nb_feature=F)
+    b1 = mod.RandLANetRes(indim=32, outdim=128, ratio=[0.5, 0.5], point_pos_nn=[[10, 16, 32], [10, 32, 64]],
+                          attention_nn=[[64, 128, 64], [128, 256, 128]], down_conv_nn=[[64, 64, 64], [128, 128, 128]],
+                          index=1, nb_feature=F)
+    net = torch.nn.ModuleDict({"b0": b0, "b1": b1})
+    net.train()
+    put_state("blk", net)
+    net64 = copy.deepcopy(net).double()
+
+    drawn = []
+    real_randint = torch.randint
+
+    def recording_randint(*a, **kw):
+        out = real_randint(*a, **kw)
+        drawn.append(out.clone())
+        return out
+
+    def run(model, xx, pp, record_draws):
+        torch.manual_seed(43)  # RandomSampler is the only consumer of the global generator in forward
+        if record_draws:
+            torch.randint = recording_randint
+        try:
+            d0 = model["b0"](_Data(pos=pp, batch=batch, x=xx))
+            d1 = model["b1"](d0)
+        finally:
+            torch.randint = real_randint
+        return d0, d1
+
+    xin = x.clone().requires_grad_(True)
+    d0, d1 = run(net, xin, pos, True)
+    cot = torch.randn(d1.x.shape, generator=g)
+    (d1.x * cot).sum().backward()
+    e0, e1 = run(net64, x.double(), pos.double(), False)
+    put_after("blk", net)
+    put_grads("blk", net)
+    net.eval()
+    with torch.no_grad():
+        v0, v1 = run(net, x, pos, False)
+    assert len(drawn) == 4 and torch.equal(d1.idx, drawn[3])
+    rec.update({"blk/pos": pos, "blk/batch": batch, "blk/x": x, "blk/cot": cot, "blk/grad_x": xin.grad,
+                "blk/b0_x": d0.x, "blk/b0_pos": d0.pos, "blk/b1_x": d1.x, "blk/b1_pos": d1.pos, "blk/b1_batch": d1.batch,
+                "blk/b0_x64": e0.x.detach().numpy(), "blk/b1_x64": e1.x.detach().numpy(),
+                "blk/b0_x_eval": v0.x, "blk/b1_x_eval": v1.x})
+    for i, t in enumerate(drawn):
+        rec["blk/draw%d" % i] = t
+    path = os.path.join(HERE, "randla.npz")
+    np.savez_compressed(path, **to_np(rec))
+    print("wrote %s (%.1f KiB): kernel fixtures %d edges; blocks %d -> %d -> %d points; fp32-vs-fp64 distance of the "
+          "reference pass: kernel %.2e, b0 %.2e, b1 %.2e" % (
+              path, os.path.getsize(path) / 1024.0, edge_index.shape[1], N, d0.pos.shape[0], d1.pos.shape[0],
+              float((rec["kx/out"].double() - torch.from_numpy(rec["kx/out64"])).abs().max()),
+              float((d0.x.double() - e0.x).abs().max()), float((d1.x.double() - e1.x).abs().max())))
+
+
 SMALL_CFG = dict(npoint=[160, 40], radii=[[0.35], [0.7]], nsample=[[24], [16]],
                  down_conv_nn=[[[4 + 3, 16, 16, 24]], [[24 + 3, 24, 24, 32]]], innermost=[32 + 3, 32, 48],
                  up_conv_nn=[[48 + 32, 32, 32], [32 + 24, 32, 24], [24 + 4, 24, 24, 24]],
@@ -909,6 +1097,8 @@ def main():
         return make_conditioned_cases(SMALL_CFG, MSG_CFG)
     if sys.argv[1:] == ["rsconv"]:  # only this fixture (the others are unchanged)
         return make_rsconv_case()
+    if sys.argv[1:] == ["randla"]:
+        return make_randla_case()
     make_kpconv_case()
     from torch_points3d_amd.pointnet2 import unet_config
 
@@ -954,6 +1144,7 @@ def main():
     make_c3_case()
 
     make_rsconv_case()
+    make_randla_case()
 
     # (4) KPConv blocks + FPModule_PD through the reference's own classes (last: it replaces further modules by stubs)
     make_kpconv_blocks_case()
