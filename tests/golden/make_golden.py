@@ -579,7 +579,7 @@ def make_kpconv_case():
     print("wrote %s (%.1f KiB)" % (path, os.path.getsize(path) / 1024.0))
 
 
-def make_kpconv_blocks_case():
+def make_kpconv_blocks_case(name="kpconv_blocks", slope=None):
     """Partial-dense KPConv path through the REFERENCE's own block classes (modules/KPConv/blocks.py: SimpleBlock,
     ResnetBBlock, KPDualBlock; core/base_conv/partial_dense.py: FPModule_PD; core/common_modules/base_modules.py: MLP,
     FastBatchNorm1d) composed as applications/conf/kpconv/unet_4.yaml composes its first two levels and last decoder
@@ -587,7 +587,13 @@ def make_kpconv_blocks_case():
     torch_points_kernels.ball_query -> oracle/tpk_ref_cpu.c, GridSampling3D -> oracle/voxel_ref.py (the reference's
     transform module needs torch_cluster), torch_geometric.knn_interpolate -> brute-force kNN + the published
     inverse-squared-distance formula.  So the fixture pins the block LOGIC (radius rule, bottleneck, BatchNorm
-    momentum, strided shortcut, skip concatenation, kernel-point scaling) as the reference wrote it."""
+    momentum, strided shortcut, skip concatenation, kernel-point scaling) as the reference wrote it.
+
+    Per stage (level0, level1, decoder) the fixture holds the train-mode fp32 output, the same pass in float64 (same
+    sampled clouds and neighbour tables: positions go through the fp32 searches on both sides) and the eval-mode output
+    after the one training pass.  slope: every activation replaced by LeakyReLU(slope) -- slope 1.0 gives the kink-free
+    twin whose gradients two correct fp32 implementations agree on element-wise."""
+    import copy
     from oracle import voxel_ref
 
     class CpuGridSampling3D(object):
@@ -595,22 +601,24 @@ def make_kpconv_blocks_case():
             self._grid_size = size
 
         def __call__(self, data):
-            out = voxel_ref.grid_sampling_mean(data.pos.numpy(), self._grid_size, batch=data.batch.numpy(),
-                                               x=data.x.detach().numpy())
-            data.pos, data.batch = torch.from_numpy(out["pos"]), torch.from_numpy(out["batch"])
-            data.x = torch.from_numpy(out["x"])
+            dt = data.pos.dtype  # the float64 evaluation samples the SAME fp32 cloud
+            out = voxel_ref.grid_sampling_mean(data.pos.float().numpy(), self._grid_size, batch=data.batch.numpy(),
+                                               x=data.x.detach().float().numpy())
+            data.pos, data.batch = torch.from_numpy(out["pos"]).to(dt), torch.from_numpy(out["batch"])
+            data.x = torch.from_numpy(out["x"]).to(dt)  # (overwritten by the block: blocks.py:88)
             return data
 
     def knn_interpolate(x, pos_x, pos_y, batch_x=None, batch_y=None, k=3, num_workers=1):
-        idx, d2 = tpk_ref.knn(k, pos_x, pos_y, batch_x, batch_y)
+        idx, _ = tpk_ref.knn(k, pos_x.float(), pos_y.float(), batch_x, batch_y)
         Nq = pos_y.shape[0]
         y_idx = torch.arange(Nq).repeat_interleave(k)
         x_idx = idx.reshape(-1)
         keep = x_idx >= 0
-        w = (1.0 / torch.clamp(d2.reshape(-1, 1), min=1e-16))[keep]
         y_idx, x_idx = y_idx[keep], x_idx[keep]
-        num = torch.zeros(Nq, x.shape[1]).index_add_(0, y_idx, x[x_idx] * w)
-        return num / torch.zeros(Nq, 1).index_add_(0, y_idx, w)
+        d2 = ((pos_x[x_idx] - pos_y[y_idx]) ** 2).sum(-1, keepdim=True)
+        w = 1.0 / torch.clamp(d2, min=1e-16)
+        num = torch.zeros(Nq, x.shape[1], dtype=x.dtype).index_add_(0, y_idx, x[x_idx] * w)
+        return num / torch.zeros(Nq, 1, dtype=x.dtype).index_add_(0, y_idx, w)
 
     class _BILM(torch.nn.Module):
         pass
@@ -630,8 +638,10 @@ def make_kpconv_blocks_case():
         _stub("matplotlib").pyplot = _stub("matplotlib.pyplot")
     sys.modules["torch_geometric.nn"].knn_interpolate = knn_interpolate
     from torch_points3d.modules.KPConv.blocks import KPDualBlock
+    import torch_points3d.modules.KPConv.blocks as ref_blocks
     import torch_points3d.core.base_conv.partial_dense as ref_pd
     import torch_points3d.core.spatial_ops.interpolate as ref_interp
+    ref_blocks.GridSampling3D = CpuGridSampling3D  # (bound by name at the first import of the module)
     ref_interp.knn_interpolate = knn_interpolate  # it was imported by name before the stub was replaced
     ref_pd.Batch = _Data
 
@@ -642,26 +652,43 @@ def make_kpconv_blocks_case():
     x = torch.cat([torch.ones(N, 1), torch.randn(N, 3, generator=g)], 1)
     torch.manual_seed(5)
     np.random.seed(5)  # the kernel-point disposition gets a random rotation (kernel_utils.py:251-280)
+    kw = {} if slope is None else {"activation": torch.nn.LeakyReLU(negative_slope=slope)}
     level0 = KPDualBlock(block_names=["SimpleBlock", "ResnetBBlock"], down_conv_nn=[[4, f], [f, 2 * f]],
                          grid_size=[grid, grid], prev_grid_size=[grid, grid], has_bottleneck=[False, True],
-                         max_num_neighbors=[20, 20], deformable=[False, False], module_name="KPDualBlock", index=0)
+                         max_num_neighbors=[20, 20], deformable=[False, False], module_name="KPDualBlock", index=0, **kw)
     level1 = KPDualBlock(block_names=["ResnetBBlock", "ResnetBBlock"], down_conv_nn=[[2 * f, 2 * f], [2 * f, 4 * f]],
                          grid_size=[2 * grid, 2 * grid], prev_grid_size=[grid, 2 * grid], has_bottleneck=[True, True],
-                         max_num_neighbors=[20, 20], deformable=[False, False], module_name="KPDualBlock", index=1)
+                         max_num_neighbors=[20, 20], deformable=[False, False], module_name="KPDualBlock", index=1, **kw)
     up = ref_pd.FPModule_PD(up_k=1, up_conv_nn=[4 * f + 2 * f, f], skip=True, bn_momentum=0.2, module_name="FPModule_PD",
                             index=0)
+    if slope is not None:  # FPModule_PD's MLP takes no activation argument: swap the module
+        for blk in up.nn:
+            blk[2] = torch.nn.LeakyReLU(negative_slope=slope)
     net = torch.nn.ModuleDict({"level0": level0, "level1": level1, "up": up})
     net.train()
     state = {k: v.clone() for k, v in net.state_dict().items()}
+    net64 = copy.deepcopy(net).double()
+
+    def run(model, xin, pp):
+        d0 = model["level0"](_Data(pos=pp, batch=batch, x=xin))
+        d1 = model["level1"](d0)
+        return d0, d1, model["up"]((d1, d0))
+
     xin = x.clone().requires_grad_(True)
-    d0 = level0(_Data(pos=pos, batch=batch, x=xin))
-    d1 = level1(d0)
-    out = up((d1, d0))
-    loss = (out.x * torch.linspace(-1.0, 1.0, f)).sum()
+    d0, d1, out = run(net, xin, pos)
+    # cotangent: per-channel weights (the original fixture); for the kink-free twin a random one -- with identity
+    # activations the network ends in a BatchNorm, whose per-channel sum over the rows is a constant (zero gradient)
+    weights = torch.linspace(-1.0, 1.0, f)
+    if slope is not None:
+        weights = torch.randn(out.x.shape, generator=torch.Generator().manual_seed(78))
+    loss = (out.x * weights).sum()
     loss.backward()
     arrays = {"pos": pos, "batch": batch, "x": x, "grid": torch.tensor([grid]), "width": torch.tensor([f]),
               "l0_x": d0.x, "l0_idx": d0.idx_neighboors, "l1_pos": d1.pos, "l1_batch": d1.batch, "l1_x": d1.x,
               "l1_idx": d1.idx_neighboors, "out_x": out.x, "loss": loss.reshape(1), "grad_x": xin.grad}
+    if slope is not None:
+        arrays["slope"] = torch.tensor([slope])
+        arrays["cotangent"] = weights
     for k, v in state.items():
         arrays["sd." + k] = v
     for k, v in net.state_dict().items():
@@ -670,11 +697,30 @@ def make_kpconv_blocks_case():
     for k, p in net.named_parameters():
         if p.grad is not None:
             arrays["grad." + k] = p.grad
-    path = os.path.join(HERE, "kpconv_blocks.npz")
+    # ---- the same pass in float64 (same clouds, same tables), with its gradients
+    x64 = x.double().clone().requires_grad_(True)
+    with _Fp64Kernels():
+        e0, e1, eout = run(net64, x64, pos.double())
+        (eout.x * weights.double()).sum().backward()
+    assert torch.equal(e1.pos.float(), d1.pos) and torch.equal(e1.idx_neighboors, d1.idx_neighboors)
+    for key, v in (("l0_x", e0.x), ("l1_x", e1.x), ("out_x", eout.x), ("grad_x", x64.grad)):
+        arrays["f64/" + key] = v.detach().numpy()
+    for k, p in net64.named_parameters():
+        if p.grad is not None and slope is not None:
+            arrays["f64/grad." + k] = p.grad.numpy()
+    # ---- eval mode (running statistics as they stand after the one training pass)
+    net.eval()
+    with torch.no_grad():
+        v0, v1, vout = run(net, x, pos)
+    for key, v in (("l0_x", v0.x), ("l1_x", v1.x), ("out_x", vout.x)):
+        arrays["eval/" + key] = v
+    path = os.path.join(HERE, name + ".npz")
     np.savez_compressed(path, **to_np(arrays))
-    print("wrote %s (%.1f KiB): levels %d -> %d points, neighbour slots filled %.0f%% / %.0f%%" % (
-        path, os.path.getsize(path) / 1024.0, N, d1.pos.shape[0], 100 * float((d0.idx_neighboors >= 0).float().mean()),
-        100 * float((d1.idx_neighboors >= 0).float().mean())))
+    dist = lambda a, b: float((a.detach().double() - b.detach()).abs().max())  # noqa: E731
+    print("wrote %s (%.1f KiB): levels %d -> %d points, neighbour slots filled %.0f%% / %.0f%%; fp32-vs-fp64 distance of the "
+          "reference pass: l0 %.2e, l1 %.2e, out %.2e" % (
+              path, os.path.getsize(path) / 1024.0, N, d1.pos.shape[0], 100 * float((d0.idx_neighboors >= 0).float().mean()),
+              100 * float((d1.idx_neighboors >= 0).float().mean()), dist(d0.x, e0.x), dist(d1.x, e1.x), dist(out.x, eout.x)))
 
 
 def make_grid_sampling_case():
@@ -838,6 +884,30 @@ def make_rsconv_case():
     rec["grad_x_in"] = x_in.grad
     rec["grad_l0_msg_conv"] = l0._mapper.nn["mlp_msg"][0][0].weight.grad
     rec["grad_l1_raise_conv"] = l1.mlp_out[0].weight.grad
+    for name, m in (("l0", l0), ("l1", l1)):
+        for k, v in m.state_dict().items():
+            if "running_" in k:
+                rec["after/%s/%s" % (name, k)] = v.detach().clone()
+    # the same pass in float64 (same indices: the searches run on the fp32 coordinates), then the eval-mode pass
+    import copy
+    m0, m1 = copy.deepcopy(l0).double(), copy.deepcopy(l1).double()
+    for m, src in ((m0, l0), (m1, l1)):  # the copies were taken after the training pass: rewind their statistics
+        m.load_state_dict({k: rec["state/%s/%s" % ("l0" if src is l0 else "l1", k)].double()
+                           if rec["state/%s/%s" % ("l0" if src is l0 else "l1", k)].is_floating_point()
+                           else rec["state/%s/%s" % ("l0" if src is l0 else "l1", k)] for k in src.state_dict()})
+        m.train()
+    with _Fp64Kernels():
+        e0 = m0(_Bag(pos=pos.double(), x=feats.double().transpose(1, 2).contiguous()))
+        e1 = m1(e0)
+    rec["f64/l0_x"], rec["f64/l1_x"] = e0.x.detach().numpy(), e1.x.detach().numpy()
+    l0.eval()
+    l1.eval()
+    with torch.no_grad():
+        v0 = l0(_Bag(pos=pos, x=feats.transpose(1, 2).contiguous()))
+        v1 = l1(v0)
+    rec["eval/l0_x"], rec["eval/l1_x"] = v0.x, v1.x
+    print("rsconv: fp32-vs-fp64 distance of the reference pass: l0 %.2e, l1 %.2e" % (
+        float((d0.x.detach().double() - e0.x.detach()).abs().max()), float((d1.x.detach().double() - e1.x.detach()).abs().max())))
     # what the modules obtained at the kernel boundary
     fps0 = tpk_ref.furthest_point_sample(pos, 128)
     rec["fps0"] = fps0
@@ -1099,6 +1169,9 @@ def main():
         return make_rsconv_case()
     if sys.argv[1:] == ["randla"]:
         return make_randla_case()
+    if sys.argv[1:] == ["kpconv_blocks"]:
+        make_kpconv_blocks_case()
+        return make_kpconv_blocks_case("kpconv_blocks_slope1", slope=1.0)
     make_kpconv_case()
     from torch_points3d_amd.pointnet2 import unet_config
 
@@ -1148,6 +1221,7 @@ def main():
 
     # (4) KPConv blocks + FPModule_PD through the reference's own classes (last: it replaces further modules by stubs)
     make_kpconv_blocks_case()
+    make_kpconv_blocks_case("kpconv_blocks_slope1", slope=1.0)
     make_grid_sampling_case()
     make_unet4_config_case()
 
