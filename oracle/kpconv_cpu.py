@@ -41,10 +41,10 @@ def torch_knn_interpolate(x, idx, d2):
     y_idx = torch.arange(Nq).repeat_interleave(k)
     x_idx = idx.reshape(-1)
     keep = x_idx >= 0
-    w = 1.0 / torch.clamp(d2.reshape(-1, 1), min=1e-16)
+    w = 1.0 / torch.clamp(d2.reshape(-1, 1).to(x.dtype), min=1e-16)
     y_idx, x_idx, w = y_idx[keep], x_idx[keep], w[keep]
-    num = torch.zeros(Nq, x.shape[1]).index_add_(0, y_idx, x[x_idx] * w)
-    den = torch.zeros(Nq, 1).index_add_(0, y_idx, w)
+    num = torch.zeros(Nq, x.shape[1], dtype=x.dtype).index_add_(0, y_idx, x[x_idx] * w)
+    den = torch.zeros(Nq, 1, dtype=x.dtype).index_add_(0, y_idx, w)
     return num / den
 
 
@@ -57,12 +57,13 @@ class CpuSampler(object):
 
     def __call__(self, data):
         x = getattr(data, "x", None)
-        out = voxel_ref.grid_sampling_mean(data.pos.numpy(), self.size, batch=data.batch.numpy(),
-                                           x=None if x is None else x.detach().numpy())
-        data.pos = torch.from_numpy(out["pos"])
+        dt = data.pos.dtype  # a float64 evaluation samples the SAME fp32 cloud (positions are fp32 values on both sides)
+        out = voxel_ref.grid_sampling_mean(data.pos.float().numpy(), self.size, batch=data.batch.numpy(),
+                                           x=None if x is None else x.detach().float().numpy())
+        data.pos = torch.from_numpy(out["pos"]).to(dt)
         data.batch = torch.from_numpy(out["batch"])
         if x is not None:
-            data.x = torch.from_numpy(out["x"])
+            data.x = torch.from_numpy(out["x"]).to(dt)
         data.grid_size = torch.tensor([self.size])
         return data
 
@@ -74,19 +75,26 @@ class CpuInterp(object):
         self.k = k
 
     def __call__(self, query, support, precomputed=None, skip=None):
-        idx, d2 = tpk_ref.knn(self.k, query.pos, support.pos, query.batch, support.batch)
+        idx, d2 = tpk_ref.knn(self.k, query.pos.float(), support.pos.float(), query.batch, support.batch)
+        if query.x.dtype == torch.float64:  # the float64 evaluation: same neighbours, distances in double
+            nb = query.pos[idx.clamp(min=0)]
+            d2 = ((nb - support.pos[:, None, :]) ** 2).sum(-1)
         y = torch_knn_interpolate(query.x, idx, d2)
         return y if skip is None else torch.cat([y, skip], dim=1)
 
 
-def cpu_mirror(model):
+def cpu_mirror(model, double=False):
     """-> (CPU copy of a torch_points3d_amd KPConv model with oracle samplers / up-samplers, context manager that
-    routes its radius searches and convolutions to the oracle while active)."""
+    routes its radius searches and convolutions to the oracle while active).  double: the float64 evaluation of the same
+    pass -- parameters and features in double, sampling and searches on the fp32 coordinates (hence the same clouds and
+    tables): the yardstick "how far may a correct fp32 implementation be from the exact result"."""
     from torch_points3d_amd import kpconv as kpconv_mod
     from torch_points3d_amd import torchpoints as tp_mod
     from torch_points3d_amd.kpconv_blocks import SimpleBlock
     from torch_points3d_amd.partial_dense import FPModule_PD
     cpu = copy.deepcopy(model).cpu()
+    if double:
+        cpu = cpu.double()
     for m in cpu.modules():
         if isinstance(m, SimpleBlock) and m.sampler is not None:
             m.sampler = CpuSampler(m.sampler._grid_size)
@@ -96,7 +104,10 @@ def cpu_mirror(model):
     @contextlib.contextmanager
     def routed():
         saved = (tp_mod.ball_query, kpconv_mod.KPConv_ops)
-        tp_mod.ball_query, kpconv_mod.KPConv_ops = tpk_ref.ball_query, torch_kpconv
+        search = tpk_ref.ball_query
+        if double:
+            search = lambda r, n, x, y, **kw: tpk_ref.ball_query(r, n, x.float(), y.float(), **kw)  # noqa: E731
+        tp_mod.ball_query, kpconv_mod.KPConv_ops = search, torch_kpconv
         try:
             yield
         finally:

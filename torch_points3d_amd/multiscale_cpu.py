@@ -17,6 +17,7 @@ import torch
 from torch_points_kernels import points_cpu
 
 from .kpconv_blocks import PDData
+from .multiscale import LevelChain, attach
 
 
 def grid_sampling_cpu(pos, batch, size):
@@ -77,56 +78,90 @@ def knn_cpu(support, query, batch_s, batch_q, k):
     return idx, d2
 
 
+class HostGridSampler(object):
+    """sampler strategy on CPU tensors: `sampler(data) -> data` with pos / batch of the voxel representatives"""
+
+    def __init__(self, size):
+        self._grid_size = float(size)
+
+    def __call__(self, data):
+        pos, batch = grid_sampling_cpu(data.pos, data.batch, self._grid_size)
+        return PDData(pos=pos, batch=batch)
+
+
+class HostRadiusFinder(object):
+    """neighbour_finder strategy on CPU tensors (the call shape of core/spatial_ops/neighbour_finder.py:25-39)"""
+
+    def __init__(self, radius, max_num_neighbors):
+        self._radius, self._max_num_neighbors = float(radius), int(max_num_neighbors)
+
+    def __call__(self, x, y, batch_x=None, batch_y=None):
+        if batch_x is None:
+            batch_x = torch.zeros(x.shape[0], dtype=torch.long)
+        if batch_y is None:
+            batch_y = torch.zeros(y.shape[0], dtype=torch.long)
+        return radius_search_cpu(x, y, batch_x, batch_y, self._radius, self._max_num_neighbors)
+
+
+class HostKnnTable(object):
+    """upsample_op strategy on CPU tensors: `.precompute(query, support)` as core/spatial_ops/interpolate.py:11-32 --
+    the inverse-squared-distance table that carries features from the sampled (query) cloud back to `support`"""
+
+    def __init__(self, k):
+        self.k = int(k)
+
+    def precompute(self, query, support):
+        k = self.k
+        idx, d2 = knn_cpu(query.pos, support.pos, query.batch, support.batch, k)
+        n_sup = support.pos.shape[0]
+        y_idx = torch.arange(n_sup).repeat_interleave(k)
+        x_idx = idx.reshape(-1)
+        keep = x_idx >= 0
+        weights = (1.0 / torch.clamp(d2.reshape(-1, 1), min=1e-16))[keep]
+        y_idx, x_idx = y_idx[keep], x_idx[keep]
+        norm = torch.zeros((n_sup, 1)).index_add_(0, y_idx, weights)
+        return PDData(num_nodes=n_sup, x_idx=x_idx, y_idx=y_idx, weights=weights, normalisation=norm, knn_idx=idx, knn_d2=d2)
+
+
+def host_strategies(strategies):
+    """The model's strategy lists (`get_spatial_ops()`) as host strategies with the same call signatures: only
+    `_grid_size`, `_radius`, `_max_num_neighbors` and `k` are read.  They are what a caller of the reference's own
+    `MultiScaleTransform` hands it to run the precompute over this package on CPU tensors (tests/golden/check_dropin.py)."""
+    return {"sampler": [None if not s else HostGridSampler(s._grid_size) for s in strategies["sampler"]],
+            "neighbour_finder": [HostRadiusFinder(f._radius, f._max_num_neighbors) for f in strategies["neighbour_finder"]],
+            "upsample_op": [HostKnnTable(u.k) for u in strategies["upsample_op"]]}
+
+
 class MultiScaleTransformCPU(object):
     def __init__(self, strategies):
         """strategies: {"sampler": [...], "neighbour_finder": [...], "upsample_op": [...]} as the model lists them
-        (`get_spatial_ops()`); only `_grid_size`, `_radius`, `_max_num_neighbors` and `k` are read."""
-        self.levels = []
-        for sampler, finder in zip(strategies["sampler"], strategies["neighbour_finder"]):
-            self.levels.append((None if not sampler else float(sampler._grid_size), float(finder._radius),
-                                int(finder._max_num_neighbors)))
-        self.up_k = [int(u.k) for u in strategies["upsample_op"]]
+        (`get_spatial_ops()`) or already host strategies; only their parameters are read."""
+        host = host_strategies(strategies)
+        self.levels = [(None if s is None else s._grid_size, f._radius, f._max_num_neighbors)
+                       for s, f in zip(host["sampler"], host["neighbour_finder"])]
+        self.up_k = [u.k for u in host["upsample_op"]]
+        self.chain = LevelChain(
+            [(s, lambda parent, child, f=f: f(parent.pos, child.pos, batch_x=parent.batch, batch_y=child.batch))
+             for s, f in zip(host["sampler"], host["neighbour_finder"])],
+            [u.precompute for u in host["upsample_op"]])
+
+    @classmethod
+    def from_parameters(cls, levels, up_k):
+        """levels: [(voxel edge or None, radius, max_num_neighbors)] per block; up_k: k of every decoder stage"""
+        return cls({"sampler": [None if g is None else HostGridSampler(g) for g, _, _ in levels],
+                    "neighbour_finder": [HostRadiusFinder(r, m) for _, r, m in levels],
+                    "upsample_op": [HostKnnTable(k) for k in up_k]})
 
     def __call__(self, data):
-        """data: CPU pos (N,3) [, batch (N,) sorted] -> PDData(multiscale=[...], upsample=[...]) + data's attributes"""
+        """data: CPU pos (N,3) [, batch (N,) sorted] -> data + multiscale=[...], upsample=[...]"""
         pos = data.pos.detach().float().contiguous()
         if pos.device.type != "cpu":
             raise RuntimeError("MultiScaleTransformCPU works on CPU tensors (use multiscale.MultiScaleTransform on the device)")
         batch = getattr(data, "batch", None)
         if batch is None:
             batch = torch.zeros(pos.shape[0], dtype=torch.long)
-        precomputed = [PDData(pos=pos, batch=batch)]
-        upsample, up_index = [], 0
-        for grid, radius, max_num in self.levels:
-            support = precomputed[-1]
-            if grid is not None:
-                qpos, qbatch = grid_sampling_cpu(support.pos, support.batch, grid)
-                query = PDData(pos=qpos, batch=qbatch)
-                if self.up_k:
-                    if up_index >= len(self.up_k):
-                        raise ValueError("You are missing some upsample blocks in your network")
-                    k = self.up_k[up_index]
-                    up_index += 1
-                    # interpolation from the sampled (query) cloud back to the support cloud
-                    idx, d2 = knn_cpu(query.pos, support.pos, query.batch, support.batch, k)
-                    n_sup = support.pos.shape[0]
-                    y_idx = torch.arange(n_sup).repeat_interleave(k)
-                    x_idx = idx.reshape(-1)
-                    keep = x_idx >= 0
-                    weights = (1.0 / torch.clamp(d2.reshape(-1, 1), min=1e-16))[keep]
-                    y_idx, x_idx = y_idx[keep], x_idx[keep]
-                    norm = torch.zeros((n_sup, 1)).index_add_(0, y_idx, weights)
-                    upsample.append(PDData(num_nodes=n_sup, x_idx=x_idx, y_idx=y_idx, weights=weights, normalisation=norm,
-                                           knn_idx=idx, knn_d2=d2))
-            else:
-                query = PDData(pos=support.pos, batch=support.batch)
-            query.idx_neighboors = radius_search_cpu(support.pos, query.pos, support.batch, query.batch, radius, max_num)
-            precomputed.append(query)
-        out = data.shallow_copy() if hasattr(data, "shallow_copy") else PDData(**vars(data))
-        out.multiscale = precomputed[1:]
-        upsample.reverse()  # innermost decoder stage first
-        out.upsample = upsample
-        return out
+        clouds, tables = self.chain.run(PDData(pos=pos, batch=batch))
+        return attach(data, clouds, tables)
 
     def __repr__(self):
         return "{}(levels={}, up_k={})".format(self.__class__.__name__, self.levels, self.up_k)
