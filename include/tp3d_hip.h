@@ -35,7 +35,7 @@ extern "C" {
 #define TP3D_E_UNSORTED (-3) /* reserved: batch vector not sorted (checked by the host wrapper) */
 #define TP3D_E_TOOBIG (-4)   /* size exceeds what the kernel's index arithmetic supports */
 
-#define TP3D_ABI_VERSION 25
+#define TP3D_ABI_VERSION 26
 
 int tp3d_abi_version(void);
 const char *tp3d_strerror(int code);
@@ -217,15 +217,6 @@ int tp3d_gemm_rows_bnact_f32(const float *Y, const float *mean, const float *sca
  * (core/common_modules/dense_modules.py:25-29). */
 int tp3d_gemm_rows_sp_chunks(int64_t M, int N, int K, int with_act_out);
 int tp3d_gemm_rows_bnact_sp_f32(const float *Y, const float *mean, const float *scale, const float *beta, float slope,
-                                const float *Bt, int64_t M, int N, int K, float *C, float *stat_partial, float *act_out,
-                                void *stream);
-/* tp3d_gemm_rows_bnact_sp_f32 with the fp32 contraction carried by the bf16 matrix pipe (csrc/gemm_rows_b3.hip): every
- * operand value as three bf16 terms (split by the loader waves), the product as the six term pairs of weight >= 2^-16,
- * fp32 accumulation -- as accurate against float64 as the fp32 MFMA form, a different rounding.  Same arguments, same
- * statistics layout; tp3d_gemm_rows_b3_chunks is its chunk count / shape rule (more than 64 output columns).  Not used
- * unless torch_points3d_amd.fused.CHAIN_BF16_TERMS is set. */
-int tp3d_gemm_rows_b3_chunks(int64_t M, int N, int K, int with_act_out);
-int tp3d_gemm_rows_bnact_b3_f32(const float *Y, const float *mean, const float *scale, const float *beta, float slope,
                                 const float *Bt, int64_t M, int N, int K, float *C, float *stat_partial, float *act_out,
                                 void *stream);
 /* Input-gradient GEMM of a layer on the split-role kernel, with the layer's BatchNorm + activation BACKWARD formed by the

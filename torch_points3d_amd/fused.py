@@ -385,9 +385,6 @@ class _MLPChain(torch.autograd.Function):
                 Y = torch.empty((M, Cout), dtype=torch.float32, device=dev)
                 sp_chunks = h.tp3d_gemm_rows_sp_chunks(M, Cout, Kp, int(keep_acts)) if (l > 0 and CHAIN_LOADER) else 0
                 sp_entry = "tp3d_gemm_rows_bnact_sp_f32"
-                if sp_chunks and CHAIN_BF16_TERMS and h.tp3d_gemm_rows_b3_chunks(M, Cout, Kp, int(keep_acts)):
-                    sp_chunks = h.tp3d_gemm_rows_b3_chunks(M, Cout, Kp, int(keep_acts))
-                    sp_entry = "tp3d_gemm_rows_bnact_b3_f32"  # the same contraction as bf16 term pairs on the matrix pipe
                 chunks = None
                 if l == 0:
                     part = _lib.workspace("gemm_rows_stats", 4 * h.tp3d_gemm_rows_stat_floats(M, Cout), dev) if training else None
@@ -558,9 +555,6 @@ def _chain_ok(rows, parts):
     return True
 
 
-CHAIN_BF16_TERMS = False  # forward contractions of the chain as bf16 term pairs on the matrix pipe (csrc/gemm_rows_b3.hip):
-                          # as accurate against float64 as the fp32 MFMA form and 11-25 % faster per layer, but another rounding --
-                          # off until the parity bars have been re-measured with it
 CHAIN_BWD_POOLED = True  # ... also for the max-pooled last layer of a set-abstraction MLP (groups of 64, 128 ... rows)
 CHAIN_BWD_LOADER = True  # the chain's input-gradient GEMMs form dY in their loader waves (else: apply pass + library GEMM)
 CHAIN_LOADER = True    # hidden layers' BatchNorm + activation in the loader waves of the split-role GEMM, activated rows as
