@@ -162,7 +162,7 @@ def algorithmic_bytes(name, a):
         return B * (m * C1 * 4 + n * 36 + n * C2 * 4 + n * ld * 4)
     if name == "tp3d_idw_weights_f32":  # rows
         return a[0] * 24
-    if name in ("tp3d_gemm_tn_f32", "tp3d_gemm_rows_f32", "tp3d_gemm_rows_bnact_f32"):  # M, N, K
+    if name in ("tp3d_gemm_tn_f32", "tp3d_gemm_tn_x3_f32", "tp3d_gemm_rows_f32", "tp3d_gemm_rows_bnact_f32"):  # M, N, K
         M, N, K = a[:3]
         return (M * (N + K) + N * K) * 4
     if name == "tp3d_gemm_rows_bnact_sp_f32":  # M, N, K (the side output of the training launches, M * K more, not counted)
@@ -219,7 +219,7 @@ def algorithmic_bytes(name, a):
 
 
 def algorithmic_flops(name, a):
-    if name in ("tp3d_gemm_tn_f32", "tp3d_gemm_rows_f32", "tp3d_gemm_rows_bnact_f32"):  # M, N, K
+    if name in ("tp3d_gemm_tn_f32", "tp3d_gemm_tn_x3_f32", "tp3d_gemm_rows_f32", "tp3d_gemm_rows_bnact_f32"):  # M, N, K
         M, N, K = a[:3]
         return 2 * M * N * K
     if name in ("tp3d_gemm_rows_bnbwd_f32", "tp3d_gemm_tn_bn_f32"):  # ns, M, N, K
@@ -271,15 +271,19 @@ def dominant_roofline(per_entry, steps):
     e = per_entry[dom]
     traffic, source = load_traffic(dom)
     sec = e["ms"] / 1e3
-    if e["flops"]:
-        achieved = e["flops"] / 1e12 / sec
-        roof = {"kernel": dom, "bound": "mfma", "achieved": round(achieved, 2), "peak": MFMA_F32_PEAK_TFLOPS,
-                "unit": "TFLOP/s", "frac": round(achieved / MFMA_F32_PEAK_TFLOPS, 4), "traffic": traffic,
+    tflops, gbs = e["flops"] / 1e12 / sec, e["bytes"] / 1e9 / sec
+    f_mfma, f_hbm = tflops / MFMA_F32_PEAK_TFLOPS, gbs / HBM_PEAK_GBS
+    # a contraction whose operands are streamed once sits between the two roofs: the binding one is the roof it is closer
+    # to (the other fraction is reported beside it)
+    if e["flops"] and f_mfma >= f_hbm:
+        roof = {"kernel": dom, "bound": "mfma", "achieved": round(tflops, 2), "peak": MFMA_F32_PEAK_TFLOPS,
+                "unit": "TFLOP/s", "frac": round(f_mfma, 4), "traffic": traffic, "frac_hbm": round(f_hbm, 4),
                 "algorithmic_flops_per_launch": int(e["flops"] / e["launches"])}
     else:
-        achieved = e["bytes"] / 1e9 / sec
-        roof = {"kernel": dom, "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic}
+        roof = {"kernel": dom, "bound": "hbm", "achieved": round(gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(f_hbm, 5), "traffic": traffic}
+        if e["flops"]:
+            roof["frac_mfma_f32"] = round(f_mfma, 4)
     roof["algorithmic_bytes_per_launch"] = int(e["bytes"] / e["launches"])
     roof.update({"avg_launch_ms": round(e["ms"] / e["launches"], 4), "launches": e["launches"],
                  "ms_per_step": round(e["ms"] / steps, 4)})

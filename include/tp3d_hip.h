@@ -35,7 +35,7 @@ extern "C" {
 #define TP3D_E_UNSORTED (-3) /* reserved: batch vector not sorted (checked by the host wrapper) */
 #define TP3D_E_TOOBIG (-4)   /* size exceeds what the kernel's index arithmetic supports */
 
-#define TP3D_ABI_VERSION 26
+#define TP3D_ABI_VERSION 27
 
 int tp3d_abi_version(void);
 const char *tp3d_strerror(int code);
@@ -252,6 +252,19 @@ int tp3d_bn_finalize_f32(float *partial, int chunks, int64_t M, int C, float eps
 size_t tp3d_gemm_tn_workspace_floats(int64_t M, int N, int K);
 int tp3d_gemm_tn_f32(const float *dY, const float *A, int64_t M, int N, int K, float *out, float *workspace,
                      void *stream);
+
+/* The same contraction with the fp32 products carried by the bf16 matrix pipe (csrc/gemm_tn_x3.hip): every operand value is
+ * split exactly into three bf16 terms (3 x 8 significand bits) by the loader waves of a split-role kernel, and the product
+ * is the sum of the term pairs -- terms = 9: all nine, every product exact as in the fp32 MFMA; terms = 6: the six of
+ * weight >= 2^-16 -- each a v_mfma_f32_32x32x16_bf16 with fp32 accumulation.  The contraction then runs at the rate HBM
+ * delivers the rows instead of at the fp32 MFMA rate.  Serves M >= 131072, N >= 64, K >= 64 (not both 64), N % 4 == 0, K % 4 == 0, M * max(N, K) < 2^30
+ * (tp3d_gemm_tn_x3_serves); other shapes: tp3d_gemm_tn_f32.  workspace: tp3d_gemm_tn_x3_workspace_floats floats.
+ * Reference: the weight gradient of Conv2d 1x1 in MLP2D (core/common_modules/dense_modules.py:5-12), autograd's
+ * grad_output^T @ input. */
+int tp3d_gemm_tn_x3_serves(int64_t M, int N, int K);
+size_t tp3d_gemm_tn_x3_workspace_floats(int64_t M, int N, int K);
+int tp3d_gemm_tn_x3_f32(const float *dY, const float *A, int64_t M, int N, int K, int terms, float *out, float *workspace,
+                        void *stream);
 /* The same weight gradient with both operands formed while they are staged, so that neither the BatchNorm-backward
  * result dY nor the activated layer input has to exist in HBM (autograd of dense_modules.py:25-29):
  *   dY = scale_n*(dZ - c1_n - (Y - mean_n)*c2_n), dZ = dA * act'((Y - mean_n)*scale_n + beta_n)
@@ -403,6 +416,9 @@ int tp3d_nbr_maxpool_bwd_f32(const float *grad_out, const int32_t *argmax, const
 /* plan[8]: splits, rows per split, tile rows (N side), tile columns (K side), tiles, rows staged per step,
  * workspace floats written, first row of the last split */
 int tp3d_gemm_tn_plan(int64_t M, int N, int K, int64_t *plan);
+/* plan[0..7] = splits, rows per split, tile rows (n), tile columns (k, strip included), tiles, rows staged per step,
+ * workspace floats, dynamic LDS bytes of tp3d_gemm_tn_x3_f32 */
+int tp3d_gemm_tn_x3_plan(int64_t M, int N, int K, int64_t *plan);
 /* plan[9]: column tiles, row blocks, work items, workgroups, statistics chunks written, 1 = one chunk set per
  * workgroup, wave rows per tile, K-ranges of a split launch (K = 0: not asked), tile columns */
 int tp3d_gemm_rows_plan(int64_t M, int N, int K, int64_t *plan);

@@ -47,6 +47,16 @@ def test_entry_sums_and_dominant_roofline():
     assert roof["launches"] == 17 * 20
 
 
+def test_roofline_names_the_roof_the_kernel_is_closer_to():
+    """a contraction that streams its operands once is priced against both roofs; the binding one is reported"""
+    summ = {("tp3d_gemm_rows_bnbwd_sp_f32", (524288, 128, 128, 128, 0, 0, 1, 0)): (20, 20 * 0.2195)}
+    roof = bench.dominant_roofline(bench.entry_sums(summ), 20)
+    assert roof["bound"] == "hbm" and roof["frac"] > roof["frac_mfma_f32"] > 0.3
+    summ = {("tp3d_gemm_tn_f32", (524288, 128, 128, 0)): (20, 20 * 0.170)}
+    roof = bench.dominant_roofline(bench.entry_sums(summ), 20)
+    assert roof["bound"] == "mfma" and roof["frac"] > roof["frac_hbm"]
+
+
 def test_every_workload_roofline_has_numbers():
     """the KPConv line's roofline was {achieved: null, frac: null} whenever a GEMM dominated"""
     summ = {("tp3d_gemm_rows_f32", (65536, 64, 960, 0)): (10, 5.1),

@@ -864,3 +864,40 @@ def test_no_grad_forward_keeps_no_side_outputs():
         _lib.set_post_call_hook(prev)
     assert fused._outer_grad is True
     torch.testing.assert_close(a, b.detach(), rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("M,N,K", [(131072, 128, 128), (140001, 128, 132), (262144, 256, 128), (131072, 128, 64),
+                                   (150000, 64, 128), (131072, 192, 100), (131073, 128, 160), (200000, 132, 260)])
+@pytest.mark.parametrize("terms", [9, 6])
+def test_gemm_tn_x3_matches_fp64(M, N, K, terms):
+    """The weight-gradient contraction on the bf16 matrix pipe (csrc/gemm_tn_x3.hip: every fp32 value split exactly into
+    three bf16 terms, the product as 9 or 6 term pairs, fp32 accumulation) against float64 -- the bar of
+    test_gemm_tn_matches_fp64 (within 2x the library GEMM's error or 1e-5 of the scale), and against the fp32 MFMA kernel's
+    own error on the same inputs (measured 1.4-2.4x: the products are exact on both pipes, the bf16 MFMA's accumulator
+    rounds differently); exact on small integers; reproducible; non-finite operands poison the same outputs."""
+    from torch_points3d_amd import _lib, fused
+    assert _lib.load().tp3d_gemm_tn_x3_serves(M, N, K)
+    g = torch.Generator().manual_seed(M + N + K)
+    dY = torch.randn(M, N, generator=g).to(DEV)
+    A = torch.randn(M, K, generator=g).to(DEV)
+    got = fused.gemm_tn(dY, A, x3=terms)
+    base = fused.gemm_tn(dY, A, x3=0)
+    ref = torch.mm(dY.double().t(), A.double())
+    scale = float(ref.abs().max())
+    err, err32 = float((got.double() - ref).abs().max()), float((base.double() - ref).abs().max())
+    lib = float((torch.mm(dY.t(), A).double() - ref).abs().max())
+    assert got.shape == (N, K)
+    assert err <= max(2.0 * lib, 1e-5 * scale), (err, lib, scale)
+    assert err <= 3.0 * err32 + 1e-7 * scale, (err, err32)
+    assert torch.equal(got, fused.gemm_tn(dY, A, x3=terms))
+    dYi = torch.randint(-3, 4, (M, N), generator=g).float().to(DEV)
+    Ai = torch.randint(-3, 4, (M, K), generator=g).float().to(DEV)
+    assert torch.equal(fused.gemm_tn(dYi, Ai, x3=terms), torch.mm(dYi.double().t(), Ai.double()).float())
+    # rows holding +-inf, NaN, a denormal-range value and FLT_MAX-sized values: the finite / non-finite pattern of the result
+    # is the fp32 kernel's (an infinity may read NaN: x - hi(x) is NaN for an infinite x)
+    dY[5, 3], dY[M - 2, 9], dY[77, 1] = float("inf"), float("nan"), 3.0e38
+    A[11, 2], A[M // 2, 4], A[77, 0] = 1e-38, -float("inf"), 0.5
+    a, b = fused.gemm_tn(dY, A, x3=terms), fused.gemm_tn(dY, A, x3=0)
+    assert torch.equal(torch.isfinite(a), torch.isfinite(b))
+    fin = torch.isfinite(b)
+    assert float((a[fin].double() - b[fin].double()).abs().max()) <= 1e-5 * float(b[fin].abs().max())

@@ -41,6 +41,33 @@ def test_gemm_tn_plan_fits_its_workspace():
             assert tiles * tn * tk >= N * K
 
 
+def test_gemm_tn_x3_plan_fits_its_workspace_and_lds():
+    """the bf16-pipe weight-gradient kernel (csrc/gemm_tn_x3.hip): shapes it declares served, its partial-tile extent, its
+    dynamic LDS (must fit the CU's 160 KiB), the 32-bit byte offsets its loader lanes use"""
+    h = _lib.load()
+    served = 0
+    for M in ROWS:
+        for N, K in itertools.product(CHANNELS, CHANNELS):
+            ok = h.tp3d_gemm_tn_x3_serves(M, N, K)
+            want = M >= 131072 and N >= 64 and K >= 64 and (N > 64 or K > 64) and N % 4 == 0 and K % 4 == 0 and \
+                M * max(N, K) < 2 ** 30
+            assert bool(ok) == want, (M, N, K)
+            if not ok:
+                assert h.tp3d_gemm_tn_x3_workspace_floats(M, N, K) == 0
+                continue
+            served += 1
+            splits, rps, tn, tk, tiles, staged, floats, lds = _plan("tp3d_gemm_tn_x3_plan", 8, M, N, K)
+            assert floats == splits * N * K == h.tp3d_gemm_tn_x3_workspace_floats(M, N, K), (M, N, K)
+            assert 1 <= splits <= 256 and splits * tiles <= 512, (M, N, K, splits, tiles)
+            assert rps % staged == 0 and splits * rps >= M and (splits - 1) * rps < M, (M, N, K, splits, rps)
+            assert lds <= 160 * 1024 and staged in (32, 64), (M, N, K, lds)
+            assert tn in (64, 128) and tk in (64, 128, 160) and tiles * tn * tk >= N * K, (M, N, K, tn, tk, tiles)
+            if 128 < K <= 160 and N > 64:
+                assert tk == 160 and tiles == -(-N // 128)  # the strip: dY is read once, not once per tile column
+            assert M * max(N, K) * 4 < 2 ** 32  # loader lanes address a row block with 32-bit byte offsets
+    assert served > 200
+
+
 def test_gemm_rows_plan_fits_its_statistics_buffer():
     h = _lib.load()
     for M in ROWS:

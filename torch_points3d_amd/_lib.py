@@ -37,6 +37,7 @@ SIGNATURES = {
     "tp3d_interp_concat_fwd_f32": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _p],
     "tp3d_idw_weights_f32": [_p, _l, _p, _p],
     "tp3d_gemm_tn_f32": [_p, _p, _l, _i, _i, _p, _p, _p],
+    "tp3d_gemm_tn_x3_f32": [_p, _p, _l, _i, _i, _i, _p, _p, _p],
     "tp3d_gemm_tn_bn_f32": [_p, _p, _p, _i, _p, _p, _p, _p, _p, _f, _p, _p, _p, _p, _f, _l, _i, _i, _p, _p, _p],
     "tp3d_bn_bwd_reduce_f32": [_p, _p, _p, _p, _p, _p, _p, _f, _l, _i, _i, _i, _p, _p, _p, _p, _p, _p],
     "tp3d_gemm_rows_f32": [_p, _p, _l, _i, _i, _p, _p, _p, _p],
@@ -65,14 +66,15 @@ SIGNATURES = {
     "tp3d_relation_rows_f32": [_p, _p, _p, _i, _i, _i, _i, _i, _p, _p],
     # launch plans (host arithmetic; the last argument is a HOST int64 array)
     "tp3d_gemm_tn_plan": [_l, _i, _i, _p],
+    "tp3d_gemm_tn_x3_plan": [_l, _i, _i, _p],
     "tp3d_gemm_rows_plan": [_l, _i, _i, _p],
     "tp3d_bn_plan": [_l, _i, _i, _p],
     "tp3d_scatter_plan": [_i, _i, _i, _i, _p],
 }
 MISC = ("tp3d_abi_version", "tp3d_strerror", "tp3d_last_hip_error", "tp3d_scatter_workspace_bytes",
-        "tp3d_bn_workspace_floats", "tp3d_gemm_tn_workspace_floats", "tp3d_ball_query_workspace_bytes",
+        "tp3d_bn_workspace_floats", "tp3d_gemm_tn_workspace_floats", "tp3d_gemm_tn_x3_workspace_floats", "tp3d_gemm_tn_x3_serves", "tp3d_ball_query_workspace_bytes",
         "tp3d_gemm_rows_stat_floats", "tp3d_gemm_rows_stat_chunks", "tp3d_gemm_rows_sp_chunks", "tp3d_gemm_rows_bnbwd_sp_serves", "tp3d_gemm_rows_workspace_floats", "tp3d_kpconv_bwd_workspace_bytes", "tp3d_voxel_workspace_bytes", "tp3d_knn_workspace_bytes", "tp3d_kpconv_grad_workspace_bytes")
-ABI_VERSION = 26
+ABI_VERSION = 27
 
 _handle = None
 
@@ -110,6 +112,10 @@ def load():
     h.tp3d_bn_workspace_floats.argtypes = [_l, _i]
     h.tp3d_gemm_tn_workspace_floats.restype = ctypes.c_size_t
     h.tp3d_gemm_tn_workspace_floats.argtypes = [_l, _i, _i]
+    h.tp3d_gemm_tn_x3_workspace_floats.restype = ctypes.c_size_t
+    h.tp3d_gemm_tn_x3_workspace_floats.argtypes = [_l, _i, _i]
+    h.tp3d_gemm_tn_x3_serves.restype = ctypes.c_int
+    h.tp3d_gemm_tn_x3_serves.argtypes = [_l, _i, _i]
     h.tp3d_kpconv_bwd_workspace_bytes.restype = ctypes.c_size_t
     h.tp3d_kpconv_bwd_workspace_bytes.argtypes = [_l, _l]
     h.tp3d_gemm_rows_stat_floats.restype = ctypes.c_size_t
@@ -335,8 +341,9 @@ def bn_workspace(M, C, device):
     return workspace("bn", 4 * n, device)
 
 
-def gemm_tn_workspace(M, N, K, device):
-    n = load().tp3d_gemm_tn_workspace_floats(M, N, K)
+def gemm_tn_workspace(M, N, K, device, x3=False):
+    h = load()
+    n = h.tp3d_gemm_tn_x3_workspace_floats(M, N, K) if x3 else h.tp3d_gemm_tn_workspace_floats(M, N, K)
     return workspace("gemm_tn", 4 * n, device)
 
 

@@ -256,6 +256,14 @@ __global__ __launch_bounds__(RD_E *RD_S) void gemm_tn_reduce_kernel(const float 
     }
 }
 
+// the split sum as a launch other translation units can enqueue (gemm_tn_x3.hip)
+int tn_reduce_splits(const float *partial, int splits, int64_t NK, float *out, hipStream_t s)
+{
+    hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3((unsigned)((NK + RD_E - 1) / RD_E)), dim3(RD_E * RD_S), 0, s, partial, splits,
+                       NK, out);
+    return check_launch();
+}
+
 struct TnPlan {
     int wm, wn, gn, tn, tk, tiles_n, tiles_k, splits;
     int64_t rows_per_split;
@@ -334,10 +342,7 @@ static int launch_tn(const float *dY, const float *A, int64_t M, int N, int K, f
 #undef TP3D_TN_ALIGN
 #undef TP3D_TN_LAUNCH
     if (int rc = check_launch()) return rc;
-    const int64_t NK = (int64_t)N * K;
-    hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3((unsigned)((NK + RD_E - 1) / RD_E)), dim3(RD_E * RD_S), 0, s, workspace,
-                       p.splits, NK, out);
-    return check_launch();
+    return tn_reduce_splits(workspace, p.splits, (int64_t)N * K, out, s);
 }
 
 }  // namespace tp3d

@@ -81,6 +81,9 @@ int invert_table(const int64_t *idx, int64_t slots, int64_t M, int *cnt, int *st
 // csr.hip: does the one-workgroup-per-cloud transpose fit LDS?
 bool csr_fits_lds(int L, int nbins);
 
+// gemm_tn.hip: out[e] = sum over the row splits of partial[s][e], in ascending split order (reproducible)
+int tn_reduce_splits(const float *partial, int splits, int64_t NK, float *out, hipStream_t s);
+
 // grid.hip: uniform-grid radius search (build + query); seg/batch_y null => dense layout (more in grid.h)
 int grid_ball_query(const float *x, const float *y, const int64_t *seg, const int64_t *batch_y, int num_clouds,
                     int64_t rows, int N, int np, int64_t total_q, int Lmax, float radius, int nsample, int sort,

@@ -65,17 +65,33 @@ def mlp_parts(mlp):
     return None if (not parts or any(p is None for p in parts)) else parts
 
 
-def gemm_tn(dY, A):
-    """dY (M,N), A (M,K) -> dY^T @ A (N,K): split-K fp32 MFMA kernel (csrc/gemm_tn.hip), reproducible."""
+WGRAD_X3 = 6  # weight-gradient contractions of the large layers on the bf16 matrix pipe, every fp32 value split exactly into
+              # three bf16 terms (csrc/gemm_tn_x3.hip): 6 = the six term pairs of weight >= 2^-15 (what is dropped is below
+              # 2^-21 of a product), 9 = all nine (every product exact), 0 = the fp32 MFMA kernel for every shape.
+              # Measured against float64 on the layers of the BASELINE step: 2.1-3.3e-7 of the scale with 6 or 9 terms
+              # (hi * hi products in an accumulator of their own), 4.2-5.4e-7 for the fp32 MFMA kernel; 524288 x 128 x 128:
+              # 133 us (6), 141 us (9), 185 us (fp32 MFMA) -- the matrix pipe's load lowers the shader clock (2.2 -> 1.8 GHz
+              # in the counters), so the nine-term form costs more than its extra MFMAs
+
+
+def gemm_tn(dY, A, x3=None):
+    """dY (M,N), A (M,K) -> dY^T @ A (N,K), split over the rows, partial tiles summed in fixed order (reproducible):
+    csrc/gemm_tn_x3.hip for the shapes it serves (x3 terms, default WGRAD_X3), else the fp32 MFMA kernel csrc/gemm_tn.hip."""
     dev = dY.device
     dY, A = dY.contiguous(), A.contiguous()
     M, N = dY.shape
     K = A.shape[1]
     out = torch.empty((N, K), dtype=torch.float32, device=dev)
-    ws = _lib.gemm_tn_workspace(M, N, K, dev)
+    terms = WGRAD_X3 if x3 is None else x3
+    use_x3 = bool(terms) and M > 0 and bool(_lib.load().tp3d_gemm_tn_x3_serves(M, N, K))
+    ws = _lib.gemm_tn_workspace(M, N, K, dev, x3=use_x3)
     with _lib.on_device(dev):
-        _lib.call("tp3d_gemm_tn_f32", _lib.ptr(dY), _lib.ptr(A), M, N, K, _lib.ptr(out), _lib.ptr(ws),
-                  _lib.stream_ptr(dev))
+        if use_x3:
+            _lib.call("tp3d_gemm_tn_x3_f32", _lib.ptr(dY), _lib.ptr(A), M, N, K, int(terms), _lib.ptr(out), _lib.ptr(ws),
+                      _lib.stream_ptr(dev))
+        else:
+            _lib.call("tp3d_gemm_tn_f32", _lib.ptr(dY), _lib.ptr(A), M, N, K, _lib.ptr(out), _lib.ptr(ws),
+                      _lib.stream_ptr(dev))
     return out
 
 
