@@ -162,7 +162,7 @@ def algorithmic_bytes(name, a):
         return B * (m * C1 * 4 + n * 36 + n * C2 * 4 + n * ld * 4)
     if name == "tp3d_idw_weights_f32":  # rows
         return a[0] * 24
-    if name in ("tp3d_gemm_tn_f32", "tp3d_gemm_tn_x3_f32", "tp3d_gemm_rows_f32", "tp3d_gemm_rows_bnact_f32"):  # M, N, K
+    if name in ("tp3d_gemm_tn_f32", "tp3d_gemm_tn_x3_f32", "tp3d_gemm_tn_x3_act_f32", "tp3d_gemm_rows_f32", "tp3d_gemm_rows_bnact_f32"):  # M, N, K
         M, N, K = a[:3]
         return (M * (N + K) + N * K) * 4
     if name == "tp3d_gemm_rows_bnact_sp_f32":  # M, N, K (the side output of the training launches, M * K more, not counted)
@@ -219,7 +219,7 @@ def algorithmic_bytes(name, a):
 
 
 def algorithmic_flops(name, a):
-    if name in ("tp3d_gemm_tn_f32", "tp3d_gemm_tn_x3_f32", "tp3d_gemm_rows_f32", "tp3d_gemm_rows_bnact_f32"):  # M, N, K
+    if name in ("tp3d_gemm_tn_f32", "tp3d_gemm_tn_x3_f32", "tp3d_gemm_tn_x3_act_f32", "tp3d_gemm_rows_f32", "tp3d_gemm_rows_bnact_f32"):  # M, N, K
         M, N, K = a[:3]
         return 2 * M * N * K
     if name in ("tp3d_gemm_rows_bnbwd_f32", "tp3d_gemm_tn_bn_f32"):  # ns, M, N, K

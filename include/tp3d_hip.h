@@ -35,7 +35,7 @@ extern "C" {
 #define TP3D_E_UNSORTED (-3) /* reserved: batch vector not sorted (checked by the host wrapper) */
 #define TP3D_E_TOOBIG (-4)   /* size exceeds what the kernel's index arithmetic supports */
 
-#define TP3D_ABI_VERSION 27
+#define TP3D_ABI_VERSION 28
 
 int tp3d_abi_version(void);
 const char *tp3d_strerror(int code);
@@ -265,6 +265,12 @@ int tp3d_gemm_tn_x3_serves(int64_t M, int N, int K);
 size_t tp3d_gemm_tn_x3_workspace_floats(int64_t M, int N, int K);
 int tp3d_gemm_tn_x3_f32(const float *dY, const float *A, int64_t M, int N, int K, int terms, float *out, float *workspace,
                         void *stream);
+/* ... with the A operand formed on the fly: dW = dY^T * LeakyReLU((Yp - mean_k) * scale_k + beta_k), Yp (M, K) the previous
+ * layer's pre-BatchNorm output, mean_k / scale_k / beta_k its statistics rows (K floats each).  The loader waves evaluate
+ * the forward kernels' expression in their order, so the result is bit for bit that of the plain entry point on the
+ * activated rows -- which the forward pass then need not write. */
+int tp3d_gemm_tn_x3_act_f32(const float *dY, const float *Yp, const float *mean_k, const float *scale_k, const float *beta_k,
+                            float slope_k, int64_t M, int N, int K, int terms, float *out, float *workspace, void *stream);
 /* The same weight gradient with both operands formed while they are staged, so that neither the BatchNorm-backward
  * result dY nor the activated layer input has to exist in HBM (autograd of dense_modules.py:25-29):
  *   dY = scale_n*(dZ - c1_n - (Y - mean_n)*c2_n), dZ = dA * act'((Y - mean_n)*scale_n + beta_n)

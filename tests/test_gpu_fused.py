@@ -857,9 +857,21 @@ def test_no_grad_forward_keeps_no_side_outputs():
         sp = [args for name, args in seen if name == "tp3d_gemm_rows_bnact_sp_f32"]
         assert sp and all(args[11] is None for args in sp)
         del seen[:]
-        b = net(Data(pos=pos, x=x)).x
+        keep = fused.WGRAD_X3_ACT
+        fused.WGRAD_X3_ACT = False  # (with it, layers whose weight gradient the bf16-pipe contraction serves keep none either)
+        try:
+            b = net(Data(pos=pos, x=x)).x
+        finally:
+            fused.WGRAD_X3_ACT = keep
         sp = [args for name, args in seen if name == "tp3d_gemm_rows_bnact_sp_f32"]
         assert sp and all(args[11] is not None for args in sp)
+        del seen[:]
+        c = net(Data(pos=pos, x=x)).x
+        sp = [args for name, args in seen if name == "tp3d_gemm_rows_bnact_sp_f32"]
+        h = _lib.load()
+        assert sp and all((args[11] is None) == bool(fused.WGRAD_X3 and fused.WGRAD_X3_ACT and h.tp3d_gemm_tn_x3_serves(args[6], args[7], args[8]))
+                          for args in sp)
+        torch.testing.assert_close(c.detach(), b.detach(), rtol=1e-5, atol=1e-5)
     finally:
         _lib.set_post_call_hook(prev)
     assert fused._outer_grad is True
@@ -901,3 +913,25 @@ def test_gemm_tn_x3_matches_fp64(M, N, K, terms):
     assert torch.equal(torch.isfinite(a), torch.isfinite(b))
     fin = torch.isfinite(b)
     assert float((a[fin].double() - b[fin].double()).abs().max()) <= 1e-5 * float(b[fin].abs().max())
+
+
+@pytest.mark.parametrize("M,N,K", [(131072, 128, 128), (140000, 128, 132), (131072, 128, 64), (150001, 256, 160)])
+def test_gemm_tn_x3_forms_the_activated_operand_bit_exactly(M, N, K):
+    """tp3d_gemm_tn_x3_act_f32: A = LeakyReLU((Yp - mean) * scale + beta) formed by the loader waves == the plain contraction on
+    the rows tp3d_bn_act_f32 writes (the forward kernels' expression and order), so dropping the forward pass's activated side
+    output changes no bit of the weight gradient."""
+    from torch_points3d_amd import _lib, fused
+    g = torch.Generator().manual_seed(M + K)
+    dY = torch.randn(M, N, generator=g).to(DEV)
+    Yp = (torch.randn(M, K, generator=g) * 2 + 0.3).to(DEV)
+    mean, scale, beta = torch.randn(K, generator=g).to(DEV), (torch.rand(K, generator=g) + 0.5).to(DEV), torch.randn(K, generator=g).to(DEV)
+    scale[0] = -0.7
+    slope = 0.01
+    act = torch.empty_like(Yp)
+    _lib.call("tp3d_bn_act_f32", _lib.ptr(Yp), _lib.ptr(mean), _lib.ptr(scale), _lib.ptr(beta), slope, M, K, _lib.ptr(act),
+              _lib.stream_ptr(Yp.device))
+    want = fused.gemm_tn(dY, act, x3=6)
+    got = fused.gemm_tn(dY, Yp, x3=6, act=(mean, scale, beta, slope))
+    assert torch.equal(got, want)
+    ref = torch.mm(dY.double().t(), torch.nn.functional.leaky_relu((Yp.double() - mean.double()) * scale.double() + beta.double(), slope))
+    assert float((got.double() - ref).abs().max()) <= 1e-5 * float(ref.abs().max())

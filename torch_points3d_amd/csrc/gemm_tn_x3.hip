@@ -74,10 +74,20 @@ __device__ __forceinline__ bf16x8 x3_frag(const unsigned short *plane, int pitch
 // WM, WN: 32x32 blocks per MFMA wave along n / k (waves 0-3 form a 2 x 2 grid: tile = 64 WM x 64 WN); STRIP: 32 more k
 // columns beside the tile (WM == 2: one strip block per wave); BR: rows staged per step; TERMS: 9 = all nine term pairs
 // (exact products), 6 = the six of weight >= 2^-16, 1 = the hi * hi pair alone (a diagnostic: loaders unchanged, a ninth of the MFMAs).
+// A-operand prologue: A = LeakyReLU((Yp - mean_k) * scale_k + beta_k), the activated input of the layer formed from the
+// previous layer's pre-BatchNorm output Yp (M, K) and its statistics rows (null mean = plain rows).  The loader waves
+// apply it on their way to the split, in the forward kernel's operation order (the rows they form are bit for bit the
+// activated rows the forward pass would have written), so the forward pass need not write that (M, K) side output at all.
+struct X3Prologue {
+    const float *mean, *scale, *beta;
+    float slope;
+};
+
 template <int WM, int WN, bool STRIP, int BR, int TERMS>
 __global__ __launch_bounds__(X3_BLOCK) void gemm_tn_x3_kernel(const float *__restrict__ dY, const float *__restrict__ A,
                                                               int64_t M, int N, int K, int64_t rows_per_split,
-                                                              int tiles_k, float *__restrict__ partial /*[S][N][K]*/)
+                                                              int tiles_k, float *__restrict__ partial /*[S][N][K]*/,
+                                                              X3Prologue pro)
 {
     static_assert(!STRIP || WM == 2, "the strip is one block per wave of a 128-row tile");
     constexpr int TN = 64 * WM, TK = 64 * WN, TKS = TK + (STRIP ? 32 : 0);
@@ -85,10 +95,21 @@ __global__ __launch_bounds__(X3_BLOCK) void gemm_tn_x3_kernel(const float *__res
     constexpr int PLANE_N = BR * PN, PLANE_K = BR * PK;   // halfwords
     constexpr int BUF = 3 * PLANE_N + 3 * PLANE_K;
     extern __shared__ __attribute__((aligned(16))) unsigned short smem[];
+    __shared__ __attribute__((aligned(16))) float sK[3][TKS];  // mean, scale, beta of the tile's k columns (zero past K)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int tile = blockIdx.x;
     const int n0 = (tile / tiles_k) * TN, k0 = (tile % tiles_k) * TK;
+    const bool prologue = pro.mean != nullptr;
+    if (prologue) {
+        for (int c = tid; c < TKS; c += X3_BLOCK) {
+            const bool in = k0 + c < K;
+            sK[0][c] = in ? pro.mean[k0 + c] : 0.0f;
+            sK[1][c] = in ? pro.scale[k0 + c] : 0.0f;
+            sK[2][c] = in ? pro.beta[k0 + c] : 0.0f;
+        }
+        __syncthreads();  // (before the roles part: every wave passes here once)
+    }
     // Row blocks of BR rows are dealt round-robin to the splits: at any moment the workgroups of a launch read ONE contiguous
     // stretch of both operands (splits x BR rows), which spreads over every HBM channel; contiguous row ranges per split would
     // be 2^k bytes apart (e.g. 2048 rows x 512 B = 1 MiB) and walk the channels in lockstep.
@@ -173,6 +194,17 @@ __global__ __launch_bounds__(X3_BLOCK) void gemm_tn_x3_kernel(const float *__res
             *reinterpret_cast<uint2 *>(dst + plane_len) = m;
             *reinterpret_cast<uint2 *>(dst + 2 * plane_len) = l;
         };
+        // (y - mean) * scale + beta, LeakyReLU -- the expression and order of gemm_rows_sp.hip's forward prologue; a column
+        // past K has mean = scale = beta = 0 and stays zero
+        auto act4 = [&](float4 v, int col) __attribute__((always_inline)) -> float4 {
+            const float4 mu = *reinterpret_cast<const float4 *>(&sK[0][col]);
+            const float4 sc = *reinterpret_cast<const float4 *>(&sK[1][col]);
+            const float4 be = *reinterpret_cast<const float4 *>(&sK[2][col]);
+            const float z0 = (v.x - mu.x) * sc.x + be.x, z1 = (v.y - mu.y) * sc.y + be.y;
+            const float z2 = (v.z - mu.z) * sc.z + be.z, z3 = (v.w - mu.w) * sc.w + be.w;
+            return make_float4(z0 > 0.0f ? z0 : z0 * pro.slope, z1 > 0.0f ? z1 : z1 * pro.slope, z2 > 0.0f ? z2 : z2 * pro.slope,
+                               z3 > 0.0f ? z3 : z3 * pro.slope);
+        };
         auto store = [&](int t, const float4 *ry, const float4 *ra, const float4 *rs) __attribute__((always_inline)) {
             unsigned short *by = smem + (t & 1) * BUF, *ba = by + 3 * PLANE_N;
 #pragma unroll
@@ -183,13 +215,15 @@ __global__ __launch_bounds__(X3_BLOCK) void gemm_tn_x3_kernel(const float *__res
 #pragma unroll
             for (int i = 0; i < SA; ++i) {
                 const int e = lt + i * 256;
-                put(ba, PLANE_K, PK, e / (TK / 4), (e % (TK / 4)) * 4, ra[i]);
+                const int col = (e % (TK / 4)) * 4;
+                put(ba, PLANE_K, PK, e / (TK / 4), col, prologue ? act4(ra[i], col) : ra[i]);
             }
             if (STRIP) {
 #pragma unroll
                 for (int i = 0; i < SS; ++i) {
                     const int e = lt + i * 256;
-                    put(ba, PLANE_K, PK, e / 8, TK + (e % 8) * 4, rs[i]);
+                    const int col = TK + (e % 8) * 4;
+                    put(ba, PLANE_K, PK, e / 8, col, prologue ? act4(rs[i], col) : rs[i]);
                 }
             }
         };
@@ -332,13 +366,14 @@ static X3Plan x3_plan(int64_t M, int N, int K)
 }
 
 template <int WM, int WN, bool STRIP, int BR, int TERMS>
-static void x3_launch(const X3Plan &p, const float *dY, const float *A, int64_t M, int N, int K, float *ws, hipStream_t s)
+static void x3_launch(const X3Plan &p, const float *dY, const float *A, int64_t M, int N, int K, float *ws, X3Prologue pro,
+                      hipStream_t s)
 {
     static bool allowed[64] = {};
     auto kern = gemm_tn_x3_kernel<WM, WN, STRIP, BR, TERMS>;
     allow_large_dynamic_lds(reinterpret_cast<const void *>(kern), p.lds_bytes, allowed);
     hipLaunchKernelGGL(kern, dim3(p.tiles_n * p.tiles_k, p.splits), dim3(X3_BLOCK), p.lds_bytes, s, dY, A, M, N, K,
-                       p.rows_per_split, p.tiles_k, ws);
+                       p.rows_per_split, p.tiles_k, ws, pro);
 }
 
 }  // namespace tp3d
@@ -370,18 +405,18 @@ TP3D_EXPORT int tp3d_gemm_tn_x3_plan(int64_t M, int N, int K, int64_t *plan)
     return TP3D_OK;
 }
 
-TP3D_EXPORT int tp3d_gemm_tn_x3_f32(const float *dY, const float *A, int64_t M, int N, int K, int terms, float *out,
-                                    float *workspace, void *stream)
+static int x3_run(const float *dY, const float *A, int64_t M, int N, int K, int terms, float *out, float *workspace,
+                  X3Prologue pro, void *stream)
 {
     if (!x3_serves(M, N, K) || !dY || !A || !out || !workspace || (terms != 9 && terms != 6 && terms != 1)) return TP3D_E_BADARG;
     hipStream_t s = (hipStream_t)stream;
     const X3Plan p = x3_plan(M, N, K);
     if (p.splits > 65535) return TP3D_E_TOOBIG;
-#define TP3D_X3(WM_, WN_, ST_, BR_)                                                   \
-    do {                                                                              \
-        if (terms == 9) x3_launch<WM_, WN_, ST_, BR_, 9>(p, dY, A, M, N, K, workspace, s);  \
-        else if (terms == 6) x3_launch<WM_, WN_, ST_, BR_, 6>(p, dY, A, M, N, K, workspace, s);   \
-        else x3_launch<WM_, WN_, ST_, BR_, 1>(p, dY, A, M, N, K, workspace, s);   \
+#define TP3D_X3(WM_, WN_, ST_, BR_)                                                                 \
+    do {                                                                                            \
+        if (terms == 9) x3_launch<WM_, WN_, ST_, BR_, 9>(p, dY, A, M, N, K, workspace, pro, s);     \
+        else if (terms == 6) x3_launch<WM_, WN_, ST_, BR_, 6>(p, dY, A, M, N, K, workspace, pro, s); \
+        else x3_launch<WM_, WN_, ST_, BR_, 1>(p, dY, A, M, N, K, workspace, pro, s);                \
     } while (0)
     if (p.wm == 2 && p.wn == 2 && p.strip) TP3D_X3(2, 2, true, 32);
     else if (p.wm == 2 && p.wn == 2) TP3D_X3(2, 2, false, 32);
@@ -391,4 +426,22 @@ TP3D_EXPORT int tp3d_gemm_tn_x3_f32(const float *dY, const float *A, int64_t M, 
 #undef TP3D_X3
     if (int rc = check_launch()) return rc;
     return tn_reduce_splits(workspace, p.splits, (int64_t)N * K, out, s);
+}
+
+TP3D_EXPORT int tp3d_gemm_tn_x3_f32(const float *dY, const float *A, int64_t M, int N, int K, int terms, float *out,
+                                    float *workspace, void *stream)
+{
+    const X3Prologue none = {nullptr, nullptr, nullptr, 1.0f};
+    return x3_run(dY, A, M, N, K, terms, out, workspace, none, stream);
+}
+
+// dW = dY^T * LeakyReLU((Yp - mean_k) * scale_k + beta_k): the A operand formed by the loader waves from the previous
+// layer's pre-BatchNorm output Yp (M, K) and its statistics rows (K floats each) -- see X3Prologue
+TP3D_EXPORT int tp3d_gemm_tn_x3_act_f32(const float *dY, const float *Yp, const float *mean_k, const float *scale_k,
+                                        const float *beta_k, float slope_k, int64_t M, int N, int K, int terms, float *out,
+                                        float *workspace, void *stream)
+{
+    if (!mean_k || !scale_k || !beta_k) return TP3D_E_BADARG;
+    const X3Prologue pro = {mean_k, scale_k, beta_k, slope_k};
+    return x3_run(dY, Yp, M, N, K, terms, out, workspace, pro, stream);
 }

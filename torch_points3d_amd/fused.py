@@ -65,6 +65,8 @@ def mlp_parts(mlp):
     return None if (not parts or any(p is None for p in parts)) else parts
 
 
+WGRAD_X3_ACT = True  # ... and its loader waves form the activated A operand from the previous layer's pre-BatchNorm output,
+                     # so that the forward kernels write no activated side output for those layers (one (M, K) store less)
 WGRAD_X3 = 6  # weight-gradient contractions of the large layers on the bf16 matrix pipe, every fp32 value split exactly into
               # three bf16 terms (csrc/gemm_tn_x3.hip): 6 = the six term pairs of weight >= 2^-15 (what is dropped is below
               # 2^-21 of a product), 9 = all nine (every product exact), 0 = the fp32 MFMA kernel for every shape.
@@ -74,7 +76,17 @@ WGRAD_X3 = 6  # weight-gradient contractions of the large layers on the bf16 mat
               # in the counters), so the nine-term form costs more than its extra MFMAs
 
 
-def gemm_tn(dY, A, x3=None):
+def _chain_wgrad(dY, l, A0, acts, Ys, stats, slopes):
+    """weight gradient of layer l of a fused chain: dY^T @ (activated input of the layer)"""
+    if l == 0:
+        return gemm_tn(dY, A0)
+    if acts[l - 1] is not None:
+        return gemm_tn(dY, acts[l - 1])
+    ps = stats[l - 1]  # the forward pass kept no activated rows: the contraction's loader waves form them from Y_{l-1}
+    return gemm_tn(dY, Ys[l - 1], act=(ps[0], ps[2], ps[3], slopes[l - 1]))
+
+
+def gemm_tn(dY, A, x3=None, act=None):
     """dY (M,N), A (M,K) -> dY^T @ A (N,K), split over the rows, partial tiles summed in fixed order (reproducible):
     csrc/gemm_tn_x3.hip for the shapes it serves (x3 terms, default WGRAD_X3), else the fp32 MFMA kernel csrc/gemm_tn.hip."""
     dev = dY.device
@@ -84,6 +96,15 @@ def gemm_tn(dY, A, x3=None):
     out = torch.empty((N, K), dtype=torch.float32, device=dev)
     terms = WGRAD_X3 if x3 is None else x3
     use_x3 = bool(terms) and M > 0 and bool(_lib.load().tp3d_gemm_tn_x3_serves(M, N, K))
+    if act is not None:
+        # A = LeakyReLU((Yp - mean) * scale + beta) formed by the contraction's loader waves (act = mean, scale, beta, slope)
+        if not use_x3:
+            raise ValueError("gemm_tn(act=): only the bf16-pipe contraction forms its A operand (shape %s x %s x %s)" % (M, N, K))
+        ws = _lib.gemm_tn_workspace(M, N, K, dev, x3=True)
+        with _lib.on_device(dev):
+            _lib.call("tp3d_gemm_tn_x3_act_f32", _lib.ptr(dY), _lib.ptr(A), _lib.ptr(act[0]), _lib.ptr(act[1]), _lib.ptr(act[2]),
+                      float(act[3]), M, N, K, int(terms), _lib.ptr(out), _lib.ptr(ws), _lib.stream_ptr(dev))
+        return out
     ws = _lib.gemm_tn_workspace(M, N, K, dev, x3=use_x3)
     with _lib.on_device(dev):
         if use_x3:
@@ -399,7 +420,11 @@ class _MLPChain(torch.autograd.Function):
                     W2 = torch.nn.functional.pad(W2, (0, Kp - W2.shape[1]))
                 W2 = W2.contiguous()
                 Y = torch.empty((M, Cout), dtype=torch.float32, device=dev)
-                sp_chunks = h.tp3d_gemm_rows_sp_chunks(M, Cout, Kp, int(keep_acts)) if (l > 0 and CHAIN_LOADER) else 0
+                # the activated rows are the A operand of this layer's weight gradient; where the bf16-pipe contraction serves
+                # that shape its loader waves form them again from Y_{l-1} (tp3d_gemm_tn_x3_act_f32) and nothing is kept
+                keep_act = keep_acts and not (WGRAD_X3 and WGRAD_X3_ACT and l > 0 and ctx.needs_input_grad[4 + 3 * l]
+                                              and h.tp3d_gemm_tn_x3_serves(M, Cout, Kp))
+                sp_chunks = h.tp3d_gemm_rows_sp_chunks(M, Cout, Kp, int(keep_act)) if (l > 0 and CHAIN_LOADER) else 0
                 sp_entry = "tp3d_gemm_rows_bnact_sp_f32"
                 chunks = None
                 if l == 0:
@@ -410,7 +435,7 @@ class _MLPChain(torch.autograd.Function):
                     # backward pass to come, the activated rows leave as a side output of the same kernel
                     ps = stats[-1]
                     part = _lib.workspace("gemm_rows_stats", 16 * sp_chunks * Cout, dev) if training else None
-                    act = torch.empty((M, Kp), dtype=torch.float32, device=dev) if keep_acts else None
+                    act = torch.empty((M, Kp), dtype=torch.float32, device=dev) if keep_act else None
                     _lib.call(sp_entry, _lib.ptr(Ys[-1]), _lib.ptr(ps[0]), _lib.ptr(ps[2]), _lib.ptr(ps[3]),
                               layers[l - 1][1], _lib.ptr(W2), M, Cout, Kp, _lib.ptr(Y), _lib.ptr(part), _lib.ptr(act), st)
                     chunks = sp_chunks
@@ -423,7 +448,7 @@ class _MLPChain(torch.autograd.Function):
                               Kp, _lib.ptr(act), st)
                     part = _lib.workspace("gemm_rows_stats", 4 * h.tp3d_gemm_rows_stat_floats(M, Cout), dev) if training else None
                     _lib.call("tp3d_gemm_rows_f32", _lib.ptr(act), _lib.ptr(W2), M, Cout, Kp, _lib.ptr(Y), _lib.ptr(part), None, st)
-                    acts.append(act if keep_acts else None)
+                    acts.append(act if keep_act else None)
                 else:
                     ps = stats[-1]
                     part = _lib.workspace("gemm_rows_stats", 4 * h.tp3d_gemm_rows_stat_floats(M, Cout), dev) if training else None
@@ -507,7 +532,7 @@ class _MLPChain(torch.autograd.Function):
                                   _lib.ptr(dprev) + 4 * c0, Kp, pad_lo_k, pad_hi_k,
                                   _lib.ptr(dY) if ctx.needs_input_grad[4 + 3 * l] else None, a_ptr, ns, st)
                         if ctx.needs_input_grad[4 + 3 * l]:
-                            grads[3 * l] = gemm_tn(dY, A0 if l == 0 else acts[l - 1])[:, :cins[l]].reshape(wshapes[l])
+                            grads[3 * l] = _chain_wgrad(dY, l, A0, acts, Ys, stats, slopes)[:, :cins[l]].reshape(wshapes[l])
                         dcur = dprev
                         if l == 0:
                             dA0 = dprev
@@ -518,7 +543,7 @@ class _MLPChain(torch.autograd.Function):
                               int(training), _lib.ptr(dgb[0]), _lib.ptr(dgb[1]), _lib.ptr(dY), _lib.ptr(ws), st)
                     grads[3 * l + 1], grads[3 * l + 2] = dgb[1], dgb[0]
                     if ctx.needs_input_grad[4 + 3 * l]:
-                        grads[3 * l] = gemm_tn(dY, A0 if l == 0 else acts[l - 1])[:, :cins[l]].reshape(wshapes[l])
+                        grads[3 * l] = _chain_wgrad(dY, l, A0, acts, Ys, stats, slopes)[:, :cins[l]].reshape(wshapes[l])
                     if l > 0 or ctx.needs_input_grad[0]:
                         dcur = torch.mm(dY, W2)
                         if l == 0:
