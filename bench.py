@@ -448,7 +448,8 @@ def cpu_forward_baseline(sample_b, iters):
 
 def shape_key(entry, sizes):
     """key of profiles/pmc_north_star.json: one counter row per (entry point, launch shape)"""
-    return "%s|%s" % (entry, ",".join(str(int(v)) for v in list(sizes)[:4]))
+    n = {"tp3d_fps_f32": 3, "tp3d_three_nn_f32": 3}.get(entry, 4)  # the size arguments that define the launch shape
+    return "%s|%s" % (entry, ",".join(str(int(v)) for v in list(sizes)[:n]))
 
 
 def north_star_kernels(summ):
