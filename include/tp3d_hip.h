@@ -257,7 +257,8 @@ int tp3d_gemm_tn_f32(const float *dY, const float *A, int64_t M, int N, int K, f
  * split exactly into three bf16 terms (3 x 8 significand bits) by the loader waves of a split-role kernel, and the product
  * is the sum of the term pairs -- terms = 9: all nine, every product exact as in the fp32 MFMA; terms = 6: the six of
  * weight >= 2^-16 -- each a v_mfma_f32_32x32x16_bf16 with fp32 accumulation.  The contraction then runs at the rate HBM
- * delivers the rows instead of at the fp32 MFMA rate.  Serves M >= 131072, N >= 64, K >= 64 (not both 64), N % 4 == 0, K % 4 == 0, M * max(N, K) < 2^30
+ * delivers the rows instead of at the fp32 MFMA rate.  Serves M >= 131072, N >= 64, K >= 64 (not both 64), N % 4 == 0, K % 4 == 0, M * max(N, K) < 2^30, and an output that
+ * fills at least 80 % of at most two tiles (128- or 64-wide, or 128 + a 32-column strip)
  * (tp3d_gemm_tn_x3_serves); other shapes: tp3d_gemm_tn_f32.  workspace: tp3d_gemm_tn_x3_workspace_floats floats.
  * Reference: the weight gradient of Conv2d 1x1 in MLP2D (core/common_modules/dense_modules.py:5-12), autograd's
  * grad_output^T @ input. */

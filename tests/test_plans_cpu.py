@@ -49,23 +49,28 @@ def test_gemm_tn_x3_plan_fits_its_workspace_and_lds():
     for M in ROWS:
         for N, K in itertools.product(CHANNELS, CHANNELS):
             ok = h.tp3d_gemm_tn_x3_serves(M, N, K)
-            want = M >= 131072 and N >= 64 and K >= 64 and (N > 64 or K > 64) and N % 4 == 0 and K % 4 == 0 and \
+            base = M >= 131072 and N >= 64 and K >= 64 and (N > 64 or K > 64) and N % 4 == 0 and K % 4 == 0 and \
                 M * max(N, K) < 2 ** 30
-            assert bool(ok) == want, (M, N, K)
+            assert not ok or base, (M, N, K)
             if not ok:
                 assert h.tp3d_gemm_tn_x3_workspace_floats(M, N, K) == 0
                 continue
             served += 1
             splits, rps, tn, tk, tiles, staged, floats, lds = _plan("tp3d_gemm_tn_x3_plan", 8, M, N, K)
             assert floats == splits * N * K == h.tp3d_gemm_tn_x3_workspace_floats(M, N, K), (M, N, K)
-            assert 1 <= splits <= 256 and splits * tiles <= 512, (M, N, K, splits, tiles)
+            assert 1 <= splits <= 256 and tiles <= 2 and splits * tiles <= 256, (M, N, K, splits, tiles)
+            assert N * K * 5 >= tiles * tn * tk * 4, (M, N, K, tn, tk)  # at least 80 % of the tiles is output
             assert rps % staged == 0 and splits * rps >= M and (splits - 1) * rps < M, (M, N, K, splits, rps)
             assert lds <= 160 * 1024 and staged in (32, 64), (M, N, K, lds)
             assert tn in (64, 128) and tk in (64, 128, 160) and tiles * tn * tk >= N * K, (M, N, K, tn, tk, tiles)
             if 128 < K <= 160 and N > 64:
                 assert tk == 160 and tiles == -(-N // 128)  # the strip: dY is read once, not once per tile column
             assert M * max(N, K) * 4 < 2 ** 32  # loader lanes address a row block with 32-bit byte offsets
-    assert served > 200
+    for shape in ((524288, 128, 128), (524288, 128, 132), (1048576, 128, 64), (262144, 256, 128)):  # the BASELINE step's layers
+        assert h.tp3d_gemm_tn_x3_serves(*shape), shape
+    for shape in ((524288, 256, 196), (2097152, 128, 96), (524288, 128, 324), (1048576, 64, 64), (40000, 128, 128)):
+        assert not h.tp3d_gemm_tn_x3_serves(*shape), shape
+    assert served > 100
 
 
 def test_gemm_rows_plan_fits_its_statistics_buffer():

@@ -328,12 +328,23 @@ struct X3Plan {
     int64_t rows_per_split;
 };
 
+static X3Plan x3_plan(int64_t M, int N, int K);
+
 static bool x3_serves(int64_t M, int N, int K)
 {
-    // (64 x 64 outputs stay on the fp32 kernel: it already runs at the rate HBM delivers those rows)
-    // (measured: below ~10^5 rows one workgroup per CU has too few steps to hide its prologue; 40000 x 128 x 160: 65 vs 42 us)
-    return M >= 131072 && N >= 64 && K >= 64 && (N > 64 || K > 64) && (N & 3) == 0 && (K & 3) == 0 &&
-           M * (int64_t)(N > K ? N : K) < ((int64_t)1 << 30);
+    // (64 x 64 outputs stay on the fp32 kernel: it already runs at the rate HBM delivers those rows; below ~10^5 rows one
+    //  workgroup per CU has too few steps to hide its prologue -- 40000 x 128 x 160: 65 vs 42 us)
+    if (!(M >= 131072 && N >= 64 && K >= 64 && (N > 64 || K > 64) && (N & 3) == 0 && (K & 3) == 0 &&
+          M * (int64_t)(N > K ? N : K) < ((int64_t)1 << 30)))
+        return false;
+    // every tile column re-reads dY and every tile row re-reads A, and a padded tile splits and multiplies zeros: the
+    // kernel pays off while the output fills at least 80 % of at most two tiles (measured on BASELINE config 3:
+    // 524288 x 256 x 196 -- four tiles -- 743 vs 606 us, 2097152 x 128 x 96 -- 75 % of a tile -- 793 vs 588 us on the fp32
+    // kernel; 262144 x 256 x 128 -- two full tiles -- 156 vs 193 us)
+    const X3Plan p = x3_plan(M, N, K);
+    const int tiles = p.tiles_n * p.tiles_k;
+    const int64_t padded = (int64_t)p.tiles_n * 64 * p.wm * ((int64_t)p.tiles_k * 64 * p.wn + (p.strip ? 32 : 0));
+    return tiles <= 2 && (int64_t)N * K * 5 >= padded * 4;
 }
 
 static X3Plan x3_plan(int64_t M, int N, int K)
