@@ -165,7 +165,7 @@ def algorithmic_bytes(name, a):
     if name in ("tp3d_gemm_tn_f32", "tp3d_gemm_tn_x3_f32", "tp3d_gemm_tn_x3_act_f32", "tp3d_gemm_rows_f32", "tp3d_gemm_rows_bnact_f32"):  # M, N, K
         M, N, K = a[:3]
         return (M * (N + K) + N * K) * 4
-    if name == "tp3d_gemm_rows_bnact_sp_f32":  # M, N, K (the side output of the training launches, M * K more, not counted)
+    if name in ("tp3d_gemm_rows_bnact_sp_f32", "tp3d_gemm_rows_bnact_x3_f32"):  # M, N, K (the side output of the training launches, M * K more, not counted)
         M, N, K = a[:3]
         return (M * (N + K) + N * K) * 4
     if name == "tp3d_gemm_rows_bnbwd_sp_f32":  # M, N, K, ldc, pad_lo, pad_hi, ns: Y and dA (dense, or pooled + winners) in, dY and C out
@@ -225,7 +225,7 @@ def algorithmic_flops(name, a):
     if name in ("tp3d_gemm_rows_bnbwd_f32", "tp3d_gemm_tn_bn_f32"):  # ns, M, N, K
         ns, M, N, K = a[:4]
         return 2 * M * N * K
-    if name in ("tp3d_gemm_rows_bnact_sp_f32", "tp3d_gemm_rows_bnbwd_sp_f32"):  # M, N, K
+    if name in ("tp3d_gemm_rows_bnact_sp_f32", "tp3d_gemm_rows_bnact_x3_f32", "tp3d_gemm_rows_bnbwd_sp_f32"):  # M, N, K
         M, N, K = a[:3]
         return 2 * M * N * K
     return 0

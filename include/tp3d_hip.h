@@ -35,7 +35,7 @@ extern "C" {
 #define TP3D_E_UNSORTED (-3) /* reserved: batch vector not sorted (checked by the host wrapper) */
 #define TP3D_E_TOOBIG (-4)   /* size exceeds what the kernel's index arithmetic supports */
 
-#define TP3D_ABI_VERSION 28
+#define TP3D_ABI_VERSION 29
 
 int tp3d_abi_version(void);
 const char *tp3d_strerror(int code);
@@ -219,6 +219,15 @@ int tp3d_gemm_rows_sp_chunks(int64_t M, int N, int K, int with_act_out);
 int tp3d_gemm_rows_bnact_sp_f32(const float *Y, const float *mean, const float *scale, const float *beta, float slope,
                                 const float *Bt, int64_t M, int N, int K, float *C, float *stat_partial, float *act_out,
                                 void *stream);
+/* tp3d_gemm_rows_bnact_sp_f32 with the fp32 contraction carried by the bf16 matrix pipe (csrc/gemm_rows_x3.hip): every operand
+ * value split exactly into three bf16 terms by the loader waves (x3_split.h), the product as the six term pairs of weight
+ * >= 2^-15, each a v_mfma_f32_32x32x16_bf16 with fp32 accumulation.  Same arguments, outputs and statistics layout;
+ * tp3d_gemm_rows_x3_chunks is its chunk count / shape rule (0: not served -- more than 64 output columns, K <= 512). */
+int tp3d_gemm_rows_x3_chunks(int64_t M, int N, int K, int with_act_out);
+int tp3d_gemm_rows_bnact_x3_f32(const float *Y, const float *mean, const float *scale, const float *beta, float slope,
+                                const float *Bt, int64_t M, int N, int K, float *C, float *stat_partial, float *act_out,
+                                void *stream);
+
 /* Input-gradient GEMM of a layer on the split-role kernel, with the layer's BatchNorm + activation BACKWARD formed by the
  * loader waves:  C[M,N] = dY[M,K] * Bt[N,K]^T,  dY = scale*((dA*act'(z) - c1) - (Y - mean)*c2),  z = (Y - mean)*scale + beta.
  * Y (M,K) pre-BatchNorm output of the layer, dA (M,K) gradient of its activated output -- or, with argmax != NULL, the

@@ -21,6 +21,7 @@
 // Reference semantics: weight gradient of Conv2d 1x1 (bias=False) inside MLP2D
 // (torch_points3d/core/common_modules/dense_modules.py:5-12,25-29) -- autograd's `grad_output^T @ input` in the reference.
 #include "tp3d_common.h"
+#include "x3_split.h"
 
 namespace tp3d {
 
@@ -32,29 +33,6 @@ typedef short s16x8 __attribute__((ext_vector_type(8)));
 constexpr int X3_BLOCK = 512;
 
 __host__ __device__ constexpr int x3_pitch(int cols) { return cols % 64 == 0 ? cols + 32 : cols; }
-
-// x = hi + mid + lo exactly (truncating split); four values -> four halfwords per plane (v_perm_b32 packs the upper
-// halves of two dwords).  Non-finite values need no special case: for x = +-inf or NaN, x - hi is NaN, so mid and lo are NaN
-// and every output that involves x becomes NaN -- the outputs the fp32 product makes non-finite as well (inf * b or NaN * b
-// is never finite); the finite / non-finite pattern of the result is that of the fp32 kernel, an infinity may read NaN.
-// Truncation never rounds up, so values next to FLT_MAX do not overflow in the split.
-__device__ __forceinline__ void x3_split(float4 v, uint2 &hi, uint2 &mid, uint2 &lo)
-{
-    const float x[4] = {v.x, v.y, v.z, v.w};
-    unsigned r1[4], r2[4];
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        const float a = x[c] - __uint_as_float(__float_as_uint(x[c]) & 0xffff0000u);
-        const float b = a - __uint_as_float(__float_as_uint(a) & 0xffff0000u);  // at most 8 significant bits left
-        r1[c] = __float_as_uint(a);
-        r2[c] = __float_as_uint(b);
-    }
-    constexpr unsigned UP = 0x07060302u;  // bytes 2,3 of the second source, then bytes 2,3 of the first
-    hi = make_uint2(__builtin_amdgcn_perm(__float_as_uint(x[1]), __float_as_uint(x[0]), UP),
-                    __builtin_amdgcn_perm(__float_as_uint(x[3]), __float_as_uint(x[2]), UP));
-    mid = make_uint2(__builtin_amdgcn_perm(r1[1], r1[0], UP), __builtin_amdgcn_perm(r1[3], r1[2], UP));
-    lo = make_uint2(__builtin_amdgcn_perm(r2[1], r2[0], UP), __builtin_amdgcn_perm(r2[3], r2[2], UP));
-}
 
 // MFMA operand fragment of the 32x32x16 block whose 16 contraction rows start at `row0` and whose 32 output rows /
 // columns are the plane columns col0 .. col0+31:  lane l (r = l & 31, h = l >> 5) gets plane[row0 + 8h + j][col0 + r],

@@ -65,6 +65,8 @@ def mlp_parts(mlp):
     return None if (not parts or any(p is None for p in parts)) else parts
 
 
+FWD_X3 = True  # forward contractions of the hidden layers (more than 64 output columns) on the bf16 matrix pipe as well
+               # (csrc/gemm_rows_x3.hip: exact three-term split, six term pairs, fp32 accumulation)
 WGRAD_X3_ACT = True  # ... and its loader waves form the activated A operand from the previous layer's pre-BatchNorm output,
                      # so that the forward kernels write no activated side output for those layers (one (M, K) store less)
 WGRAD_X3 = 6  # weight-gradient contractions of the large layers on the bf16 matrix pipe, every fp32 value split exactly into
@@ -426,6 +428,9 @@ class _MLPChain(torch.autograd.Function):
                                               and h.tp3d_gemm_tn_x3_serves(M, Cout, Kp))
                 sp_chunks = h.tp3d_gemm_rows_sp_chunks(M, Cout, Kp, int(keep_act)) if (l > 0 and CHAIN_LOADER) else 0
                 sp_entry = "tp3d_gemm_rows_bnact_sp_f32"
+                if sp_chunks and FWD_X3 and h.tp3d_gemm_rows_x3_chunks(M, Cout, Kp, int(keep_act)):
+                    sp_chunks = h.tp3d_gemm_rows_x3_chunks(M, Cout, Kp, int(keep_act))
+                    sp_entry = "tp3d_gemm_rows_bnact_x3_f32"  # the same contraction as bf16 term pairs on the matrix pipe
                 chunks = None
                 if l == 0:
                     part = _lib.workspace("gemm_rows_stats", 4 * h.tp3d_gemm_rows_stat_floats(M, Cout), dev) if training else None
