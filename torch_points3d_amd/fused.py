@@ -78,6 +78,18 @@ WGRAD_X3 = 6  # weight-gradient contractions of the large layers on the bf16 mat
               # in the counters), so the nine-term form costs more than its extra MFMAs
 
 
+_ident = {}
+
+
+def _identity_stats(K, dev):
+    """(zeros, ones) rows of K floats: the statistics under which a BatchNorm + LeakyReLU(1) prologue is the identity"""
+    key = (dev.index, K)
+    hit = _ident.get(key)
+    if hit is None:
+        hit = _ident[key] = (torch.zeros(K, dtype=torch.float32, device=dev), torch.ones(K, dtype=torch.float32, device=dev))
+    return hit
+
+
 def _chain_wgrad(dY, l, A0, acts, Ys, stats, slopes):
     """weight gradient of layer l of a fused chain: dY^T @ (activated input of the layer)"""
     if l == 0:
@@ -432,7 +444,16 @@ class _MLPChain(torch.autograd.Function):
                     sp_chunks = h.tp3d_gemm_rows_x3_chunks(M, Cout, Kp, int(keep_act))
                     sp_entry = "tp3d_gemm_rows_bnact_x3_f32"  # the same contraction as bf16 term pairs on the matrix pipe
                 chunks = None
-                if l == 0:
+                x3_first = h.tp3d_gemm_rows_x3_chunks(M, Cout, Kp, 0) if (l == 0 and FWD_X3 and CHAIN_LOADER) else 0
+                if x3_first:
+                    # the first layer on the bf16 pipe as well: the same kernel with the identity as its prologue
+                    # ((y - 0) * 1 + 0, slope 1) -- 524288 x 128 x 132: 229 us on the fp32 rows kernel
+                    ident = _identity_stats(Kp, dev)
+                    part = _lib.workspace("gemm_rows_stats", 16 * x3_first * Cout, dev) if training else None
+                    _lib.call("tp3d_gemm_rows_bnact_x3_f32", _lib.ptr(A0), _lib.ptr(ident[0]), _lib.ptr(ident[1]), _lib.ptr(ident[0]),
+                              1.0, _lib.ptr(W2), M, Cout, Kp, _lib.ptr(Y), _lib.ptr(part), None, st)
+                    chunks = x3_first
+                elif l == 0:
                     part = _lib.workspace("gemm_rows_stats", 4 * h.tp3d_gemm_rows_stat_floats(M, Cout), dev) if training else None
                     _lib.call("tp3d_gemm_rows_f32", _lib.ptr(A0), _lib.ptr(W2), M, Cout, Kp, _lib.ptr(Y), _lib.ptr(part), None, st)
                 elif sp_chunks:
