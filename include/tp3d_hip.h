@@ -35,7 +35,7 @@ extern "C" {
 #define TP3D_E_UNSORTED (-3) /* reserved: batch vector not sorted (checked by the host wrapper) */
 #define TP3D_E_TOOBIG (-4)   /* size exceeds what the kernel's index arithmetic supports */
 
-#define TP3D_ABI_VERSION 29
+#define TP3D_ABI_VERSION 30
 
 int tp3d_abi_version(void);
 const char *tp3d_strerror(int code);
@@ -254,6 +254,18 @@ int tp3d_gemm_rows_bnbwd_f32(const float *Y, const float *dA, const int *argmax,
 int tp3d_bn_finalize_f32(float *partial, int chunks, int64_t M, int C, float eps, float momentum, const float *gamma,
                          const float *beta, float *running_mean, float *running_var, int64_t *num_batches_tracked,
                          float *mean, float *invstd, float *scale, float *shift, void *stream);
+
+/* Weight gradient of the FIRST layer of a shared MLP on grouped rows (K <= 16 input channels, K % 4 == 0) with dY formed
+ * on the fly:  out[n,k] = sum_r dY[r,n] * A[r,k],  dY = BatchNorm + LeakyReLU backward of (Y, dA) as in
+ * tp3d_gemm_rows_bnbwd_sp_f32 (c1_n / c2_n from tp3d_bn_bwd_reduce_f32).  Y, dA (M,N), A (M,K) -> out (N,K).
+ * One streaming pass over Y and dA (2*M*N*K flops against 8*M*N bytes: HBM-bound); fixed summation order.
+ * workspace: tp3d_gemm_tn_bn_narrow_workspace_floats(M, N, K) floats.
+ * Autograd of Conv2d -> BatchNorm2d -> LeakyReLU (core/common_modules/dense_modules.py:25-29). */
+int tp3d_gemm_tn_bn_narrow_serves(int64_t M, int N, int K);
+size_t tp3d_gemm_tn_bn_narrow_workspace_floats(int64_t M, int N, int K);
+int tp3d_gemm_tn_bn_narrow_f32(const float *Y, const float *dA, const float *mean_n, const float *scale_n,
+                               const float *beta_n, const float *c1_n, const float *c2_n, float slope_n, const float *A,
+                               int64_t M, int N, int K, float *out, float *workspace, void *stream);
 
 /* Weight gradient of a 1x1 conv / shared-MLP layer:  out[n,k] = sum_r dY[r,n] * A[r,k]
  * dY (M,N), A (M,K) row-major -> out (N,K); rows split over the grid, fp32 MFMA, fixed-order reduction of the

@@ -661,6 +661,54 @@ def test_split_role_input_gradient_gemm_forms_dy_in_its_loaders(M, N, K):
     assert h.tp3d_gemm_rows_bnbwd_sp_serves(M, N, 260) == 0 and h.tp3d_gemm_rows_bnbwd_sp_serves(4096, N, K) == 0
 
 
+@pytest.mark.parametrize("M,N,K", [(1048576, 64, 8), (70001, 64, 8), (33000, 128, 16), (40000, 16, 4), (300, 64, 12), (5000, 256, 8), (777, 4, 4)])
+def test_narrow_first_layer_weight_gradient_from_y_and_da(M, N, K):
+    """tp3d_gemm_tn_bn_narrow_f32: dW = dY^T A with dY formed from (Y, dA), against float64 and against the two-pass route
+    (tp3d_bn_act_bwd_f32 + tp3d_gemm_tn_f32); repeated launches bit-identical (fixed summation order)."""
+    from torch_points3d_amd import _lib
+    h = _lib.load()
+    assert h.tp3d_gemm_tn_bn_narrow_serves(M, N, K) == 1 and h.tp3d_gemm_tn_bn_narrow_serves(M, N, 20) == 0
+    assert h.tp3d_gemm_tn_bn_narrow_serves(M, N, 6) == 0 and h.tp3d_gemm_tn_bn_narrow_serves(M, 72, K) == 0
+    g = torch.Generator().manual_seed(M + N + K)
+    Y = (torch.randn(M, N, generator=g) * 1.5 + 0.2).to(DEV)
+    dA = torch.randn(M, N, generator=g).to(DEV)
+    A = torch.randn(M, K, generator=g).to(DEV)
+    gamma, beta = (torch.rand(N, generator=g) + 0.5).to(DEV), (torch.randn(N, generator=g) * 0.3).to(DEV)
+    mean = Y.mean(0)
+    invstd = 1.0 / torch.sqrt(Y.var(0, unbiased=False) + 1e-5)
+    scale = gamma * invstd
+    st = _lib.stream_ptr(Y.device)
+    red = torch.empty(4, N, device=DEV)
+    ws = _lib.bn_workspace(M, N, Y.device)
+    _lib.call("tp3d_bn_bwd_reduce_f32", _lib.ptr(dA), None, _lib.ptr(Y), _lib.ptr(scale), _lib.ptr(beta), _lib.ptr(mean),
+              _lib.ptr(invstd), 0.01, M, 1, N, 1, _lib.ptr(red[0]), _lib.ptr(red[1]), _lib.ptr(red[2]), _lib.ptr(red[3]), _lib.ptr(ws), st)
+    nws = torch.empty(h.tp3d_gemm_tn_bn_narrow_workspace_floats(M, N, K), device=DEV)
+    outs = []
+    for _ in range(2):
+        dW = torch.full((N, K), float("nan"), device=DEV)
+        _lib.call("tp3d_gemm_tn_bn_narrow_f32", _lib.ptr(Y), _lib.ptr(dA), _lib.ptr(mean), _lib.ptr(scale), _lib.ptr(beta),
+                  _lib.ptr(red[2]), _lib.ptr(red[3]), 0.01, _lib.ptr(A), M, N, K, _lib.ptr(dW), _lib.ptr(nws), st)
+        outs.append(dW)
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0], outs[1])
+    yc = Y.double() - mean.double()
+    dz = dA.double() * torch.where(yc * scale.double() + beta.double() > 0, 1.0, 0.01)
+    dY64 = scale.double() * ((dz - red[2].double()) - yc * red[3].double())
+    want = dY64.t() @ A.double()
+    mag = dY64.abs().t() @ A.double().abs()
+    assert float(((outs[0].double() - want).abs() / mag).max()) < 1e-6
+    # the two-pass route of the layer-wise backward
+    dY = torch.empty_like(Y)
+    dgb = torch.empty(2, N, device=DEV)
+    _lib.call("tp3d_bn_act_bwd_f32", _lib.ptr(dA), None, _lib.ptr(Y), _lib.ptr(scale), _lib.ptr(beta), _lib.ptr(mean), _lib.ptr(invstd),
+              0.01, M, 1, N, 1, _lib.ptr(dgb[0]), _lib.ptr(dgb[1]), _lib.ptr(dY), _lib.ptr(ws), st)
+    two = torch.empty(N, K, device=DEV)
+    tws = _lib.gemm_tn_workspace(M, N, K, Y.device)
+    _lib.call("tp3d_gemm_tn_f32", _lib.ptr(dY), _lib.ptr(A), M, N, K, _lib.ptr(two), _lib.ptr(tws), st)
+    assert float(((two.double() - want).abs() / mag).max()) < 1e-6
+    assert float(((outs[0] - two).abs().double() / mag).max()) < 1e-6
+
+
 def test_chain_contracts_only_the_feature_columns_of_grouped_rows():
     """Grouped rows are [relative position (3), features (C), padding]; their producer reads the gradient of the feature
     columns only, and the chain's first input-gradient GEMM computes just those (the rest stays zero): the gradient that

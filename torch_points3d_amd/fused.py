@@ -563,6 +563,22 @@ class _MLPChain(torch.autograd.Function):
                         if l == 0:
                             dA0 = dprev
                         continue
+                    if (WGRAD_NARROW and not pooled and not want_prev and ctx.needs_input_grad[4 + 3 * l] and l == 0
+                            and _lib.load().tp3d_gemm_tn_bn_narrow_serves(M, C, Kp)):
+                        # the first layer of grouped rows (a handful of input channels, nobody reads their gradient): the
+                        # reduction pass, then dW straight from (Y, dA, A0) -- dY is never written
+                        red = torch.empty((4, C), dtype=torch.float32, device=dev)  # dbeta, dgamma, c1, c2
+                        _lib.call("tp3d_bn_bwd_reduce_f32", _lib.ptr(dcur), None, _lib.ptr(Y), _lib.ptr(ls[2]), _lib.ptr(ls[3]),
+                                  _lib.ptr(ls[0]), _lib.ptr(ls[1]), slope, M, 1, C, int(training), _lib.ptr(red[0]),
+                                  _lib.ptr(red[1]), _lib.ptr(red[2]), _lib.ptr(red[3]), _lib.ptr(ws), st)
+                        grads[3 * l + 1], grads[3 * l + 2] = red[1], red[0]
+                        dW = torch.empty((C, Kp), dtype=torch.float32, device=dev)
+                        nws = _lib.workspace("gemm_tn_narrow", 4 * _lib.load().tp3d_gemm_tn_bn_narrow_workspace_floats(M, C, Kp), dev)
+                        _lib.call("tp3d_gemm_tn_bn_narrow_f32", _lib.ptr(Y), _lib.ptr(dcur), _lib.ptr(ls[0]), _lib.ptr(ls[2]),
+                                  _lib.ptr(ls[3]), _lib.ptr(red[2]), _lib.ptr(red[3]), slope, _lib.ptr(A0), M, C, Kp, _lib.ptr(dW),
+                                  _lib.ptr(nws), st)
+                        grads[3 * l] = dW[:, :cins[l]].reshape(wshapes[l])
+                        continue
                     dgb = torch.empty((2, C), dtype=torch.float32, device=dev)  # dbeta, dgamma
                     _lib.call("tp3d_bn_act_bwd_f32", _lib.ptr(dcur), _lib.ptr(arg) if pooled else None, _lib.ptr(Y), _lib.ptr(ls[2]),
                               _lib.ptr(ls[3]), _lib.ptr(ls[0]), _lib.ptr(ls[1]), slope, M, pool_ns if pooled else 1, C,
@@ -623,6 +639,8 @@ def _chain_ok(rows, parts):
 
 
 CHAIN_BWD_POOLED = True  # ... also for the max-pooled last layer of a set-abstraction MLP (groups of 64, 128 ... rows)
+WGRAD_NARROW = True  # first layer of grouped rows (<= 16 input channels, no input gradient wanted): dW from (Y, dA, A0) in one
+                     # streaming kernel (tp3d_gemm_tn_bn_narrow_f32) instead of the dY pass + the 64-column MFMA tile kernel
 CHAIN_BWD_LOADER = True  # the chain's input-gradient GEMMs form dY in their loader waves (else: apply pass + library GEMM)
 CHAIN_LOADER = True    # hidden layers' BatchNorm + activation in the loader waves of the split-role GEMM, activated rows as
                        # its side output, layer-wise backward (else: the prologue / backward-fused variants in the MFMA waves)
