@@ -35,7 +35,7 @@ extern "C" {
 #define TP3D_E_UNSORTED (-3) /* reserved: batch vector not sorted (checked by the host wrapper) */
 #define TP3D_E_TOOBIG (-4)   /* size exceeds what the kernel's index arithmetic supports */
 
-#define TP3D_ABI_VERSION 30
+#define TP3D_ABI_VERSION 31
 
 int tp3d_abi_version(void);
 const char *tp3d_strerror(int code);
@@ -181,13 +181,20 @@ int tp3d_bn_act_bwd_f32(const float *dA, const int *argmax, const float *Y, cons
  * (both zero with training == 0).  Same arguments and workspace as tp3d_bn_act_bwd_f32, no dY. */
 int tp3d_bn_bwd_reduce_f32(const float *dA, const int *argmax, const float *Y, const float *scale, const float *shift,
                            const float *mean, const float *invstd, float slope, int64_t M, int ns, int C, int training,
-                           float *dbeta, float *dgamma, float *c1, float *c2, float *workspace, void *stream);
+                           float *dbeta, float *dgamma, float *c1, float *c2, float *workspace, int reverse,
+                           void *stream);
 
 /* out[(b,i), :] = [ (w0*f0 + w1*f1) + w2*f2 , skip_cl[b,i,0:C2], 0.. ],  f_t = feat_cl[b, idx[b,i,t], 0:C1]
  * feat_cl (B,m,C1), idx/weight (B,n,3), skip_cl (B,n,C2) or NULL -> out (B*n, ld), ld >= C1+C2 (zero padded). */
 int tp3d_interp_concat_fwd_f32(const float *feat_cl, const int64_t *idx, const float *weight, const float *skip_cl,
                                int B, int m, int n, int C1, int C2, int ld, float *out, void *stream);
 
+/* `reverse` (tp3d_gemm_rows_bnact_sp_f32, tp3d_gemm_rows_bnact_x3_f32, tp3d_gemm_rows_bnbwd_sp_f32, tp3d_gemm_tn_x3_f32,
+ * tp3d_gemm_tn_x3_act_f32, tp3d_bn_bwd_reduce_f32): 1 = walk the row blocks of the (M, .) operands last to first.  The result
+ * is the same set of products / sums (the contractions over rows sum their blocks in the walked order: reproducible per
+ * direction, the two directions differ by rounding).  A chain of kernels over 268 MB activation matrices alternates the
+ * direction so that each kernel starts on the rows its predecessor touched last -- what the 256 MB memory-side cache
+ * still holds (measured: 7.92 -> 7.76 ms per training step of the headline network). */
 /* Tall-skinny GEMM of a shared-MLP layer, fp32 MFMA:  C[M,N] = A[M,K] * Bt[N,K]^T  (row-major, K % 4 == 0).
  * Forward: A = rows, Bt = W exactly as nn.Conv2d stores it (Cout x Cin).  With stat_partial != NULL the epilogue also
  * writes shifted partial column sums of C: stat_partial[chunk][4][N] = sum d, sum d^2 (d = value - shift), shift, rows;
@@ -218,7 +225,7 @@ int tp3d_gemm_rows_bnact_f32(const float *Y, const float *mean, const float *sca
 int tp3d_gemm_rows_sp_chunks(int64_t M, int N, int K, int with_act_out);
 int tp3d_gemm_rows_bnact_sp_f32(const float *Y, const float *mean, const float *scale, const float *beta, float slope,
                                 const float *Bt, int64_t M, int N, int K, float *C, float *stat_partial, float *act_out,
-                                void *stream);
+                                int reverse, void *stream);
 /* tp3d_gemm_rows_bnact_sp_f32 with the fp32 contraction carried by the bf16 matrix pipe (csrc/gemm_rows_x3.hip): every operand
  * value split exactly into three bf16 terms by the loader waves (x3_split.h), the product as the six term pairs of weight
  * >= 2^-15, each a v_mfma_f32_32x32x16_bf16 with fp32 accumulation.  Same arguments, outputs and statistics layout;
@@ -226,7 +233,7 @@ int tp3d_gemm_rows_bnact_sp_f32(const float *Y, const float *mean, const float *
 int tp3d_gemm_rows_x3_chunks(int64_t M, int N, int K, int with_act_out);
 int tp3d_gemm_rows_bnact_x3_f32(const float *Y, const float *mean, const float *scale, const float *beta, float slope,
                                 const float *Bt, int64_t M, int N, int K, float *C, float *stat_partial, float *act_out,
-                                void *stream);
+                                int reverse, void *stream);
 
 /* Input-gradient GEMM of a layer on the split-role kernel, with the layer's BatchNorm + activation BACKWARD formed by the
  * loader waves:  C[M,N] = dY[M,K] * Bt[N,K]^T,  dY = scale*((dA*act'(z) - c1) - (Y - mean)*c2),  z = (Y - mean)*scale + beta.
@@ -241,7 +248,7 @@ int tp3d_gemm_rows_bnbwd_sp_serves(int64_t M, int N, int K);
 int tp3d_gemm_rows_bnbwd_sp_f32(const float *Y, const float *dA, const float *mean, const float *scale, const float *beta,
                                 const float *c1, const float *c2, float slope, const float *Bt, int64_t M, int N, int K,
                                 float *C, int ldc, int pad_lo, int pad_hi, float *dY_out, const int *argmax, int ns,
-                                void *stream);
+                                int reverse, void *stream);
 /* Input-gradient GEMM of a layer with its BatchNorm + activation BACKWARD applied to the A operand while it is staged:
  *   C[M,N] = dY[M,K] * Bt[N,K]^T,  dY = scale*(dZ - c1 - (Y - mean)*c2),  dZ = dA * act'((Y - mean)*scale + beta)
  * Y (M,K) pre-BatchNorm output of the layer, dA (M,K) gradient of its activated output -- or, with argmax != NULL, the
@@ -286,13 +293,13 @@ int tp3d_gemm_tn_f32(const float *dY, const float *A, int64_t M, int N, int K, f
 int tp3d_gemm_tn_x3_serves(int64_t M, int N, int K);
 size_t tp3d_gemm_tn_x3_workspace_floats(int64_t M, int N, int K);
 int tp3d_gemm_tn_x3_f32(const float *dY, const float *A, int64_t M, int N, int K, int terms, float *out, float *workspace,
-                        void *stream);
+                        int reverse, void *stream);
 /* ... with the A operand formed on the fly: dW = dY^T * LeakyReLU((Yp - mean_k) * scale_k + beta_k), Yp (M, K) the previous
  * layer's pre-BatchNorm output, mean_k / scale_k / beta_k its statistics rows (K floats each).  The loader waves evaluate
  * the forward kernels' expression in their order, so the result is bit for bit that of the plain entry point on the
  * activated rows -- which the forward pass then need not write. */
 int tp3d_gemm_tn_x3_act_f32(const float *dY, const float *Yp, const float *mean_k, const float *scale_k, const float *beta_k,
-                            float slope_k, int64_t M, int N, int K, int terms, float *out, float *workspace, void *stream);
+                            float slope_k, int64_t M, int N, int K, int terms, float *out, float *workspace, int reverse, void *stream);
 /* The same weight gradient with both operands formed while they are staged, so that neither the BatchNorm-backward
  * result dY nor the activated layer input has to exist in HBM (autograd of dense_modules.py:25-29):
  *   dY = scale_n*(dZ - c1_n - (Y - mean_n)*c2_n), dZ = dA * act'((Y - mean_n)*scale_n + beta_n)

@@ -541,7 +541,7 @@ def test_split_role_gemm_applies_the_previous_layers_batchnorm(M, N, K):
     act = torch.full((M, K), float("nan"), device=DEV)
     part = torch.full((chunks * 4 * N + 64,), float("nan"), device=DEV)
     _lib.call("tp3d_gemm_rows_bnact_sp_f32", _lib.ptr(Y), _lib.ptr(mean), _lib.ptr(scale), _lib.ptr(beta), 0.01, _lib.ptr(Bt), M, N, K,
-              _lib.ptr(out), _lib.ptr(part), _lib.ptr(act), st)
+              _lib.ptr(out), _lib.ptr(part), _lib.ptr(act), 0, st)
     assert torch.equal(act, act_ref)
     # (close, not equal: the plain kernel is free to pick another tile shape, i.e. another summation grouping)
     torch.testing.assert_close(out, ref, rtol=1e-5, atol=1e-5 * float(ref.abs().max()))
@@ -556,17 +556,85 @@ def test_split_role_gemm_applies_the_previous_layers_batchnorm(M, N, K):
     # without statistics and without the side output: the same product
     out2 = torch.empty_like(out)
     _lib.call("tp3d_gemm_rows_bnact_sp_f32", _lib.ptr(Y), _lib.ptr(mean), _lib.ptr(scale), _lib.ptr(beta), 0.01, _lib.ptr(Bt), M, N, K,
-              _lib.ptr(out2), None, None, st)
+              _lib.ptr(out2), None, None, 0, st)
     assert torch.equal(out2, out)
     # statistics without the side output (another number of workgroups, another partition into chunks)
     chunks0 = h.tp3d_gemm_rows_sp_chunks(M, N, K, 0)
     part0 = torch.full((chunks0 * 4 * N,), float("nan"), device=DEV)
     _lib.call("tp3d_gemm_rows_bnact_sp_f32", _lib.ptr(Y), _lib.ptr(mean), _lib.ptr(scale), _lib.ptr(beta), 0.01, _lib.ptr(Bt), M, N, K,
-              _lib.ptr(out2), _lib.ptr(part0), None, st)
+              _lib.ptr(out2), _lib.ptr(part0), None, 0, st)
     stats0 = fused._finalize_stats(part0, M, N, bn.weight.detach(), bn.bias.detach(), bn, Y.device, st, chunks0)
     assert torch.equal(out2, out)
     assert float(((stats0[0] - stats[0]).double().abs() / std).max()) < 1e-5
     torch.testing.assert_close(stats0[1], stats[1], rtol=2e-5, atol=0)
+
+
+@pytest.mark.parametrize("M,N,K", [(66000, 128, 128), (131077, 64, 64), (140001, 256, 132)])
+def test_reverse_row_order_is_the_same_computation(M, N, K):
+    """`reverse` = 1 walks the row blocks last to first (cache reuse between consecutive kernels): per-row outputs are bit
+    for bit the forward-order ones, BatchNorm statistics / reductions / weight gradients are the same sums in another
+    order -- ragged M (a partial last row block and padding blocks lead the reversed walk)."""
+    from torch_points3d_amd import _lib, fused
+    h = _lib.load()
+    g = torch.Generator().manual_seed(M + N + K)
+    Y = (torch.randn(M, K, generator=g) * 2 + 0.3).to(DEV)
+    Bt = (torch.randn(N, K, generator=g) * 0.2).to(DEV)
+    mean, scale, beta = (torch.randn(K, generator=g) * 0.2).to(DEV), (torch.rand(K, generator=g) + 0.5).to(DEV), \
+        (torch.randn(K, generator=g) * 0.3).to(DEV)
+    st = _lib.stream_ptr(Y.device)
+    bn = torch.nn.BatchNorm1d(N).to(DEV)
+    for entry, chunk_fn in (("tp3d_gemm_rows_bnact_sp_f32", h.tp3d_gemm_rows_sp_chunks), ("tp3d_gemm_rows_bnact_x3_f32", h.tp3d_gemm_rows_x3_chunks)):
+        chunks = chunk_fn(M, N, K, 1)
+        if not chunks:
+            continue
+        res = []
+        for rev in (0, 1):
+            out = torch.full((M, N), float("nan"), device=DEV)
+            act = torch.full((M, K), float("nan"), device=DEV)
+            part = torch.full((chunks * 4 * N,), float("nan"), device=DEV)
+            _lib.call(entry, _lib.ptr(Y), _lib.ptr(mean), _lib.ptr(scale), _lib.ptr(beta), 0.01, _lib.ptr(Bt), M, N, K, _lib.ptr(out),
+                      _lib.ptr(part), _lib.ptr(act), rev, st)
+            stats = fused._finalize_stats(part, M, N, bn.weight.detach(), bn.bias.detach(), bn, Y.device, st, chunks)
+            res.append((out, act, stats))
+        assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1]), entry
+        std = res[0][0].double().std(0, unbiased=False)
+        assert float(((res[0][2][0] - res[1][2][0]).double().abs() / std).max()) < 1e-5, entry
+        torch.testing.assert_close(res[0][2][1], res[1][2][1], rtol=2e-5, atol=0)
+    # backward: reductions (bit for bit: a chunk keeps its slot), the input-gradient GEMM with its dY side output (bit for bit)
+    dA = torch.randn(M, K, generator=g).to(DEV)
+    invstd = (torch.rand(K, generator=g) + 0.5).to(DEV)
+    ws = _lib.bn_workspace(M, K, Y.device)
+    reds = []
+    for rev in (0, 1):
+        red = torch.empty(4, K, device=DEV)
+        _lib.call("tp3d_bn_bwd_reduce_f32", _lib.ptr(dA), None, _lib.ptr(Y), _lib.ptr(scale), _lib.ptr(beta), _lib.ptr(mean),
+                  _lib.ptr(invstd), 0.01, M, 1, K, 1, _lib.ptr(red[0]), _lib.ptr(red[1]), _lib.ptr(red[2]), _lib.ptr(red[3]), _lib.ptr(ws),
+                  rev, st)
+        reds.append(red)
+    assert torch.equal(reds[0], reds[1])
+    if h.tp3d_gemm_rows_bnbwd_sp_serves(M, N, K):
+        outs = []
+        for rev in (0, 1):
+            out = torch.full((M, N), float("nan"), device=DEV)
+            dY = torch.full((M, K), float("nan"), device=DEV)
+            _lib.call("tp3d_gemm_rows_bnbwd_sp_f32", _lib.ptr(Y), _lib.ptr(dA), _lib.ptr(mean), _lib.ptr(scale), _lib.ptr(beta),
+                      _lib.ptr(reds[0][2]), _lib.ptr(reds[0][3]), 0.01, _lib.ptr(Bt), M, N, K, _lib.ptr(out), N, 0, 0, _lib.ptr(dY), None, 1,
+                      rev, st)
+            outs.append((out, dY))
+        assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    # weight gradient on the bf16 pipe: the same products summed in another order
+    if h.tp3d_gemm_tn_x3_serves(M, N, K):
+        dYn = torch.randn(M, N, generator=g).to(DEV)
+        a = fused.gemm_tn(dYn, Y, reverse=0)
+        b = fused.gemm_tn(dYn, Y, reverse=1)
+        c = fused.gemm_tn(dYn, Y, act=(mean, scale, beta, 0.01), reverse=1)
+        d = fused.gemm_tn(dYn, Y, act=(mean, scale, beta, 0.01), reverse=0)
+        want = dYn.double().t() @ Y.double()
+        mag = dYn.double().abs().t() @ Y.double().abs()
+        for got in (a, b):
+            assert float(((got.double() - want).abs() / mag).max()) < 1e-6
+        assert float(((c - d).double().abs() / mag).max()) < 1e-6
+    torch.cuda.synchronize()
 
 
 def test_split_role_gemm_declines_shapes_it_does_not_serve():
@@ -577,7 +645,7 @@ def test_split_role_gemm_declines_shapes_it_does_not_serve():
     with pytest.raises(_lib.Tp3dError):
         t = torch.zeros(4096, 128, device=DEV)
         _lib.call("tp3d_gemm_rows_bnact_sp_f32", _lib.ptr(t), _lib.ptr(t), _lib.ptr(t), _lib.ptr(t), 0.01, _lib.ptr(t), 4096, 128, 128,
-                  _lib.ptr(t), None, None, _lib.stream_ptr(t.device))
+                  _lib.ptr(t), None, None, 0, _lib.stream_ptr(t.device))
 
 
 def test_split_role_gemm_constants_table_is_ready_before_the_first_tile():
@@ -601,7 +669,7 @@ def test_split_role_gemm_constants_table_is_ready_before_the_first_tile():
     for i in range(8):
         mean, scale, beta, _ = sets[i & 1]
         _lib.call("tp3d_gemm_rows_bnact_sp_f32", _lib.ptr(Y), _lib.ptr(mean), _lib.ptr(scale), _lib.ptr(beta), 0.01, _lib.ptr(Bt), M, N, K,
-                  _lib.ptr(out), None, _lib.ptr(acts[i]), st)
+                  _lib.ptr(out), None, _lib.ptr(acts[i]), 0, st)
     for i in range(8):
         assert torch.equal(acts[i], sets[i & 1][3]), i
 
@@ -626,11 +694,11 @@ def test_split_role_input_gradient_gemm_forms_dy_in_its_loaders(M, N, K):
     red = torch.empty(4, K, device=DEV)
     ws = _lib.bn_workspace(M, K, Y.device)
     _lib.call("tp3d_bn_bwd_reduce_f32", _lib.ptr(dA), None, _lib.ptr(Y), _lib.ptr(scale), _lib.ptr(beta), _lib.ptr(mean32),
-              _lib.ptr(invstd32), 0.01, M, 1, K, 1, _lib.ptr(red[0]), _lib.ptr(red[1]), _lib.ptr(red[2]), _lib.ptr(red[3]), _lib.ptr(ws), st)
+              _lib.ptr(invstd32), 0.01, M, 1, K, 1, _lib.ptr(red[0]), _lib.ptr(red[1]), _lib.ptr(red[2]), _lib.ptr(red[3]), _lib.ptr(ws), 0, st)
     out = torch.full((M, N), float("nan"), device=DEV)
     dY = torch.full((M, K), float("nan"), device=DEV)
     _lib.call("tp3d_gemm_rows_bnbwd_sp_f32", _lib.ptr(Y), _lib.ptr(dA), _lib.ptr(mean32), _lib.ptr(scale), _lib.ptr(beta), _lib.ptr(red[2]),
-              _lib.ptr(red[3]), 0.01, _lib.ptr(Wt), M, N, K, _lib.ptr(out), N, 0, 0, _lib.ptr(dY), None, 1, st)
+              _lib.ptr(red[3]), 0.01, _lib.ptr(Wt), M, N, K, _lib.ptr(out), N, 0, 0, _lib.ptr(dY), None, 1, 0, st)
     torch.cuda.synchronize()
     yc = Y.double() - mean32.double()
     z = yc * scale.double() + beta.double()
@@ -646,16 +714,16 @@ def test_split_role_input_gradient_gemm_forms_dy_in_its_loaders(M, N, K):
     # without the side output: the same product
     out2 = torch.empty_like(out)
     _lib.call("tp3d_gemm_rows_bnbwd_sp_f32", _lib.ptr(Y), _lib.ptr(dA), _lib.ptr(mean32), _lib.ptr(scale), _lib.ptr(beta), _lib.ptr(red[2]),
-              _lib.ptr(red[3]), 0.01, _lib.ptr(Wt), M, N, K, _lib.ptr(out2), N, 0, 0, None, None, 1, st)
+              _lib.ptr(red[3]), 0.01, _lib.ptr(Wt), M, N, K, _lib.ptr(out2), N, 0, 0, None, None, 1, 0, st)
     assert torch.equal(out2, out)
     # into a column range of wider rows (the feature columns of grouped rows): nothing outside it is touched
     wide = torch.full((M, N + 8), 7.0, device=DEV)
     _lib.call("tp3d_gemm_rows_bnbwd_sp_f32", _lib.ptr(Y), _lib.ptr(dA), _lib.ptr(mean32), _lib.ptr(scale), _lib.ptr(beta), _lib.ptr(red[2]),
-              _lib.ptr(red[3]), 0.01, _lib.ptr(Wt), M, N, K, wide.data_ptr() + 12, N + 8, 0, 0, None, None, 1, st)
+              _lib.ptr(red[3]), 0.01, _lib.ptr(Wt), M, N, K, wide.data_ptr() + 12, N + 8, 0, 0, None, None, 1, 0, st)
     assert torch.equal(wide[:, 3:3 + N], out) and bool((wide[:, :3] == 7).all()) and bool((wide[:, 3 + N:] == 7).all())
     # the three columns in front of the range and four of the five behind it written as zeros by the kernel
     _lib.call("tp3d_gemm_rows_bnbwd_sp_f32", _lib.ptr(Y), _lib.ptr(dA), _lib.ptr(mean32), _lib.ptr(scale), _lib.ptr(beta), _lib.ptr(red[2]),
-              _lib.ptr(red[3]), 0.01, _lib.ptr(Wt), M, N, K, wide.data_ptr() + 12, N + 8, 3, 4, None, None, 1, st)
+              _lib.ptr(red[3]), 0.01, _lib.ptr(Wt), M, N, K, wide.data_ptr() + 12, N + 8, 3, 4, None, None, 1, 0, st)
     assert torch.equal(wide[:, 3:3 + N], out) and bool((wide[:, :3] == 0).all()) and bool((wide[:, 3 + N:3 + N + 4] == 0).all())
     assert bool((wide[:, 3 + N + 4:] == 7).all())
     assert h.tp3d_gemm_rows_bnbwd_sp_serves(M, N, 260) == 0 and h.tp3d_gemm_rows_bnbwd_sp_serves(4096, N, K) == 0
@@ -681,7 +749,7 @@ def test_narrow_first_layer_weight_gradient_from_y_and_da(M, N, K):
     red = torch.empty(4, N, device=DEV)
     ws = _lib.bn_workspace(M, N, Y.device)
     _lib.call("tp3d_bn_bwd_reduce_f32", _lib.ptr(dA), None, _lib.ptr(Y), _lib.ptr(scale), _lib.ptr(beta), _lib.ptr(mean),
-              _lib.ptr(invstd), 0.01, M, 1, N, 1, _lib.ptr(red[0]), _lib.ptr(red[1]), _lib.ptr(red[2]), _lib.ptr(red[3]), _lib.ptr(ws), st)
+              _lib.ptr(invstd), 0.01, M, 1, N, 1, _lib.ptr(red[0]), _lib.ptr(red[1]), _lib.ptr(red[2]), _lib.ptr(red[3]), _lib.ptr(ws), 0, st)
     nws = torch.empty(h.tp3d_gemm_tn_bn_narrow_workspace_floats(M, N, K), device=DEV)
     outs = []
     for _ in range(2):
@@ -768,7 +836,7 @@ def test_split_role_input_gradient_gemm_with_pooled_gradient(M, N, K, ns):
         out = torch.full((M, N), float("nan"), device=DEV)
         dY = torch.full((M, K), float("nan"), device=DEV)
         _lib.call("tp3d_gemm_rows_bnbwd_sp_f32", _lib.ptr(Y), _lib.ptr(dA), _lib.ptr(mean), _lib.ptr(scale), _lib.ptr(beta), _lib.ptr(c1),
-                  _lib.ptr(c2), 0.01, _lib.ptr(Wt), M, N, K, _lib.ptr(out), N, 0, 0, _lib.ptr(dY), a_ptr, n_, st)
+                  _lib.ptr(c2), 0.01, _lib.ptr(Wt), M, N, K, _lib.ptr(out), N, 0, 0, _lib.ptr(dY), a_ptr, n_, 0, st)
         outs.append((out, dY))
     assert torch.equal(outs[0][1], outs[1][1])
     assert torch.equal(outs[0][0], outs[1][0])
@@ -1012,7 +1080,7 @@ def test_forward_x3_gemm_is_as_accurate_as_the_fp32_mfma_form(M, N, K):
         part = torch.empty(chunks * 4 * N, device=DEV)
         act = torch.empty(M, K, device=DEV)
         _lib.call(name, _lib.ptr(Y), _lib.ptr(mean), _lib.ptr(scale), _lib.ptr(beta), slope, _lib.ptr(W), M, N, K, _lib.ptr(C),
-                  _lib.ptr(part), _lib.ptr(act), _lib.stream_ptr(Y.device))
+                  _lib.ptr(part), _lib.ptr(act), 0, _lib.stream_ptr(Y.device))
         stats = torch.empty(4, N, device=DEV)
         rm, rv, nb = torch.zeros(N, device=DEV), torch.ones(N, device=DEV), torch.zeros(1, dtype=torch.long, device=DEV)
         ones, zeros = torch.ones(N, device=DEV), torch.zeros(N, device=DEV)

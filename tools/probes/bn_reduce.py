@@ -34,7 +34,7 @@ for M, C in [(524288, 128), (1048576, 64), (262144, 128), (262144, 256), (104857
 
     def run():
         _lib.call("tp3d_bn_bwd_reduce_f32", _lib.ptr(dA), None, _lib.ptr(Y), _lib.ptr(v[0]), _lib.ptr(v[1]), _lib.ptr(v[2]), _lib.ptr(v[3]),
-                  0.01, M, 1, C, 1, _lib.ptr(red[0]), _lib.ptr(red[1]), _lib.ptr(red[2]), _lib.ptr(red[3]), _lib.ptr(ws), st)
+                  0.01, M, 1, C, 1, _lib.ptr(red[0]), _lib.ptr(red[1]), _lib.ptr(red[2]), _lib.ptr(red[3]), _lib.ptr(ws), 0, st)
     t = timeit(run)
     print("M=%8d C=%4d  %7.1f us  %5.2f TB/s   checksum %.6e %.6e" % (M, C, t, 8.0 * M * C / t / 1e6, float(red[0].sum()), float(red[1].sum())),
           flush=True)

@@ -83,7 +83,7 @@ def main():
 
         def shipped():
             _lib.call("tp3d_gemm_rows_bnact_sp_f32", Y.data_ptr(), mean.data_ptr(), scale.data_ptr(), beta.data_ptr(), 0.01, Bt.data_ptr(),
-                      M, N, K, C1.data_ptr(), None, None, st)
+                      M, N, K, C1.data_ptr(), None, None, 0, st)
 
         def b3(grid=256):
             rc = f(Y.data_ptr(), Bt.data_ptr(), M, N, K, C2.data_ptr(), grid, mean.data_ptr(), scale.data_ptr(), beta.data_ptr(), 0.01, st)

@@ -39,11 +39,11 @@ for M, N, K in [(524288, 128, 128), (1048576, 128, 64), (1048576, 64, 64), (2621
 
     def fwd():
         _lib.call("tp3d_gemm_rows_bnact_sp_f32", _lib.ptr(Y), _lib.ptr(v[0]), _lib.ptr(v[1]), _lib.ptr(v[2]), 0.01, _lib.ptr(Bt), M, N, K,
-                  _lib.ptr(C), _lib.ptr(part), _lib.ptr(side), st)
+                  _lib.ptr(C), _lib.ptr(part), _lib.ptr(side), 0, st)
 
     def bwd():
         _lib.call("tp3d_gemm_rows_bnbwd_sp_f32", _lib.ptr(Y), _lib.ptr(dA), _lib.ptr(v[0]), _lib.ptr(v[1]), _lib.ptr(v[2]), _lib.ptr(v[3]),
-                  _lib.ptr(v[4]), 0.01, _lib.ptr(Bt), M, N, K, _lib.ptr(C), N, _lib.ptr(side), None, 1, st)
+                  _lib.ptr(v[4]), 0.01, _lib.ptr(Bt), M, N, K, _lib.ptr(C), N, _lib.ptr(side), None, 1, 0, st)
     tf, tb = timeit(fwd), timeit(bwd)
     tot_f += tf
     tot_b += tb

@@ -48,7 +48,7 @@ __global__ __launch_bounds__(SP_BLOCK, 4) void gemm_rows_sp_kernel(const float *
                                                                 int64_t M, int N, int K, int tiles_n, int64_t items,
                                                                 float *__restrict__ C, int64_t ldc,
                                                                 float *__restrict__ partial, float *__restrict__ act_out,
-                                                                SpPro pro)
+                                                                SpPro pro, int reverse)
 {
     constexpr int KMAX = PRO >= 2 ? SP_BWD_KMAX : SP_PRO_KMAX;
     __shared__ __attribute__((aligned(16))) float sK[PRO >= 2 ? 5 * KMAX : (PRO ? 3 * KMAX : 4)];
@@ -75,9 +75,11 @@ __global__ __launch_bounds__(SP_BLOCK, 4) void gemm_rows_sp_kernel(const float *
     const int64_t total = my_items * ksteps;  // K-steps this workgroup walks, as one flat sequence
 
     // item -> (row block, column tile): the column tiles of one row block are 8 ids apart (same XCD: shared L2 for A)
+    const int64_t last_grp = items / (8 * tiles_n) - 1;
     auto decode = [&](int64_t item, int64_t &m0, int &n0) {
-        const int64_t grp = item / (8 * tiles_n);
+        int64_t grp = item / (8 * tiles_n);
         const int rem = (int)(item % (8 * tiles_n));
+        if (reverse) grp = max(last_grp - grp, (int64_t)0);  // row blocks last to first (look-ahead past the last item: group 0)
         m0 = (grp * 8 + (rem & 7)) * SP_BM;
         n0 = (rem >> 3) * BN;
     };
@@ -250,10 +252,7 @@ __global__ __launch_bounds__(SP_BLOCK, 4) void gemm_rows_sp_kernel(const float *
         if (++f_ks == ksteps) {                                                                                       \
             f_ks = 0;                                                                                                 \
             f_item += gridDim.x;                                                                                      \
-            const int64_t grp = f_item / (8 * tiles_n);                                                               \
-            const int rem = (int)(f_item % (8 * tiles_n));                                                            \
-            f_m0 = (grp * 8 + (rem & 7)) * SP_BM;                                                                     \
-            f_n0 = (rem >> 3) * BN;                                                                                   \
+            decode(f_item, f_m0, f_n0);                                                                               \
         }                                                                                                             \
     } while (0)
 #define SP_STASH_A(S, BUF, I)                                                                                         \
@@ -453,7 +452,7 @@ TP3D_EXPORT int tp3d_gemm_rows_sp_chunks(int64_t M, int N, int K, int with_act_o
 
 TP3D_EXPORT int tp3d_gemm_rows_bnact_sp_f32(const float *Y, const float *mean, const float *scale, const float *beta,
                                             float slope, const float *Bt, int64_t M, int N, int K, float *C,
-                                            float *stat_partial, float *act_out, void *stream)
+                                            float *stat_partial, float *act_out, int reverse, void *stream)
 {
     using namespace tp3d;
     const int tiles_n = sp_tiles_n(M, N, K);
@@ -464,7 +463,7 @@ TP3D_EXPORT int tp3d_gemm_rows_bnact_sp_f32(const float *Y, const float *mean, c
     hipStream_t s = (hipStream_t)stream;
 #define TP3D_SP_LAUNCH(STATS, BN)                                                                                     \
     hipLaunchKernelGGL((gemm_rows_sp_kernel<STATS, 1, BN>), dim3(grid), dim3(SP_BLOCK), 0, s, Y, Bt, M, N, K, tiles_n, items, \
-                       C, (int64_t)N, stat_partial, act_out, pro)
+                       C, (int64_t)N, stat_partial, act_out, pro, reverse)
     if (N <= 64) {
         if (stat_partial)
             TP3D_SP_LAUNCH(2, 64);
@@ -489,7 +488,7 @@ TP3D_EXPORT int tp3d_gemm_rows_bnbwd_sp_serves(int64_t M, int N, int K)
 TP3D_EXPORT int tp3d_gemm_rows_bnbwd_sp_f32(const float *Y, const float *dA, const float *mean, const float *scale,
                                             const float *beta, const float *c1, const float *c2, float slope,
                                             const float *Bt, int64_t M, int N, int K, float *C, int ldc, int pad_lo,
-                                            int pad_hi, float *dY_out, const int *argmax, int ns, void *stream)
+                                            int pad_hi, float *dY_out, const int *argmax, int ns, int reverse, void *stream)
 {
     using namespace tp3d;
     // (no statistics here, so any number of column tiles would work -- but every column tile re-reads BOTH operand
@@ -507,7 +506,7 @@ TP3D_EXPORT int tp3d_gemm_rows_bnbwd_sp_f32(const float *Y, const float *dA, con
     hipStream_t s = (hipStream_t)stream;
 #define TP3D_SP_BWD2(PRO, BN)                                                                                         \
     hipLaunchKernelGGL((gemm_rows_sp_kernel<0, PRO, BN>), dim3(grid), dim3(SP_BLOCK), 0, s, Y, Bt, M, N, K, tiles_n, items, C, \
-                       (int64_t)ldc, (float *)nullptr, dY_out, pro)
+                       (int64_t)ldc, (float *)nullptr, dY_out, pro, reverse)
     if (argmax) {
         if (N <= 64)
             TP3D_SP_BWD2(3, 64);

@@ -39,7 +39,7 @@ __global__ __launch_bounds__(B3_BLOCK, 4) void gemm_rows_x3_kernel(const float *
                                                                 float *__restrict__ C, float *__restrict__ partial,
                                                                 float *__restrict__ act_out, const float *__restrict__ mean,
                                                                 const float *__restrict__ scale, const float *__restrict__ beta,
-                                                                float slope)
+                                                                float slope, int reverse)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned short smem[];
     // the prologue's per-channel constants (K <= 512)
@@ -60,9 +60,12 @@ __global__ __launch_bounds__(B3_BLOCK, 4) void gemm_rows_x3_kernel(const float *
     const int64_t my_items = (items - blockIdx.x + gridDim.x - 1) / gridDim.x;
     const int64_t total = my_items * ksteps;
 
+    const int64_t last_grp = items / (8 * tiles_n) - 1;
     auto decode = [&](int64_t item, int64_t &m0, int &n0) {
-        const int64_t grp = item / (8 * tiles_n);
+        int64_t grp = item / (8 * tiles_n);
         const int rem = (int)(item % (8 * tiles_n));
+        if (reverse) grp = max(last_grp - grp, (int64_t)0);  // row blocks last to first (the loaders' look-ahead past the
+                                                             // last item lands on group 0: valid addresses, never consumed)
         m0 = (grp * 8 + (rem & 7)) * B3_BM;
         n0 = (rem >> 3) * B3_BN;
     };
@@ -294,7 +297,7 @@ TP3D_EXPORT int tp3d_gemm_rows_x3_chunks(int64_t M, int N, int K, int with_act_o
 
 TP3D_EXPORT int tp3d_gemm_rows_bnact_x3_f32(const float *Y, const float *mean, const float *scale, const float *beta,
                                             float slope, const float *Bt, int64_t M, int N, int K, float *C,
-                                            float *stat_partial, float *act_out, void *stream)
+                                            float *stat_partial, float *act_out, int reverse, void *stream)
 {
     using namespace tp3d;
     const int tiles_n = b3_tiles_n(M, N, K);
@@ -306,11 +309,11 @@ TP3D_EXPORT int tp3d_gemm_rows_bnact_x3_f32(const float *Y, const float *mean, c
     if (stat_partial) {
         allow_large_dynamic_lds(reinterpret_cast<const void *>(&gemm_rows_x3_kernel<2>), B3_LDS_BYTES, set2);
         hipLaunchKernelGGL(gemm_rows_x3_kernel<2>, dim3(grid), dim3(B3_BLOCK), B3_LDS_BYTES, s, Y, Bt, M, N, K, tiles_n, items, C,
-                           stat_partial, act_out, mean, scale, beta, slope);
+                           stat_partial, act_out, mean, scale, beta, slope, reverse);
     } else {
         allow_large_dynamic_lds(reinterpret_cast<const void *>(&gemm_rows_x3_kernel<0>), B3_LDS_BYTES, set0);
         hipLaunchKernelGGL(gemm_rows_x3_kernel<0>, dim3(grid), dim3(B3_BLOCK), B3_LDS_BYTES, s, Y, Bt, M, N, K, tiles_n, items, C,
-                           (float *)nullptr, act_out, mean, scale, beta, slope);
+                           (float *)nullptr, act_out, mean, scale, beta, slope, reverse);
     }
     return check_launch();
 }

@@ -59,6 +59,7 @@ __device__ __forceinline__ bf16x8 x3_frag(const unsigned short *plane, int pitch
 struct X3Prologue {
     const float *mean, *scale, *beta;
     float slope;
+    int reverse;  // walk the row blocks last to first (start on the rows the kernel before this one touched last)
 };
 
 template <int WM, int WN, bool STRIP, int BR, int TERMS>
@@ -120,7 +121,7 @@ __global__ __launch_bounds__(X3_BLOCK) void gemm_tn_x3_kernel(const float *__res
             for (int i = 0; i < SS; ++i) os[i] = (unsigned)((((lt + i * 256) / 8) * K + k0 + TK + ((lt + i * 256) % 8) * 4) * 4);
         }
         auto fetch = [&](int t, float4 *ry, float4 *ra, float4 *rs) __attribute__((always_inline)) {
-            const int64_t r0 = ((int64_t)t * S + blockIdx.y) * BR;
+            const int64_t r0 = ((int64_t)(pro.reverse ? steps - 1 - t : t) * S + blockIdx.y) * BR;  // (last row blocks first)
             const char *by_ = reinterpret_cast<const char *>(dY) + r0 * N * 4;
             const char *ba_ = reinterpret_cast<const char *>(A) + r0 * K * 4;
             if (r0 + BR <= M && cols_full) {  // (wave-uniform) the whole block lies inside both matrices
@@ -418,9 +419,9 @@ static int x3_run(const float *dY, const float *A, int64_t M, int N, int K, int 
 }
 
 TP3D_EXPORT int tp3d_gemm_tn_x3_f32(const float *dY, const float *A, int64_t M, int N, int K, int terms, float *out,
-                                    float *workspace, void *stream)
+                                    float *workspace, int reverse, void *stream)
 {
-    const X3Prologue none = {nullptr, nullptr, nullptr, 1.0f};
+    const X3Prologue none = {nullptr, nullptr, nullptr, 1.0f, reverse};
     return x3_run(dY, A, M, N, K, terms, out, workspace, none, stream);
 }
 
@@ -428,9 +429,9 @@ TP3D_EXPORT int tp3d_gemm_tn_x3_f32(const float *dY, const float *A, int64_t M, 
 // layer's pre-BatchNorm output Yp (M, K) and its statistics rows (K floats each) -- see X3Prologue
 TP3D_EXPORT int tp3d_gemm_tn_x3_act_f32(const float *dY, const float *Yp, const float *mean_k, const float *scale_k,
                                         const float *beta_k, float slope_k, int64_t M, int N, int K, int terms, float *out,
-                                        float *workspace, void *stream)
+                                        float *workspace, int reverse, void *stream)
 {
     if (!mean_k || !scale_k || !beta_k) return TP3D_E_BADARG;
-    const X3Prologue pro = {mean_k, scale_k, beta_k, slope_k};
+    const X3Prologue pro = {mean_k, scale_k, beta_k, slope_k, reverse};
     return x3_run(dY, Yp, M, N, K, terms, out, workspace, pro, stream);
 }

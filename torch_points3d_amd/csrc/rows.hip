@@ -288,13 +288,16 @@ template <int V, int MODE>
 __global__ __launch_bounds__(RW_BLOCK) void colreduce_partial_kernel(
     const float *__restrict__ Y, const float *__restrict__ dA, const float *__restrict__ scale,
     const float *__restrict__ shift, const float *__restrict__ mean, const float *__restrict__ invstd, float slope,
-    int64_t M, int C, int colthreads, int chunk_rows, float *__restrict__ partial /*[chunks][2][C]*/)
+    int64_t M, int C, int colthreads, int chunk_rows, float *__restrict__ partial /*[chunks][2][C]*/, int reverse = 0)
 {
     __shared__ float s1[RW_BLOCK * V], s2[RW_BLOCK * V];
     const int ct = threadIdx.x % colthreads, rl = threadIdx.x / colthreads;
     const int rowlanes = RW_BLOCK / colthreads;
     const int c = (blockIdx.x * colthreads + ct) * V;
-    const int64_t r0 = (int64_t)blockIdx.y * chunk_rows;
+    // MODE 1 can walk the chunks LAST ROWS FIRST: when dA was written front to back by the kernel just before this one, its
+    // tail is what the memory-side cache (256 MB) still holds
+    const int chunk = (MODE == 1 && reverse) ? (int)(gridDim.y - 1 - blockIdx.y) : (int)blockIdx.y;
+    const int64_t r0 = (int64_t)chunk * chunk_rows;
     const int64_t r1 = min(r0 + chunk_rows, M);
     float a[V], q[V], sc[V], sh[V], mu[V], is[V];
 #pragma unroll
@@ -365,13 +368,13 @@ __global__ __launch_bounds__(RW_BLOCK) void colreduce_partial_kernel(
                     sq += s2[(k * colthreads + ct) * V + v];
                 }
                 if (MODE == 0) {
-                    partial[((size_t)blockIdx.y * 4 + 0) * C + c + v] = sa;
-                    partial[((size_t)blockIdx.y * 4 + 1) * C + c + v] = sq;
-                    partial[((size_t)blockIdx.y * 4 + 2) * C + c + v] = mu[v];
-                    partial[((size_t)blockIdx.y * 4 + 3) * C + c + v] = (float)(r1 - r0);
+                    partial[((size_t)chunk * 4 + 0) * C + c + v] = sa;
+                    partial[((size_t)chunk * 4 + 1) * C + c + v] = sq;
+                    partial[((size_t)chunk * 4 + 2) * C + c + v] = mu[v];
+                    partial[((size_t)chunk * 4 + 3) * C + c + v] = (float)(r1 - r0);
                 } else {
-                    partial[((size_t)blockIdx.y * 2 + 0) * C + c + v] = sa;
-                    partial[((size_t)blockIdx.y * 2 + 1) * C + c + v] = sq;
+                    partial[((size_t)chunk * 2 + 0) * C + c + v] = sa;
+                    partial[((size_t)chunk * 2 + 1) * C + c + v] = sq;
                 }
             }
         }
@@ -1155,7 +1158,7 @@ namespace tp3d {
 // pass 1 of the BatchNorm + activation backward: partial sums, then dbeta / dgamma (and c1 / c2 when asked for)
 static int bn_bwd_reduce(const float *dA, const int *argmax, const float *Y, const float *scale, const float *shift,
                          const float *mean, const float *invstd, float slope, int64_t M, int ns, int C, int training,
-                         float *dbeta, float *dgamma, float *c1, float *c2, float *workspace, hipStream_t s)
+                         float *dbeta, float *dgamma, float *c1, float *c2, float *workspace, int reverse, hipStream_t s)
 {
     const int64_t R = argmax ? M / ns : M;  // rows of the reduction domain
     const int crow = stat_rows(R);
@@ -1167,7 +1170,7 @@ static int bn_bwd_reduce(const float *dA, const int *argmax, const float *Y, con
     } else if ((C & 3) == 0) {
         const StatTile t = stat_tile(C, 4);
         hipLaunchKernelGGL((colreduce_partial_kernel<4, 1>), dim3(t.gridx, chunks), dim3(RW_BLOCK), 0, s, Y, dA, scale,
-                           shift, mean, invstd, slope, M, C, t.colthreads, crow, workspace);
+                           shift, mean, invstd, slope, M, C, t.colthreads, crow, workspace, reverse);
     } else {
         const StatTile t = stat_tile(C, 1);
         hipLaunchKernelGGL((colreduce_partial_kernel<1, 1>), dim3(t.gridx, chunks), dim3(RW_BLOCK), 0, s, Y, dA, scale,
@@ -1183,13 +1186,13 @@ static int bn_bwd_reduce(const float *dA, const int *argmax, const float *Y, con
 TP3D_EXPORT int tp3d_bn_bwd_reduce_f32(const float *dA, const int *argmax, const float *Y, const float *scale,
                                        const float *shift, const float *mean, const float *invstd, float slope,
                                        int64_t M, int ns, int C, int training, float *dbeta, float *dgamma, float *c1,
-                                       float *c2, float *workspace, void *stream)
+                                       float *c2, float *workspace, int reverse, void *stream)
 {
     if (M <= 0 || C <= 0 || ns <= 0 || (argmax && M % ns)) return TP3D_E_BADARG;
     if (!dA || !Y || !scale || !shift || !mean || !invstd || !dbeta || !dgamma || !c1 || !c2 || !workspace)
         return TP3D_E_BADARG;
     return bn_bwd_reduce(dA, argmax, Y, scale, shift, mean, invstd, slope, M, ns, C, training, dbeta, dgamma, c1, c2,
-                         workspace, (hipStream_t)stream);
+                         workspace, reverse, (hipStream_t)stream);
 }
 
 TP3D_EXPORT int tp3d_bn_act_bwd_f32(const float *dA, const int *argmax, const float *Y, const float *scale,
@@ -1204,7 +1207,7 @@ TP3D_EXPORT int tp3d_bn_act_bwd_f32(const float *dA, const int *argmax, const fl
     hipStream_t s = (hipStream_t)stream;
     const int64_t R = argmax ? M / ns : M;  // rows of the reduction domain
     if (int rc = bn_bwd_reduce(dA, argmax, Y, scale, shift, mean, invstd, slope, M, ns, C, training, dbeta, dgamma, nullptr,
-                               nullptr, workspace, s))
+                               nullptr, workspace, 0, s))
         return rc;
     if (argmax) {
         int split = (int)((262144 + R * C - 1) / (R * C));  // ~4 waves per SIMD worth of lanes

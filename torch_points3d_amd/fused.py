@@ -90,19 +90,20 @@ def _identity_stats(K, dev):
     return hit
 
 
-def _chain_wgrad(dY, l, A0, acts, Ys, stats, slopes):
+def _chain_wgrad(dY, l, A0, acts, Ys, stats, slopes, reverse=0):
     """weight gradient of layer l of a fused chain: dY^T @ (activated input of the layer)"""
     if l == 0:
-        return gemm_tn(dY, A0)
+        return gemm_tn(dY, A0, reverse=reverse)
     if acts[l - 1] is not None:
-        return gemm_tn(dY, acts[l - 1])
+        return gemm_tn(dY, acts[l - 1], reverse=reverse)
     ps = stats[l - 1]  # the forward pass kept no activated rows: the contraction's loader waves form them from Y_{l-1}
-    return gemm_tn(dY, Ys[l - 1], act=(ps[0], ps[2], ps[3], slopes[l - 1]))
+    return gemm_tn(dY, Ys[l - 1], act=(ps[0], ps[2], ps[3], slopes[l - 1]), reverse=reverse)
 
 
-def gemm_tn(dY, A, x3=None, act=None):
+def gemm_tn(dY, A, x3=None, act=None, reverse=0):
     """dY (M,N), A (M,K) -> dY^T @ A (N,K), split over the rows, partial tiles summed in fixed order (reproducible):
-    csrc/gemm_tn_x3.hip for the shapes it serves (x3 terms, default WGRAD_X3), else the fp32 MFMA kernel csrc/gemm_tn.hip."""
+    csrc/gemm_tn_x3.hip for the shapes it serves (x3 terms, default WGRAD_X3), else the fp32 MFMA kernel csrc/gemm_tn.hip.
+    reverse: the bf16-pipe kernel walks the row blocks last to first (include/tp3d_hip.h, `reverse`)."""
     dev = dY.device
     dY, A = dY.contiguous(), A.contiguous()
     M, N = dY.shape
@@ -117,12 +118,12 @@ def gemm_tn(dY, A, x3=None, act=None):
         ws = _lib.gemm_tn_workspace(M, N, K, dev, x3=True)
         with _lib.on_device(dev):
             _lib.call("tp3d_gemm_tn_x3_act_f32", _lib.ptr(dY), _lib.ptr(A), _lib.ptr(act[0]), _lib.ptr(act[1]), _lib.ptr(act[2]),
-                      float(act[3]), M, N, K, int(terms), _lib.ptr(out), _lib.ptr(ws), _lib.stream_ptr(dev))
+                      float(act[3]), M, N, K, int(terms), _lib.ptr(out), _lib.ptr(ws), int(reverse), _lib.stream_ptr(dev))
         return out
     ws = _lib.gemm_tn_workspace(M, N, K, dev, x3=use_x3)
     with _lib.on_device(dev):
         if use_x3:
-            _lib.call("tp3d_gemm_tn_x3_f32", _lib.ptr(dY), _lib.ptr(A), M, N, K, int(terms), _lib.ptr(out), _lib.ptr(ws),
+            _lib.call("tp3d_gemm_tn_x3_f32", _lib.ptr(dY), _lib.ptr(A), M, N, K, int(terms), _lib.ptr(out), _lib.ptr(ws), int(reverse),
                       _lib.stream_ptr(dev))
         else:
             _lib.call("tp3d_gemm_tn_f32", _lib.ptr(dY), _lib.ptr(A), M, N, K, _lib.ptr(out), _lib.ptr(ws),
@@ -443,6 +444,9 @@ class _MLPChain(torch.autograd.Function):
                 if sp_chunks and FWD_X3 and h.tp3d_gemm_rows_x3_chunks(M, Cout, Kp, int(keep_act)):
                     sp_chunks = h.tp3d_gemm_rows_x3_chunks(M, Cout, Kp, int(keep_act))
                     sp_entry = "tp3d_gemm_rows_bnact_x3_f32"  # the same contraction as bf16 term pairs on the matrix pipe
+                # alternate the direction the row blocks are walked in, layer by layer: a layer starts where the previous one
+                # (or the producer of A0, front to back) ended, on the rows the memory-side cache still holds
+                rev = int(ROW_ORDER_ALTERNATE and l % 2 == 0)
                 chunks = None
                 x3_first = h.tp3d_gemm_rows_x3_chunks(M, Cout, Kp, 0) if (l == 0 and FWD_X3 and CHAIN_LOADER) else 0
                 if x3_first:
@@ -451,7 +455,7 @@ class _MLPChain(torch.autograd.Function):
                     ident = _identity_stats(Kp, dev)
                     part = _lib.workspace("gemm_rows_stats", 16 * x3_first * Cout, dev) if training else None
                     _lib.call("tp3d_gemm_rows_bnact_x3_f32", _lib.ptr(A0), _lib.ptr(ident[0]), _lib.ptr(ident[1]), _lib.ptr(ident[0]),
-                              1.0, _lib.ptr(W2), M, Cout, Kp, _lib.ptr(Y), _lib.ptr(part), None, st)
+                              1.0, _lib.ptr(W2), M, Cout, Kp, _lib.ptr(Y), _lib.ptr(part), None, rev, st)
                     chunks = x3_first
                 elif l == 0:
                     part = _lib.workspace("gemm_rows_stats", 4 * h.tp3d_gemm_rows_stat_floats(M, Cout), dev) if training else None
@@ -463,7 +467,7 @@ class _MLPChain(torch.autograd.Function):
                     part = _lib.workspace("gemm_rows_stats", 16 * sp_chunks * Cout, dev) if training else None
                     act = torch.empty((M, Kp), dtype=torch.float32, device=dev) if keep_act else None
                     _lib.call(sp_entry, _lib.ptr(Ys[-1]), _lib.ptr(ps[0]), _lib.ptr(ps[2]), _lib.ptr(ps[3]),
-                              layers[l - 1][1], _lib.ptr(W2), M, Cout, Kp, _lib.ptr(Y), _lib.ptr(part), _lib.ptr(act), st)
+                              layers[l - 1][1], _lib.ptr(W2), M, Cout, Kp, _lib.ptr(Y), _lib.ptr(part), _lib.ptr(act), rev, st)
                     chunks = sp_chunks
                     acts.append(act)
                 elif CHAIN_LOADER:
@@ -521,26 +525,58 @@ class _MLPChain(torch.autograd.Function):
         if ctx.layerwise:
             # the activated rows were kept (side outputs of the forward kernels): the layer-wise backward passes
             acts = saved[2 + 3 * L:2 + 3 * L + (L - 1)]
+            h = _lib.load()
+
+            def route(l):
+                """how layer l's backward runs: (kind, columns of the input gradient that are contracted)"""
+                C_, Kp_ = W2s[l].shape
+                pooled_ = bool(pool_ns) and l == L - 1
+                want_prev_ = l > 0 or ctx.needs_input_grad[0]
+                # the grouped rows' producer reads the gradient of the feature columns only: contract just those
+                cols_ = ctx.grad_cols if (l == 0 and ctx.grad_cols is not None and ctx.grad_cols[1] >= ROWS_GEMM_MIN_COLS) else None
+                ncol_ = cols_[1] if cols_ else Kp_
+                pow2 = pooled_ and pool_ns >= 64 and (pool_ns & (pool_ns - 1)) == 0
+                if (CHAIN_BWD_LOADER and (not pooled_ or (CHAIN_BWD_POOLED and pow2)) and want_prev_
+                        and h.tp3d_gemm_rows_bnbwd_sp_serves(M, ncol_, C_)):
+                    return "loader", cols_
+                if (WGRAD_NARROW and not pooled_ and not want_prev_ and ctx.needs_input_grad[4 + 3 * l] and l == 0
+                        and h.tp3d_gemm_tn_bn_narrow_serves(M, C_, Kp_)):
+                    return "narrow", cols_
+                return "passes", cols_
+
+            # consecutive big kernels walk the rows in opposite directions: each starts on the rows its predecessor touched
+            # last, which the memory-side cache (256 MB against 268 MB per activation matrix) still holds
+            turn = [True]  # the producer of grad_out wrote front to back
+
+            def direction():
+                rev_ = int(ROW_ORDER_ALTERNATE and turn[0])
+                turn[0] = not turn[0]
+                return rev_
+
+            def reduce_pass(l, dA_l):
+                """dbeta, dgamma, c1, c2 of layer l from the gradient of its activated (or pooled) output"""
+                C_ = W2s[l].shape[0]
+                pooled_ = bool(pool_ns) and l == L - 1
+                a_ptr_, ns_ = (_lib.ptr(arg), pool_ns) if pooled_ else (None, 1)
+                red_ = torch.empty((4, C_), dtype=torch.float32, device=dev)
+                ls_ = stats[l]
+                _lib.call("tp3d_bn_bwd_reduce_f32", _lib.ptr(dA_l), a_ptr_, _lib.ptr(Ys[l]), _lib.ptr(ls_[2]), _lib.ptr(ls_[3]),
+                          _lib.ptr(ls_[0]), _lib.ptr(ls_[1]), slopes[l], M, ns_, C_, int(training), _lib.ptr(red_[0]),
+                          _lib.ptr(red_[1]), _lib.ptr(red_[2]), _lib.ptr(red_[3]), _lib.ptr(_lib.bn_workspace(M, C_, dev)), direction(), st)
+                return red_
+
             with _lib.on_device(dev):
                 for l in range(L - 1, -1, -1):
                     Y, ls, W2, slope = Ys[l], stats[l], W2s[l], slopes[l]
                     C, Kp = W2.shape
                     pooled = bool(pool_ns) and l == L - 1
-                    dY = torch.empty_like(Y)
-                    ws = _lib.bn_workspace(M, C, dev)
-                    want_prev = l > 0 or ctx.needs_input_grad[0]
-                    # the grouped rows' producer reads the gradient of the feature columns only: contract just those
-                    cols = ctx.grad_cols if (l == 0 and ctx.grad_cols is not None and ctx.grad_cols[1] >= ROWS_GEMM_MIN_COLS) else None
+                    kind, cols = route(l)
                     ncol = cols[1] if cols else Kp
-                    pool_pow2 = pooled and pool_ns >= 64 and (pool_ns & (pool_ns - 1)) == 0
-                    if (CHAIN_BWD_LOADER and (not pooled or (CHAIN_BWD_POOLED and pool_pow2)) and want_prev
-                            and _lib.load().tp3d_gemm_rows_bnbwd_sp_serves(M, ncol, C)):
+                    if kind == "loader":
                         # reduction pass, then the input-gradient GEMM whose loader waves form dY (side output for dW)
-                        red = torch.empty((4, C), dtype=torch.float32, device=dev)  # dbeta, dgamma, c1, c2
+                        dY = torch.empty_like(Y)
                         a_ptr, ns = (_lib.ptr(arg), pool_ns) if pooled else (None, 1)
-                        _lib.call("tp3d_bn_bwd_reduce_f32", _lib.ptr(dcur), a_ptr, _lib.ptr(Y), _lib.ptr(ls[2]), _lib.ptr(ls[3]),
-                                  _lib.ptr(ls[0]), _lib.ptr(ls[1]), slope, M, ns, C, int(training), _lib.ptr(red[0]), _lib.ptr(red[1]),
-                                  _lib.ptr(red[2]), _lib.ptr(red[3]), _lib.ptr(ws), st)
+                        red = reduce_pass(l, dcur)
                         grads[3 * l + 1], grads[3 * l + 2] = red[1], red[0]
                         # dA_{l-1}[M,Kp] = dY_l[M,C] (W^T)[Kp,C]^T (a transposed copy of the weight: reading it as stored, four
                         # strided scalars per slot, made the loader waves the bottleneck -- 8.55 vs 8.32 ms/step)
@@ -556,29 +592,27 @@ class _MLPChain(torch.autograd.Function):
                         _lib.call("tp3d_gemm_rows_bnbwd_sp_f32", _lib.ptr(Y), _lib.ptr(dcur), _lib.ptr(ls[0]), _lib.ptr(ls[2]),
                                   _lib.ptr(ls[3]), _lib.ptr(red[2]), _lib.ptr(red[3]), slope, _lib.ptr(Wt), M, ncol, C,
                                   _lib.ptr(dprev) + 4 * c0, Kp, pad_lo_k, pad_hi_k,
-                                  _lib.ptr(dY) if ctx.needs_input_grad[4 + 3 * l] else None, a_ptr, ns, st)
+                                  _lib.ptr(dY) if ctx.needs_input_grad[4 + 3 * l] else None, a_ptr, ns, direction(), st)
                         if ctx.needs_input_grad[4 + 3 * l]:
-                            grads[3 * l] = _chain_wgrad(dY, l, A0, acts, Ys, stats, slopes)[:, :cins[l]].reshape(wshapes[l])
+                            grads[3 * l] = _chain_wgrad(dY, l, A0, acts, Ys, stats, slopes, direction())[:, :cins[l]].reshape(wshapes[l])
                         dcur = dprev
                         if l == 0:
                             dA0 = dprev
                         continue
-                    if (WGRAD_NARROW and not pooled and not want_prev and ctx.needs_input_grad[4 + 3 * l] and l == 0
-                            and _lib.load().tp3d_gemm_tn_bn_narrow_serves(M, C, Kp)):
+                    if kind == "narrow":
                         # the first layer of grouped rows (a handful of input channels, nobody reads their gradient): the
                         # reduction pass, then dW straight from (Y, dA, A0) -- dY is never written
-                        red = torch.empty((4, C), dtype=torch.float32, device=dev)  # dbeta, dgamma, c1, c2
-                        _lib.call("tp3d_bn_bwd_reduce_f32", _lib.ptr(dcur), None, _lib.ptr(Y), _lib.ptr(ls[2]), _lib.ptr(ls[3]),
-                                  _lib.ptr(ls[0]), _lib.ptr(ls[1]), slope, M, 1, C, int(training), _lib.ptr(red[0]),
-                                  _lib.ptr(red[1]), _lib.ptr(red[2]), _lib.ptr(red[3]), _lib.ptr(ws), st)
+                        red = reduce_pass(l, dcur)
                         grads[3 * l + 1], grads[3 * l + 2] = red[1], red[0]
                         dW = torch.empty((C, Kp), dtype=torch.float32, device=dev)
-                        nws = _lib.workspace("gemm_tn_narrow", 4 * _lib.load().tp3d_gemm_tn_bn_narrow_workspace_floats(M, C, Kp), dev)
+                        nws = _lib.workspace("gemm_tn_narrow", 4 * h.tp3d_gemm_tn_bn_narrow_workspace_floats(M, C, Kp), dev)
                         _lib.call("tp3d_gemm_tn_bn_narrow_f32", _lib.ptr(Y), _lib.ptr(dcur), _lib.ptr(ls[0]), _lib.ptr(ls[2]),
                                   _lib.ptr(ls[3]), _lib.ptr(red[2]), _lib.ptr(red[3]), slope, _lib.ptr(A0), M, C, Kp, _lib.ptr(dW),
                                   _lib.ptr(nws), st)
                         grads[3 * l] = dW[:, :cins[l]].reshape(wshapes[l])
                         continue
+                    dY = torch.empty_like(Y)
+                    ws = _lib.bn_workspace(M, C, dev)
                     dgb = torch.empty((2, C), dtype=torch.float32, device=dev)  # dbeta, dgamma
                     _lib.call("tp3d_bn_act_bwd_f32", _lib.ptr(dcur), _lib.ptr(arg) if pooled else None, _lib.ptr(Y), _lib.ptr(ls[2]),
                               _lib.ptr(ls[3]), _lib.ptr(ls[0]), _lib.ptr(ls[1]), slope, M, pool_ns if pooled else 1, C,
@@ -601,7 +635,7 @@ class _MLPChain(torch.autograd.Function):
                 ws = _lib.bn_workspace(M, C, dev)
                 _lib.call("tp3d_bn_bwd_reduce_f32", _lib.ptr(dcur), a_ptr, _lib.ptr(Y), _lib.ptr(ls[2]), _lib.ptr(ls[3]),
                           _lib.ptr(ls[0]), _lib.ptr(ls[1]), slope, M, ns, C, int(training), _lib.ptr(red[0]), _lib.ptr(red[1]),
-                          _lib.ptr(red[2]), _lib.ptr(red[3]), _lib.ptr(ws), st)
+                          _lib.ptr(red[2]), _lib.ptr(red[3]), _lib.ptr(ws), 0, st)
                 grads[3 * l + 1], grads[3 * l + 2] = red[1], red[0]
                 if ctx.needs_input_grad[4 + 3 * l]:
                     dW = torch.empty((C, Kp), dtype=torch.float32, device=dev)
@@ -639,6 +673,7 @@ def _chain_ok(rows, parts):
 
 
 CHAIN_BWD_POOLED = True  # ... also for the max-pooled last layer of a set-abstraction MLP (groups of 64, 128 ... rows)
+ROW_ORDER_ALTERNATE = True  # (experiment) consecutive big kernels walk the rows in opposite directions
 WGRAD_NARROW = True  # first layer of grouped rows (<= 16 input channels, no input gradient wanted): dW from (Y, dA, A0) in one
                      # streaming kernel (tp3d_gemm_tn_bn_narrow_f32) instead of the dY pass + the 64-column MFMA tile kernel
 CHAIN_BWD_LOADER = True  # the chain's input-gradient GEMMs form dY in their loader waves (else: apply pass + library GEMM)
