@@ -35,7 +35,7 @@ extern "C" {
 #define TP3D_E_UNSORTED (-3) /* reserved: batch vector not sorted (checked by the host wrapper) */
 #define TP3D_E_TOOBIG (-4)   /* size exceeds what the kernel's index arithmetic supports */
 
-#define TP3D_ABI_VERSION 31
+#define TP3D_ABI_VERSION 32
 
 int tp3d_abi_version(void);
 const char *tp3d_strerror(int code);
@@ -189,7 +189,7 @@ int tp3d_bn_bwd_reduce_f32(const float *dA, const int *argmax, const float *Y, c
 int tp3d_interp_concat_fwd_f32(const float *feat_cl, const int64_t *idx, const float *weight, const float *skip_cl,
                                int B, int m, int n, int C1, int C2, int ld, float *out, void *stream);
 
-/* `reverse` (tp3d_gemm_rows_bnact_sp_f32, tp3d_gemm_rows_bnact_x3_f32, tp3d_gemm_rows_bnbwd_sp_f32, tp3d_gemm_tn_x3_f32,
+/* `reverse` (tp3d_gemm_tn_bn_narrow_f32, tp3d_gemm_rows_bnact_sp_f32, tp3d_gemm_rows_bnact_x3_f32, tp3d_gemm_rows_bnbwd_sp_f32, tp3d_gemm_tn_x3_f32,
  * tp3d_gemm_tn_x3_act_f32, tp3d_bn_bwd_reduce_f32): 1 = walk the row blocks of the (M, .) operands last to first.  The result
  * is the same set of products / sums (the contractions over rows sum their blocks in the walked order: reproducible per
  * direction, the two directions differ by rounding).  A chain of kernels over 268 MB activation matrices alternates the
@@ -272,7 +272,7 @@ int tp3d_gemm_tn_bn_narrow_serves(int64_t M, int N, int K);
 size_t tp3d_gemm_tn_bn_narrow_workspace_floats(int64_t M, int N, int K);
 int tp3d_gemm_tn_bn_narrow_f32(const float *Y, const float *dA, const float *mean_n, const float *scale_n,
                                const float *beta_n, const float *c1_n, const float *c2_n, float slope_n, const float *A,
-                               int64_t M, int N, int K, float *out, float *workspace, void *stream);
+                               int64_t M, int N, int K, float *out, float *workspace, int reverse, void *stream);
 
 /* Weight gradient of a 1x1 conv / shared-MLP layer:  out[n,k] = sum_r dY[r,n] * A[r,k]
  * dY (M,N), A (M,K) row-major -> out (N,K); rows split over the grid, fp32 MFMA, fixed-order reduction of the

@@ -755,10 +755,14 @@ def test_narrow_first_layer_weight_gradient_from_y_and_da(M, N, K):
     for _ in range(2):
         dW = torch.full((N, K), float("nan"), device=DEV)
         _lib.call("tp3d_gemm_tn_bn_narrow_f32", _lib.ptr(Y), _lib.ptr(dA), _lib.ptr(mean), _lib.ptr(scale), _lib.ptr(beta),
-                  _lib.ptr(red[2]), _lib.ptr(red[3]), 0.01, _lib.ptr(A), M, N, K, _lib.ptr(dW), _lib.ptr(nws), st)
+                  _lib.ptr(red[2]), _lib.ptr(red[3]), 0.01, _lib.ptr(A), M, N, K, _lib.ptr(dW), _lib.ptr(nws), 0, st)
         outs.append(dW)
+    rev = torch.full((N, K), float("nan"), device=DEV)  # last rows first: the same row splits, each in its slot -- bit for bit
+    _lib.call("tp3d_gemm_tn_bn_narrow_f32", _lib.ptr(Y), _lib.ptr(dA), _lib.ptr(mean), _lib.ptr(scale), _lib.ptr(beta),
+              _lib.ptr(red[2]), _lib.ptr(red[3]), 0.01, _lib.ptr(A), M, N, K, _lib.ptr(rev), _lib.ptr(nws), 1, st)
+    outs.append(rev)
     torch.cuda.synchronize()
-    assert torch.equal(outs[0], outs[1])
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
     yc = Y.double() - mean.double()
     dz = dA.double() * torch.where(yc * scale.double() + beta.double() > 0, 1.0, 0.01)
     dY64 = scale.double() * ((dz - red[2].double()) - yc * red[3].double())

@@ -24,7 +24,7 @@ __global__ __launch_bounds__(TNN_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4)
     const float *__restrict__ Y, const float *__restrict__ dA, const float *__restrict__ A, const float *__restrict__ mean,
     const float *__restrict__ scale, const float *__restrict__ beta, const float *__restrict__ c1,
     const float *__restrict__ c2, float slope, int64_t M, int N, int nv_shift, int64_t rows_per_split,
-    float *__restrict__ partial)
+    float *__restrict__ partial, int reverse)
 {
     constexpr int K = 4 * KQ;
     __shared__ float red[TNN_WAVES - 1][TNN_NMAX * K];
@@ -35,7 +35,8 @@ __global__ __launch_bounds__(TNN_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4)
     const float4 mu = *reinterpret_cast<const float4 *>(mean + 4 * cq), sc = *reinterpret_cast<const float4 *>(scale + 4 * cq);
     const float4 be = *reinterpret_cast<const float4 *>(beta + 4 * cq), k1 = *reinterpret_cast<const float4 *>(c1 + 4 * cq);
     const float4 k2 = *reinterpret_cast<const float4 *>(c2 + 4 * cq);
-    const int64_t r0 = (int64_t)blockIdx.x * rows_per_split;
+    const int split = reverse ? (int)(gridDim.x - 1 - blockIdx.x) : (int)blockIdx.x;  // (last rows first: include/tp3d_hip.h)
+    const int64_t r0 = (int64_t)split * rows_per_split;
     const int64_t r1 = min(r0 + rows_per_split, M);
     float acc[4][K];
 #pragma unroll
@@ -90,7 +91,7 @@ __global__ __launch_bounds__(TNN_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4)
     }
     __syncthreads();
     if (w == 0 && rsub == 0) {
-        float *out = partial + ((size_t)blockIdx.x * N + 4 * cq) * K;
+        float *out = partial + ((size_t)split * N + 4 * cq) * K;
 #pragma unroll
         for (int c = 0; c < 4; ++c)
 #pragma unroll
@@ -138,7 +139,7 @@ TP3D_EXPORT size_t tp3d_gemm_tn_bn_narrow_workspace_floats(int64_t M, int N, int
 TP3D_EXPORT int tp3d_gemm_tn_bn_narrow_f32(const float *Y, const float *dA, const float *mean_n, const float *scale_n,
                                            const float *beta_n, const float *c1_n, const float *c2_n, float slope_n,
                                            const float *A, int64_t M, int N, int K, float *out, float *workspace,
-                                           void *stream)
+                                           int reverse, void *stream)
 {
     if (!tp3d_gemm_tn_bn_narrow_serves(M, N, K) || !out) return TP3D_E_BADARG;
     if (!Y || !dA || !mean_n || !scale_n || !beta_n || !c1_n || !c2_n || !A || !workspace) return TP3D_E_BADARG;
@@ -150,7 +151,7 @@ TP3D_EXPORT int tp3d_gemm_tn_bn_narrow_f32(const float *Y, const float *dA, cons
     while ((4 << nv_shift) < N) ++nv_shift;
 #define TP3D_TNN(KQ_)                                                                                                  \
     hipLaunchKernelGGL((gemm_tn_narrow_bn_kernel<KQ_>), grid, dim3(TNN_BLOCK), 0, s, Y, dA, A, mean_n, scale_n, beta_n, c1_n, \
-                       c2_n, slope_n, M, N, nv_shift, rps, workspace)
+                       c2_n, slope_n, M, N, nv_shift, rps, workspace, reverse)
     switch (K / 4) {
     case 1: TP3D_TNN(1); break;
     case 2: TP3D_TNN(2); break;

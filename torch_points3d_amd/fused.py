@@ -424,6 +424,7 @@ class _MLPChain(torch.autograd.Function):
         # under torch.no_grad() the parameters still report requires_grad: no side outputs for a backward that cannot come
         keep_acts = CHAIN_LOADER and _outer_grad and any(ctx.needs_input_grad)
         h = _lib.load()
+        prev_rev = 0  # the producer of A0 wrote front to back
         with _lib.on_device(dev):
             for l, (bn, slope) in enumerate(layers):
                 weight, gamma, beta = params[3 * l], params[3 * l + 1], params[3 * l + 2]
@@ -446,7 +447,8 @@ class _MLPChain(torch.autograd.Function):
                     sp_entry = "tp3d_gemm_rows_bnact_x3_f32"  # the same contraction as bf16 term pairs on the matrix pipe
                 # alternate the direction the row blocks are walked in, layer by layer: a layer starts where the previous one
                 # (or the producer of A0, front to back) ended, on the rows the memory-side cache still holds
-                rev = int(ROW_ORDER_ALTERNATE and l % 2 == 0)
+                rev = int(ROW_ORDER_ALTERNATE and not prev_rev)  # (used by the kernels that take a direction; the others walk
+                prev_rev = rev                                   # front to back -- corrected below)
                 chunks = None
                 x3_first = h.tp3d_gemm_rows_x3_chunks(M, Cout, Kp, 0) if (l == 0 and FWD_X3 and CHAIN_LOADER) else 0
                 if x3_first:
@@ -460,6 +462,7 @@ class _MLPChain(torch.autograd.Function):
                 elif l == 0:
                     part = _lib.workspace("gemm_rows_stats", 4 * h.tp3d_gemm_rows_stat_floats(M, Cout), dev) if training else None
                     _lib.call("tp3d_gemm_rows_f32", _lib.ptr(A0), _lib.ptr(W2), M, Cout, Kp, _lib.ptr(Y), _lib.ptr(part), None, st)
+                    prev_rev = 0
                 elif sp_chunks:
                     # the previous layer's BatchNorm + activation in the loader waves of the split-role kernel; with a
                     # backward pass to come, the activated rows leave as a side output of the same kernel
@@ -479,11 +482,13 @@ class _MLPChain(torch.autograd.Function):
                     part = _lib.workspace("gemm_rows_stats", 4 * h.tp3d_gemm_rows_stat_floats(M, Cout), dev) if training else None
                     _lib.call("tp3d_gemm_rows_f32", _lib.ptr(act), _lib.ptr(W2), M, Cout, Kp, _lib.ptr(Y), _lib.ptr(part), None, st)
                     acts.append(act if keep_act else None)
+                    prev_rev = 0
                 else:
                     ps = stats[-1]
                     part = _lib.workspace("gemm_rows_stats", 4 * h.tp3d_gemm_rows_stat_floats(M, Cout), dev) if training else None
                     _lib.call("tp3d_gemm_rows_bnact_f32", _lib.ptr(Ys[-1]), _lib.ptr(ps[0]), _lib.ptr(ps[2]), _lib.ptr(ps[3]),
                               layers[l - 1][1], _lib.ptr(W2), M, Cout, Kp, _lib.ptr(Y), _lib.ptr(part), st)
+                    prev_rev = 0
                 if training:
                     stats.append(_finalize_stats(part, M, Cout, gamma, beta, bn, dev, st, chunks))
                 else:
@@ -608,7 +613,7 @@ class _MLPChain(torch.autograd.Function):
                         nws = _lib.workspace("gemm_tn_narrow", 4 * h.tp3d_gemm_tn_bn_narrow_workspace_floats(M, C, Kp), dev)
                         _lib.call("tp3d_gemm_tn_bn_narrow_f32", _lib.ptr(Y), _lib.ptr(dcur), _lib.ptr(ls[0]), _lib.ptr(ls[2]),
                                   _lib.ptr(ls[3]), _lib.ptr(red[2]), _lib.ptr(red[3]), slope, _lib.ptr(A0), M, C, Kp, _lib.ptr(dW),
-                                  _lib.ptr(nws), st)
+                                  _lib.ptr(nws), direction(), st)
                         grads[3 * l] = dW[:, :cins[l]].reshape(wshapes[l])
                         continue
                     dY = torch.empty_like(Y)
