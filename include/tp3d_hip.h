@@ -35,7 +35,7 @@ extern "C" {
 #define TP3D_E_UNSORTED (-3) /* reserved: batch vector not sorted (checked by the host wrapper) */
 #define TP3D_E_TOOBIG (-4)   /* size exceeds what the kernel's index arithmetic supports */
 
-#define TP3D_ABI_VERSION 32
+#define TP3D_ABI_VERSION 33
 
 int tp3d_abi_version(void);
 const char *tp3d_strerror(int code);
@@ -189,7 +189,7 @@ int tp3d_bn_bwd_reduce_f32(const float *dA, const int *argmax, const float *Y, c
 int tp3d_interp_concat_fwd_f32(const float *feat_cl, const int64_t *idx, const float *weight, const float *skip_cl,
                                int B, int m, int n, int C1, int C2, int ld, float *out, void *stream);
 
-/* `reverse` (tp3d_gemm_tn_bn_narrow_f32, tp3d_gemm_rows_bnact_sp_f32, tp3d_gemm_rows_bnact_x3_f32, tp3d_gemm_rows_bnbwd_sp_f32, tp3d_gemm_tn_x3_f32,
+/* `reverse` (tp3d_gemm_rows_narrow_f32, tp3d_gemm_tn_bn_narrow_f32, tp3d_gemm_rows_bnact_sp_f32, tp3d_gemm_rows_bnact_x3_f32, tp3d_gemm_rows_bnbwd_sp_f32, tp3d_gemm_tn_x3_f32,
  * tp3d_gemm_tn_x3_act_f32, tp3d_bn_bwd_reduce_f32): 1 = walk the row blocks of the (M, .) operands last to first.  The result
  * is the same set of products / sums (the contractions over rows sum their blocks in the walked order: reproducible per
  * direction, the two directions differ by rounding).  A chain of kernels over 268 MB activation matrices alternates the
@@ -269,6 +269,13 @@ int tp3d_bn_finalize_f32(float *partial, int chunks, int64_t M, int C, float eps
  * workspace: tp3d_gemm_tn_bn_narrow_workspace_floats(M, N, K) floats.
  * Autograd of Conv2d -> BatchNorm2d -> LeakyReLU (core/common_modules/dense_modules.py:25-29). */
 int tp3d_gemm_tn_bn_narrow_serves(int64_t M, int N, int K);
+/* The forward contraction of such a layer (same shape rule):  Y (M,N) = A (M,K) W (N,K)^T, k ascending per output, one
+ * streaming pass (4 M (N + K) bytes: write-dominated; the MFMA tile kernel pads K to its 32-wide step and runs at 3 TB/s).
+ * stat_partial != NULL: tp3d_gemm_rows_narrow_chunks(M) chunks of [4][N] floats (sum d, sum d^2, shift, rows) in the layout
+ * tp3d_bn_finalize_f32 folds.  Conv2d 1x1 bias=False of core/common_modules/dense_modules.py:25-29. */
+int tp3d_gemm_rows_narrow_chunks(int64_t M);
+int tp3d_gemm_rows_narrow_f32(const float *A, const float *W, int64_t M, int N, int K, float *Y, float *stat_partial,
+                              int reverse, void *stream);
 size_t tp3d_gemm_tn_bn_narrow_workspace_floats(int64_t M, int N, int K);
 int tp3d_gemm_tn_bn_narrow_f32(const float *Y, const float *dA, const float *mean_n, const float *scale_n,
                                const float *beta_n, const float *c1_n, const float *c2_n, float slope_n, const float *A,

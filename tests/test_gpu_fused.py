@@ -781,6 +781,42 @@ def test_narrow_first_layer_weight_gradient_from_y_and_da(M, N, K):
     assert float(((outs[0] - two).abs().double() / mag).max()) < 1e-6
 
 
+@pytest.mark.parametrize("M,N,K", [(1048576, 64, 8), (70001, 64, 8), (33000, 128, 16), (40000, 16, 4), (300, 64, 12), (5000, 256, 8), (777, 4, 4)])
+def test_narrow_first_layer_forward_contraction_and_its_statistics(M, N, K):
+    """tp3d_gemm_rows_narrow_f32: Y = A W^T against float64 (1e-5 of the scale: k ascending, fp32 FMA) and against the MFMA
+    rows kernel; the statistics chunks finalize to the mean / variance of the output; both directions bit for bit."""
+    from torch_points3d_amd import _lib, fused
+    h = _lib.load()
+    g = torch.Generator().manual_seed(M + N + K)
+    A = (torch.randn(M, K, generator=g) + 0.3).to(DEV)
+    W = (torch.randn(N, K, generator=g) * 0.4).to(DEV)
+    st = _lib.stream_ptr(A.device)
+    chunks = h.tp3d_gemm_rows_narrow_chunks(M)
+    assert 1 <= chunks <= 1024
+    outs = []
+    for rev in (0, 1):
+        Y = torch.full((M, N), float("nan"), device=DEV)
+        part = torch.full((chunks * 4 * N,), float("nan"), device=DEV)
+        _lib.call("tp3d_gemm_rows_narrow_f32", _lib.ptr(A), _lib.ptr(W), M, N, K, _lib.ptr(Y), _lib.ptr(part), rev, st)
+        outs.append((Y, part.clone()))
+    plain = torch.full((M, N), float("nan"), device=DEV)
+    _lib.call("tp3d_gemm_rows_narrow_f32", _lib.ptr(A), _lib.ptr(W), M, N, K, _lib.ptr(plain), None, 0, st)
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]) and torch.equal(plain, outs[0][0])
+    want = A.double() @ W.double().t()
+    mag = A.double().abs() @ W.double().abs().t()
+    assert float(((outs[0][0].double() - want).abs() / mag).max()) < 1e-6
+    ref = fused.gemm_rows(A, W)[0]
+    torch.testing.assert_close(outs[0][0], ref, rtol=1e-5, atol=1e-5 * float(want.abs().max()))
+    bn = torch.nn.BatchNorm1d(N).to(DEV)
+    stats = fused._finalize_stats(outs[0][1], M, N, bn.weight.detach(), bn.bias.detach(), bn, A.device, st, chunks)
+    torch.cuda.synchronize()
+    o64 = outs[0][0].double()
+    std = o64.std(0, unbiased=False)
+    assert float(((stats[0].double() - o64.mean(0)).abs() / std).max()) < 1e-5
+    torch.testing.assert_close(stats[1].double(), 1.0 / torch.sqrt(o64.var(0, unbiased=False) + bn.eps), rtol=2e-5, atol=0)
+
+
 def test_chain_contracts_only_the_feature_columns_of_grouped_rows():
     """Grouped rows are [relative position (3), features (C), padding]; their producer reads the gradient of the feature
     columns only, and the chain's first input-gradient GEMM computes just those (the rest stays zero): the gradient that

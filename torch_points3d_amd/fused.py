@@ -459,6 +459,11 @@ class _MLPChain(torch.autograd.Function):
                     _lib.call("tp3d_gemm_rows_bnact_x3_f32", _lib.ptr(A0), _lib.ptr(ident[0]), _lib.ptr(ident[1]), _lib.ptr(ident[0]),
                               1.0, _lib.ptr(W2), M, Cout, Kp, _lib.ptr(Y), _lib.ptr(part), None, rev, st)
                     chunks = x3_first
+                elif l == 0 and FWD_NARROW and h.tp3d_gemm_tn_bn_narrow_serves(M, Cout, Kp):
+                    # a handful of input channels (grouped rows: relative position + features): the streaming kernel
+                    chunks = h.tp3d_gemm_rows_narrow_chunks(M)
+                    part = _lib.workspace("gemm_rows_stats", 16 * chunks * Cout, dev) if training else None
+                    _lib.call("tp3d_gemm_rows_narrow_f32", _lib.ptr(A0), _lib.ptr(W2), M, Cout, Kp, _lib.ptr(Y), _lib.ptr(part), rev, st)
                 elif l == 0:
                     part = _lib.workspace("gemm_rows_stats", 4 * h.tp3d_gemm_rows_stat_floats(M, Cout), dev) if training else None
                     _lib.call("tp3d_gemm_rows_f32", _lib.ptr(A0), _lib.ptr(W2), M, Cout, Kp, _lib.ptr(Y), _lib.ptr(part), None, st)
@@ -678,9 +683,10 @@ def _chain_ok(rows, parts):
 
 
 CHAIN_BWD_POOLED = True  # ... also for the max-pooled last layer of a set-abstraction MLP (groups of 64, 128 ... rows)
-ROW_ORDER_ALTERNATE = True  # (experiment) consecutive big kernels walk the rows in opposite directions
+ROW_ORDER_ALTERNATE = True  # consecutive big kernels of a chain walk the rows in opposite directions (`reverse`, tp3d_hip.h)
 WGRAD_NARROW = True  # first layer of grouped rows (<= 16 input channels, no input gradient wanted): dW from (Y, dA, A0) in one
                      # streaming kernel (tp3d_gemm_tn_bn_narrow_f32) instead of the dY pass + the 64-column MFMA tile kernel
+FWD_NARROW = True    # ... and its forward contraction (tp3d_gemm_rows_narrow_f32) instead of the MFMA tile kernel
 CHAIN_BWD_LOADER = True  # the chain's input-gradient GEMMs form dY in their loader waves (else: apply pass + library GEMM)
 CHAIN_LOADER = True    # hidden layers' BatchNorm + activation in the loader waves of the split-role GEMM, activated rows as
                        # its side output, layer-wise backward (else: the prologue / backward-fused variants in the MFMA waves)
