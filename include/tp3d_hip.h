@@ -35,7 +35,7 @@ extern "C" {
 #define TP3D_E_UNSORTED (-3) /* reserved: batch vector not sorted (checked by the host wrapper) */
 #define TP3D_E_TOOBIG (-4)   /* size exceeds what the kernel's index arithmetic supports */
 
-#define TP3D_ABI_VERSION 33
+#define TP3D_ABI_VERSION 34
 
 int tp3d_abi_version(void);
 const char *tp3d_strerror(int code);
@@ -189,7 +189,7 @@ int tp3d_bn_bwd_reduce_f32(const float *dA, const int *argmax, const float *Y, c
 int tp3d_interp_concat_fwd_f32(const float *feat_cl, const int64_t *idx, const float *weight, const float *skip_cl,
                                int B, int m, int n, int C1, int C2, int ld, float *out, void *stream);
 
-/* `reverse` (tp3d_gemm_rows_narrow_f32, tp3d_gemm_tn_bn_narrow_f32, tp3d_gemm_rows_bnact_sp_f32, tp3d_gemm_rows_bnact_x3_f32, tp3d_gemm_rows_bnbwd_sp_f32, tp3d_gemm_tn_x3_f32,
+/* `reverse` (tp3d_gemm_tn_x3_act_red_f32, tp3d_gemm_rows_narrow_f32, tp3d_gemm_tn_bn_narrow_f32, tp3d_gemm_rows_bnact_sp_f32, tp3d_gemm_rows_bnact_x3_f32, tp3d_gemm_rows_bnbwd_sp_f32, tp3d_gemm_tn_x3_f32,
  * tp3d_gemm_tn_x3_act_f32, tp3d_bn_bwd_reduce_f32): 1 = walk the row blocks of the (M, .) operands last to first.  The result
  * is the same set of products / sums (the contractions over rows sum their blocks in the walked order: reproducible per
  * direction, the two directions differ by rounding).  A chain of kernels over 268 MB activation matrices alternates the
@@ -307,6 +307,17 @@ int tp3d_gemm_tn_x3_f32(const float *dY, const float *A, int64_t M, int N, int K
  * activated rows -- which the forward pass then need not write. */
 int tp3d_gemm_tn_x3_act_f32(const float *dY, const float *Yp, const float *mean_k, const float *scale_k, const float *beta_k,
                             float slope_k, int64_t M, int N, int K, int terms, float *out, float *workspace, int reverse, void *stream);
+/* ... and, from one more operand stream, the BatchNorm-backward REDUCTIONS of the layer Yp belongs to: dA_k (M,K) is the
+ * gradient of that layer's activated output, invstd_k (K) its statistics row; red_out (4,K) = dbeta, dgamma,
+ * c1 = dbeta / M, c2 = invstd * dgamma / M (zero with training == 0) -- what tp3d_bn_bwd_reduce_f32(dA_k, Yp) returns,
+ * without that pass (its 8 M K bytes become 4 M K here: Yp is already streaming through this kernel's loader waves).
+ * tp3d_gemm_tn_x3_red_chunks(M,N,K): 0 = shape not served (needs one tile column: K <= 128, N > 64), else the chunks of
+ * [2][K] floats red_workspace must hold.  terms == 6. */
+int tp3d_gemm_tn_x3_red_chunks(int64_t M, int N, int K);
+int tp3d_gemm_tn_x3_act_red_f32(const float *dY, const float *Yp, const float *mean_k, const float *scale_k,
+                                const float *beta_k, const float *invstd_k, float slope_k, const float *dA_k, int training,
+                                int64_t M, int N, int K, int terms, float *out, float *workspace, float *red_out,
+                                float *red_workspace, int reverse, void *stream);
 /* The same weight gradient with both operands formed while they are staged, so that neither the BatchNorm-backward
  * result dY nor the activated layer input has to exist in HBM (autograd of dense_modules.py:25-29):
  *   dY = scale_n*(dZ - c1_n - (Y - mean_n)*c2_n), dZ = dA * act'((Y - mean_n)*scale_n + beta_n)

@@ -817,6 +817,56 @@ def test_narrow_first_layer_forward_contraction_and_its_statistics(M, N, K):
     torch.testing.assert_close(stats[1].double(), 1.0 / torch.sqrt(o64.var(0, unbiased=False) + bn.eps), rtol=2e-5, atol=0)
 
 
+@pytest.mark.parametrize("M,N,K", [(131072, 128, 128), (140001, 128, 64), (262144, 256, 128), (150016, 128, 112)])
+@pytest.mark.parametrize("reverse", [0, 1])
+def test_weight_gradient_kernel_also_reduces_the_layer_below(M, N, K, reverse):
+    """tp3d_gemm_tn_x3_act_red_f32: dW bit for bit the plain activated-operand form's; dbeta / dgamma / c1 / c2 of the
+    layer below against float64 and against tp3d_bn_bwd_reduce_f32 on the same (dA, Yp); eval-mode: c1 = c2 = 0."""
+    from torch_points3d_amd import _lib, fused
+    h = _lib.load()
+    chunks = h.tp3d_gemm_tn_x3_red_chunks(M, N, K)
+    assert chunks > 0 and h.tp3d_gemm_tn_x3_red_chunks(M, N, 160) == 0 and h.tp3d_gemm_tn_x3_red_chunks(M, 64, 128) == 0
+    g = torch.Generator().manual_seed(M + N + K)
+    dY = torch.randn(M, N, generator=g).to(DEV)
+    Yp = (torch.randn(M, K, generator=g) * 1.5 + 0.2).to(DEV)
+    dA = torch.randn(M, K, generator=g).to(DEV)
+    gamma, beta = (torch.rand(K, generator=g) + 0.5).to(DEV), (torch.randn(K, generator=g) * 0.3).to(DEV)
+    mean = Yp.mean(0)
+    invstd = 1.0 / torch.sqrt(Yp.var(0, unbiased=False) + 1e-5)
+    scale = gamma * invstd
+    st = _lib.stream_ptr(dY.device)
+    plain = fused.gemm_tn(dY, Yp, act=(mean, scale, beta, 0.01), reverse=reverse)
+    ws = _lib.gemm_tn_workspace(M, N, K, dY.device, x3=True)
+    rws = torch.full((chunks * 2 * K,), float("nan"), device=DEV)
+    out = torch.full((N, K), float("nan"), device=DEV)
+    red = torch.full((4, K), float("nan"), device=DEV)
+    _lib.call("tp3d_gemm_tn_x3_act_red_f32", _lib.ptr(dY), _lib.ptr(Yp), _lib.ptr(mean), _lib.ptr(scale), _lib.ptr(beta), _lib.ptr(invstd),
+              0.01, _lib.ptr(dA), 1, M, N, K, 6, _lib.ptr(out), _lib.ptr(ws), _lib.ptr(red), _lib.ptr(rws), reverse, st)
+    torch.cuda.synchronize()
+    assert torch.equal(out, plain)
+    assert bool(torch.isfinite(rws).all())
+    yc = Yp.double() - mean.double()
+    # (the side of the activation's kink decided in fp32, in the kernels' operation order: with 10^7 elements a few z
+    #  round to the other side of zero in float64, and one flipped row moves a column sum by ~|dA|)
+    positive = ((Yp - mean) * scale + beta) > 0
+    dz = dA.double() * torch.where(positive, 1.0, 0.01)
+    xh = yc * invstd.double()
+    want = torch.stack([dz.sum(0), (dz * xh).sum(0)])
+    mag = torch.stack([dz.abs().sum(0), (dz * xh).abs().sum(0)])
+    assert float(((red[:2].double() - want).abs() / mag).max()) < 1e-6
+    sep = torch.empty(4, K, device=DEV)
+    bws = _lib.bn_workspace(M, K, dY.device)
+    _lib.call("tp3d_bn_bwd_reduce_f32", _lib.ptr(dA), None, _lib.ptr(Yp), _lib.ptr(scale), _lib.ptr(beta), _lib.ptr(mean), _lib.ptr(invstd),
+              0.01, M, 1, K, 1, _lib.ptr(sep[0]), _lib.ptr(sep[1]), _lib.ptr(sep[2]), _lib.ptr(sep[3]), _lib.ptr(bws), 0, st)
+    assert float(((red[:2] - sep[:2]).double().abs() / mag).max()) < 1e-6
+    torch.testing.assert_close(red[2], red[0] / M, rtol=1e-6, atol=0)
+    torch.testing.assert_close(red[3], invstd * (red[1] / M), rtol=1e-6, atol=0)
+    _lib.call("tp3d_gemm_tn_x3_act_red_f32", _lib.ptr(dY), _lib.ptr(Yp), _lib.ptr(mean), _lib.ptr(scale), _lib.ptr(beta), _lib.ptr(invstd),
+              0.01, _lib.ptr(dA), 0, M, N, K, 6, _lib.ptr(out), _lib.ptr(ws), _lib.ptr(red), _lib.ptr(rws), reverse, st)
+    torch.cuda.synchronize()
+    assert float(red[2:].abs().max()) == 0.0 and torch.equal(out, plain)
+
+
 def test_chain_contracts_only_the_feature_columns_of_grouped_rows():
     """Grouped rows are [relative position (3), features (C), padding]; their producer reads the gradient of the feature
     columns only, and the chain's first input-gradient GEMM computes just those (the rest stays zero): the gradient that

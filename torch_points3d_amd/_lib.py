@@ -39,6 +39,7 @@ SIGNATURES = {
     "tp3d_gemm_tn_f32": [_p, _p, _l, _i, _i, _p, _p, _p],
     "tp3d_gemm_tn_x3_f32": [_p, _p, _l, _i, _i, _i, _p, _p, _i, _p],
     "tp3d_gemm_tn_x3_act_f32": [_p, _p, _p, _p, _p, _f, _l, _i, _i, _i, _p, _p, _i, _p],
+    "tp3d_gemm_tn_x3_act_red_f32": [_p, _p, _p, _p, _p, _p, _f, _p, _i, _l, _i, _i, _i, _p, _p, _p, _p, _i, _p],
     "tp3d_gemm_tn_bn_f32": [_p, _p, _p, _i, _p, _p, _p, _p, _p, _f, _p, _p, _p, _p, _f, _l, _i, _i, _p, _p, _p],
     "tp3d_gemm_rows_narrow_f32": [_p, _p, _l, _i, _i, _p, _p, _i, _p],
     "tp3d_gemm_tn_bn_narrow_f32": [_p, _p, _p, _p, _p, _p, _p, _f, _p, _l, _i, _i, _p, _p, _i, _p],
@@ -76,9 +77,9 @@ SIGNATURES = {
     "tp3d_scatter_plan": [_i, _i, _i, _i, _p],
 }
 MISC = ("tp3d_abi_version", "tp3d_strerror", "tp3d_last_hip_error", "tp3d_scatter_workspace_bytes",
-        "tp3d_bn_workspace_floats", "tp3d_gemm_tn_workspace_floats", "tp3d_gemm_tn_x3_workspace_floats", "tp3d_gemm_tn_x3_serves", "tp3d_ball_query_workspace_bytes",
+        "tp3d_bn_workspace_floats", "tp3d_gemm_tn_workspace_floats", "tp3d_gemm_tn_x3_workspace_floats", "tp3d_gemm_tn_x3_serves", "tp3d_gemm_tn_x3_red_chunks", "tp3d_ball_query_workspace_bytes",
         "tp3d_gemm_rows_stat_floats", "tp3d_gemm_rows_stat_chunks", "tp3d_gemm_rows_sp_chunks", "tp3d_gemm_rows_x3_chunks", "tp3d_gemm_rows_bnbwd_sp_serves", "tp3d_gemm_tn_bn_narrow_serves", "tp3d_gemm_rows_narrow_chunks", "tp3d_gemm_tn_bn_narrow_workspace_floats", "tp3d_gemm_rows_workspace_floats", "tp3d_kpconv_bwd_workspace_bytes", "tp3d_voxel_workspace_bytes", "tp3d_knn_workspace_bytes", "tp3d_kpconv_grad_workspace_bytes")
-ABI_VERSION = 33
+ABI_VERSION = 34
 
 _handle = None
 
@@ -120,6 +121,8 @@ def load():
     h.tp3d_gemm_tn_x3_workspace_floats.argtypes = [_l, _i, _i]
     h.tp3d_gemm_tn_x3_serves.restype = ctypes.c_int
     h.tp3d_gemm_tn_x3_serves.argtypes = [_l, _i, _i]
+    h.tp3d_gemm_tn_x3_red_chunks.restype = ctypes.c_int
+    h.tp3d_gemm_tn_x3_red_chunks.argtypes = [_l, _i, _i]
     h.tp3d_kpconv_bwd_workspace_bytes.restype = ctypes.c_size_t
     h.tp3d_kpconv_bwd_workspace_bytes.argtypes = [_l, _l]
     h.tp3d_gemm_rows_stat_floats.restype = ctypes.c_size_t

@@ -60,21 +60,27 @@ struct X3Prologue {
     const float *mean, *scale, *beta;
     float slope;
     int reverse;  // walk the row blocks last to first (start on the rows the kernel before this one touched last)
+    // RED: the BatchNorm-backward REDUCTIONS of the layer whose pre-BatchNorm output Yp this kernel's loader waves already
+    // stream -- sum dZ and sum dZ * yhat per column k, dZ = dA * act'(z) -- from one more operand stream, dA (M, K), the
+    // gradient of that layer's activated output: the separate pass read Yp again.  One chunk [2][K] per workgroup.
+    const float *dA, *invstd;
+    float *red_partial;
 };
 
-template <int WM, int WN, bool STRIP, int BR, int TERMS>
+template <int WM, int WN, bool STRIP, int BR, int TERMS, bool RED = false>
 __global__ __launch_bounds__(X3_BLOCK) void gemm_tn_x3_kernel(const float *__restrict__ dY, const float *__restrict__ A,
                                                               int64_t M, int N, int K, int64_t rows_per_split,
                                                               int tiles_k, float *__restrict__ partial /*[S][N][K]*/,
                                                               X3Prologue pro)
 {
     static_assert(!STRIP || WM == 2, "the strip is one block per wave of a 128-row tile");
+    static_assert(!(RED && STRIP), "the reductions ride on the plain tiles (one tile column: every workgroup sees all K columns)");
     constexpr int TN = 64 * WM, TK = 64 * WN, TKS = TK + (STRIP ? 32 : 0);
     constexpr int PN = x3_pitch(TN), PK = x3_pitch(TKS);
     constexpr int PLANE_N = BR * PN, PLANE_K = BR * PK;   // halfwords
     constexpr int BUF = 3 * PLANE_N + 3 * PLANE_K;
     extern __shared__ __attribute__((aligned(16))) unsigned short smem[];
-    __shared__ __attribute__((aligned(16))) float sK[3][TKS];  // mean, scale, beta of the tile's k columns (zero past K)
+    __shared__ __attribute__((aligned(16))) float sK[RED ? 4 : 3][TKS];  // mean, scale, beta (, invstd) of the tile's k columns (zero past K)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int tile = blockIdx.x;
@@ -86,6 +92,7 @@ __global__ __launch_bounds__(X3_BLOCK) void gemm_tn_x3_kernel(const float *__res
             sK[0][c] = in ? pro.mean[k0 + c] : 0.0f;
             sK[1][c] = in ? pro.scale[k0 + c] : 0.0f;
             sK[2][c] = in ? pro.beta[k0 + c] : 0.0f;
+            if (RED) sK[3][c] = in ? pro.invstd[k0 + c] : 0.0f;
         }
         __syncthreads();  // (before the roles part: every wave passes here once)
     }
@@ -107,6 +114,11 @@ __global__ __launch_bounds__(X3_BLOCK) void gemm_tn_x3_kernel(const float *__res
         static_assert(SY >= 1 && SA >= 1 && SY * 256 == BR * (TN / 4) && SA * 256 == BR * (TK / 4), "whole float4 slots per thread");
         static_assert(!STRIP || SS * 256 == BR * 8, "whole strip slots per thread");
         float4 ry0[SY], ra0[SA], rs0[STRIP ? SS : 1], ry1[SY], ra1[SA], rs1[STRIP ? SS : 1], ry2[SY], ra2[SA], rs2[STRIP ? SS : 1];
+        float4 rd0[RED ? SA : 1], rd1[RED ? SA : 1], rd2[RED ? SA : 1];  // RED: the dA rows under the A rows
+        float red1[4] = {0.f, 0.f, 0.f, 0.f}, red2[4] = {0.f, 0.f, 0.f, 0.f};  // this thread's four columns (the same in every slot)
+        // the row blocks of a step are reduced by ONE of the tile rows' workgroups (they all stream the same A rows)
+        const int red_tiles = (int)gridDim.x;  // (one tile column)
+        auto mine = [&](int t) __attribute__((always_inline)) -> bool { return RED && (t % red_tiles) == tile; };
         const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
         // every slot keeps its place inside a row block for the whole kernel: byte offset inside the block as a 32-bit lane
         // value, the block's address as a wave-uniform pointer (x3_serves bounds M * max(N, K) * 4 below 2^32)
@@ -120,7 +132,7 @@ __global__ __launch_bounds__(X3_BLOCK) void gemm_tn_x3_kernel(const float *__res
 #pragma unroll
             for (int i = 0; i < SS; ++i) os[i] = (unsigned)((((lt + i * 256) / 8) * K + k0 + TK + ((lt + i * 256) % 8) * 4) * 4);
         }
-        auto fetch = [&](int t, float4 *ry, float4 *ra, float4 *rs) __attribute__((always_inline)) {
+        auto fetch = [&](int t, float4 *ry, float4 *ra, float4 *rs, float4 *rd) __attribute__((always_inline)) {
             const int64_t r0 = ((int64_t)(pro.reverse ? steps - 1 - t : t) * S + blockIdx.y) * BR;  // (last row blocks first)
             const char *by_ = reinterpret_cast<const char *>(dY) + r0 * N * 4;
             const char *ba_ = reinterpret_cast<const char *>(A) + r0 * K * 4;
@@ -129,6 +141,11 @@ __global__ __launch_bounds__(X3_BLOCK) void gemm_tn_x3_kernel(const float *__res
                 for (int i = 0; i < SY; ++i) ry[i] = *reinterpret_cast<const float4 *>(by_ + oy[i]);
 #pragma unroll
                 for (int i = 0; i < SA; ++i) ra[i] = *reinterpret_cast<const float4 *>(ba_ + oa[i]);
+                if (mine(t)) {
+                    const char *bd_ = reinterpret_cast<const char *>(pro.dA) + r0 * K * 4;
+#pragma unroll
+                    for (int i = 0; i < SA; ++i) rd[i] = *reinterpret_cast<const float4 *>(bd_ + oa[i]);
+                }
                 if (STRIP) {
 #pragma unroll
                     for (int i = 0; i < SS; ++i) {
@@ -153,6 +170,10 @@ __global__ __launch_bounds__(X3_BLOCK) void gemm_tn_x3_kernel(const float *__res
                 const int c = k0 + (e % (TK / 4)) * 4;
                 ra[i] = zero;
                 if (r < r_end && c < K) ra[i] = *reinterpret_cast<const float4 *>(A + r * K + c);
+                if (mine(t)) {
+                    rd[i] = zero;  // (a zero gradient adds nothing: rows past M, columns past K)
+                    if (r < r_end && c < K) rd[i] = *reinterpret_cast<const float4 *>(pro.dA + r * K + c);
+                }
             }
             if (STRIP) {
 #pragma unroll
@@ -184,8 +205,27 @@ __global__ __launch_bounds__(X3_BLOCK) void gemm_tn_x3_kernel(const float *__res
             return make_float4(z0 > 0.0f ? z0 : z0 * pro.slope, z1 > 0.0f ? z1 : z1 * pro.slope, z2 > 0.0f ? z2 : z2 * pro.slope,
                                z3 > 0.0f ? z3 : z3 * pro.slope);
         };
-        auto store = [&](int t, const float4 *ry, const float4 *ra, const float4 *rs) __attribute__((always_inline)) {
+        auto store = [&](int t, const float4 *ry, const float4 *ra, const float4 *rs, const float4 *rd) __attribute__((always_inline)) {
             unsigned short *by = smem + (t & 1) * BUF, *ba = by + 3 * PLANE_N;
+            if (mine(t)) {
+                // dZ = dA * act'(z), sums of dZ and dZ * yhat: the expressions of colreduce_partial_kernel<., 1> (rows.hip)
+                const int col = ((lt % (TK / 4))) * 4;  // (256 % (TK / 4) == 0: every slot of this thread has these columns)
+                const float4 mu = *reinterpret_cast<const float4 *>(&sK[0][col]), sc = *reinterpret_cast<const float4 *>(&sK[1][col]);
+                const float4 be = *reinterpret_cast<const float4 *>(&sK[2][col]), is = *reinterpret_cast<const float4 *>(&sK[3][col]);
+#pragma unroll
+                for (int i = 0; i < SA; ++i) {
+                    const float y[4] = {ra[i].x, ra[i].y, ra[i].z, ra[i].w}, d[4] = {rd[i].x, rd[i].y, rd[i].z, rd[i].w};
+                    const float m4[4] = {mu.x, mu.y, mu.z, mu.w}, s4[4] = {sc.x, sc.y, sc.z, sc.w};
+                    const float b4[4] = {be.x, be.y, be.z, be.w}, i4[4] = {is.x, is.y, is.z, is.w};
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const float yc = y[c] - m4[c];
+                        const float dz = d[c] * (yc * s4[c] + b4[c] > 0.0f ? 1.0f : pro.slope);
+                        red1[c] += dz;
+                        red2[c] += dz * (yc * i4[c]);
+                    }
+                }
+            }
 #pragma unroll
             for (int i = 0; i < SY; ++i) {
                 const int e = lt + i * 256;
@@ -209,18 +249,48 @@ __global__ __launch_bounds__(X3_BLOCK) void gemm_tn_x3_kernel(const float *__res
         // three register stages: while stage t is split and written, stages t+1 and t+2 are in flight -- the barrier couples the
         // loaders to the MFMA waves step by step, and with two stages a late barrier delayed the next fetch (4.1 TB/s with
         // the MFMAs running against 5.3 TB/s without them)
-        if (steps > 0) fetch(0, ry0, ra0, rs0);
-        if (steps > 1) fetch(1, ry1, ra1, rs1);
-        if (steps > 2) fetch(2, ry2, ra2, rs2);
-        auto iter = [&](int t, float4 *ry, float4 *ra, float4 *rs) __attribute__((always_inline)) {
-            store(t, ry, ra, rs);
-            if (t + 3 < steps) fetch(t + 3, ry, ra, rs);
+        if (steps > 0) fetch(0, ry0, ra0, rs0, rd0);
+        if (steps > 1) fetch(1, ry1, ra1, rs1, rd1);
+        if (steps > 2) fetch(2, ry2, ra2, rs2, rd2);
+        auto iter = [&](int t, float4 *ry, float4 *ra, float4 *rs, float4 *rd) __attribute__((always_inline)) {
+            store(t, ry, ra, rs, rd);
+            if (t + 3 < steps) fetch(t + 3, ry, ra, rs, rd);
             __syncthreads();
         };
         for (int t = 0; t < steps; t += 3) {
-            iter(t, ry0, ra0, rs0);
-            if (t + 1 < steps) iter(t + 1, ry1, ra1, rs1);
-            if (t + 2 < steps) iter(t + 2, ry2, ra2, rs2);
+            iter(t, ry0, ra0, rs0, rd0);
+            if (t + 1 < steps) iter(t + 1, ry1, ra1, rs1, rd1);
+            if (t + 2 < steps) iter(t + 2, ry2, ra2, rs2, rd2);
+        }
+        if (RED) {
+            // the threads that share a column group (lt % (TK/4)) fold their sums through the LDS buffer the MFMA waves are
+            // NOT reading in their last step, in thread order (fixed: reproducible); one chunk [2][K] per workgroup
+            float *scr = reinterpret_cast<float *>(smem + (steps & 1) * BUF);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                scr[lt * 8 + c] = red1[c];
+                scr[lt * 8 + 4 + c] = red2[c];
+            }
+            __syncthreads();  // (met by the MFMA waves after their loop)
+            constexpr int CG = TK / 4, PER = 256 / CG;
+            if (lt < CG) {
+                float a1[4] = {0.f, 0.f, 0.f, 0.f}, a2[4] = {0.f, 0.f, 0.f, 0.f};
+                for (int x = 0; x < PER; ++x)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        a1[c] += scr[(lt + x * CG) * 8 + c];
+                        a2[c] += scr[(lt + x * CG) * 8 + 4 + c];
+                    }
+                float *pr = pro.red_partial + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 2 * K;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const int k = k0 + lt * 4 + c;
+                    if (k < K) {
+                        pr[k] = a1[c];
+                        pr[K + k] = a2[c];
+                    }
+                }
+            }
         }
         return;
     }
@@ -279,6 +349,7 @@ __global__ __launch_bounds__(X3_BLOCK) void gemm_tn_x3_kernel(const float *__res
             if (STRIP) accs = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as[0], bs[0], accs, 0, 0, 0);
         }
     }
+    if (RED) __syncthreads();  // the loader waves fold their column sums through the idle LDS buffer
 
     // D[row][col]: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
     float *out = partial + (size_t)blockIdx.y * N * K;
@@ -355,12 +426,12 @@ static X3Plan x3_plan(int64_t M, int N, int K)
     return p;
 }
 
-template <int WM, int WN, bool STRIP, int BR, int TERMS>
+template <int WM, int WN, bool STRIP, int BR, int TERMS, bool RED = false>
 static void x3_launch(const X3Plan &p, const float *dY, const float *A, int64_t M, int N, int K, float *ws, X3Prologue pro,
                       hipStream_t s)
 {
     static bool allowed[64] = {};
-    auto kern = gemm_tn_x3_kernel<WM, WN, STRIP, BR, TERMS>;
+    auto kern = gemm_tn_x3_kernel<WM, WN, STRIP, BR, TERMS, RED>;
     allow_large_dynamic_lds(reinterpret_cast<const void *>(kern), p.lds_bytes, allowed);
     hipLaunchKernelGGL(kern, dim3(p.tiles_n * p.tiles_k, p.splits), dim3(X3_BLOCK), p.lds_bytes, s, dY, A, M, N, K,
                        p.rows_per_split, p.tiles_k, ws, pro);
@@ -421,7 +492,7 @@ static int x3_run(const float *dY, const float *A, int64_t M, int N, int K, int 
 TP3D_EXPORT int tp3d_gemm_tn_x3_f32(const float *dY, const float *A, int64_t M, int N, int K, int terms, float *out,
                                     float *workspace, int reverse, void *stream)
 {
-    const X3Prologue none = {nullptr, nullptr, nullptr, 1.0f, reverse};
+    const X3Prologue none = {nullptr, nullptr, nullptr, 1.0f, reverse, nullptr, nullptr, nullptr};
     return x3_run(dY, A, M, N, K, terms, out, workspace, none, stream);
 }
 
@@ -432,6 +503,43 @@ TP3D_EXPORT int tp3d_gemm_tn_x3_act_f32(const float *dY, const float *Yp, const 
                                         float *workspace, int reverse, void *stream)
 {
     if (!mean_k || !scale_k || !beta_k) return TP3D_E_BADARG;
-    const X3Prologue pro = {mean_k, scale_k, beta_k, slope_k, reverse};
+    const X3Prologue pro = {mean_k, scale_k, beta_k, slope_k, reverse, nullptr, nullptr, nullptr};
     return x3_run(dY, Yp, M, N, K, terms, out, workspace, pro, stream);
+}
+
+// ... and the BatchNorm-backward reductions of the layer Yp belongs to, from its dA (M, K) (see X3Prologue): red_out (4, K)
+// = dbeta, dgamma, c1 = dbeta / M, c2 = invstd * dgamma / M (zero with training == 0) -- what tp3d_bn_bwd_reduce_f32 would
+// return for (dA_k, Yp), without its pass over both.  Served (tp3d_gemm_tn_x3_red_chunks > 0): the shapes of
+// tp3d_gemm_tn_x3_serves with one tile column and no strip (K <= 128), terms == 6.  red_workspace: chunks * 2 * K floats.
+static bool x3_red_serves(int64_t M, int N, int K)
+{
+    if (!x3_serves(M, N, K)) return false;
+    const X3Plan p = x3_plan(M, N, K);
+    return p.tiles_k == 1 && !p.strip && p.wm == 2;
+}
+
+TP3D_EXPORT int tp3d_gemm_tn_x3_red_chunks(int64_t M, int N, int K)
+{
+    if (!x3_red_serves(M, N, K)) return 0;
+    const X3Plan p = x3_plan(M, N, K);
+    return p.tiles_n * p.splits;
+}
+
+TP3D_EXPORT int tp3d_gemm_tn_x3_act_red_f32(const float *dY, const float *Yp, const float *mean_k, const float *scale_k,
+                                            const float *beta_k, const float *invstd_k, float slope_k, const float *dA_k,
+                                            int training, int64_t M, int N, int K, int terms, float *out, float *workspace,
+                                            float *red_out, float *red_workspace, int reverse, void *stream)
+{
+    if (!mean_k || !scale_k || !beta_k || !invstd_k || !dA_k || !red_out || !red_workspace || terms != 6) return TP3D_E_BADARG;
+    if (!x3_red_serves(M, N, K) || !dY || !Yp || !out || !workspace) return TP3D_E_BADARG;
+    hipStream_t s = (hipStream_t)stream;
+    const X3Plan p = x3_plan(M, N, K);
+    if (p.splits > 65535) return TP3D_E_TOOBIG;
+    const X3Prologue pro = {mean_k, scale_k, beta_k, slope_k, reverse, dA_k, invstd_k, red_workspace};
+    if (p.wn == 2) x3_launch<2, 2, false, 32, 6, true>(p, dY, Yp, M, N, K, workspace, pro, s);
+    else x3_launch<2, 1, false, 32, 6, true>(p, dY, Yp, M, N, K, workspace, pro, s);
+    if (int rc = check_launch()) return rc;
+    if (int rc = tn_reduce_splits(workspace, p.splits, (int64_t)N * K, out, s)) return rc;
+    return bn_bwd_finalize_launch(red_workspace, p.tiles_n * p.splits, K, red_out, red_out + K, invstd_k, M, training,
+                                  red_out + 2 * (size_t)K, red_out + 3 * (size_t)K, s);
 }

@@ -1155,6 +1155,14 @@ TP3D_EXPORT int tp3d_bn_act_maxpool_f32(const float *Y, const float *mean, const
 }
 
 namespace tp3d {
+int bn_bwd_finalize_launch(const float *partial, int chunks, int C, float *dbeta, float *dgamma, const float *invstd, int64_t M,
+                           int training, float *c1, float *c2, hipStream_t s)
+{
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(RW_BLOCK), 0, s, partial, chunks, C, dbeta, dgamma, invstd, M,
+                       training, c1, c2);
+    return check_launch();
+}
+
 // pass 1 of the BatchNorm + activation backward: partial sums, then dbeta / dgamma (and c1 / c2 when asked for)
 static int bn_bwd_reduce(const float *dA, const int *argmax, const float *Y, const float *scale, const float *shift,
                          const float *mean, const float *invstd, float slope, int64_t M, int ns, int C, int training,

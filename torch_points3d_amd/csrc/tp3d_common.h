@@ -82,6 +82,9 @@ int invert_table(const int64_t *idx, int64_t slots, int64_t M, int *cnt, int *st
 bool csr_fits_lds(int L, int nbins);
 
 // gemm_tn.hip: out[e] = sum over the row splits of partial[s][e], in ascending split order (reproducible)
+// dbeta, dgamma (, c1, c2) from chunk partials [chunks][2][C] (rows.hip)
+int bn_bwd_finalize_launch(const float *partial, int chunks, int C, float *dbeta, float *dgamma, const float *invstd, int64_t M,
+                           int training, float *c1, float *c2, hipStream_t s);
 int tn_reduce_splits(const float *partial, int splits, int64_t NK, float *out, hipStream_t s);
 
 // grid.hip: uniform-grid radius search (build + query); seg/batch_y null => dense layout (more in grid.h)

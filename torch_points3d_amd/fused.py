@@ -90,6 +90,30 @@ def _identity_stats(K, dev):
     return hit
 
 
+def _chain_wgrad_red(dY, l, Ys, stats, slopes, dA_prev, training, reverse=0):
+    """weight gradient of layer l >= 1 of a fused chain AND the BatchNorm-backward reductions of layer l - 1 from dA_prev,
+    the gradient of its activated output: both need Y_{l-1}, which streams through the contraction's loader waves once
+    (tp3d_gemm_tn_x3_act_red_f32).  Returns (dW, red) with red (4, C_{l-1}) = dbeta, dgamma, c1, c2, or None where the
+    kernel does not serve the shape."""
+    dev = dY.device
+    M, N = dY.shape
+    K = Ys[l - 1].shape[1]
+    h = _lib.load()
+    chunks = h.tp3d_gemm_tn_x3_red_chunks(M, N, K) if WGRAD_X3 == 6 else 0
+    if not chunks:
+        return None
+    ps = stats[l - 1]
+    out = torch.empty((N, K), dtype=torch.float32, device=dev)
+    red = torch.empty((4, K), dtype=torch.float32, device=dev)
+    ws = _lib.gemm_tn_workspace(M, N, K, dev, x3=True)
+    rws = _lib.workspace("gemm_tn_red", 4 * 2 * chunks * K, dev)
+    with _lib.on_device(dev):
+        _lib.call("tp3d_gemm_tn_x3_act_red_f32", _lib.ptr(dY), _lib.ptr(Ys[l - 1]), _lib.ptr(ps[0]), _lib.ptr(ps[2]), _lib.ptr(ps[3]),
+                  _lib.ptr(ps[1]), float(slopes[l - 1]), _lib.ptr(dA_prev), int(training), M, N, K, 6, _lib.ptr(out), _lib.ptr(ws),
+                  _lib.ptr(red), _lib.ptr(rws), int(reverse), _lib.stream_ptr(dev))
+    return out, red
+
+
 def _chain_wgrad(dY, l, A0, acts, Ys, stats, slopes, reverse=0):
     """weight gradient of layer l of a fused chain: dY^T @ (activated input of the layer)"""
     if l == 0:
@@ -575,6 +599,7 @@ class _MLPChain(torch.autograd.Function):
                           _lib.ptr(red_[1]), _lib.ptr(red_[2]), _lib.ptr(red_[3]), _lib.ptr(_lib.bn_workspace(M, C_, dev)), direction(), st)
                 return red_
 
+            red_next = None  # reductions of the next layer down, when the weight-gradient kernel above it produced them
             with _lib.on_device(dev):
                 for l in range(L - 1, -1, -1):
                     Y, ls, W2, slope = Ys[l], stats[l], W2s[l], slopes[l]
@@ -582,11 +607,12 @@ class _MLPChain(torch.autograd.Function):
                     pooled = bool(pool_ns) and l == L - 1
                     kind, cols = route(l)
                     ncol = cols[1] if cols else Kp
+                    red_have, red_next = red_next, None
                     if kind == "loader":
                         # reduction pass, then the input-gradient GEMM whose loader waves form dY (side output for dW)
                         dY = torch.empty_like(Y)
                         a_ptr, ns = (_lib.ptr(arg), pool_ns) if pooled else (None, 1)
-                        red = reduce_pass(l, dcur)
+                        red = red_have if red_have is not None else reduce_pass(l, dcur)
                         grads[3 * l + 1], grads[3 * l + 2] = red[1], red[0]
                         # dA_{l-1}[M,Kp] = dY_l[M,C] (W^T)[Kp,C]^T (a transposed copy of the weight: reading it as stored, four
                         # strided scalars per slot, made the loader waves the bottleneck -- 8.55 vs 8.32 ms/step)
@@ -604,7 +630,15 @@ class _MLPChain(torch.autograd.Function):
                                   _lib.ptr(dprev) + 4 * c0, Kp, pad_lo_k, pad_hi_k,
                                   _lib.ptr(dY) if ctx.needs_input_grad[4 + 3 * l] else None, a_ptr, ns, direction(), st)
                         if ctx.needs_input_grad[4 + 3 * l]:
-                            grads[3 * l] = _chain_wgrad(dY, l, A0, acts, Ys, stats, slopes, direction())[:, :cins[l]].reshape(wshapes[l])
+                            both = None
+                            if WGRAD_RED and l > 0 and acts[l - 1] is None and route(l - 1)[0] != "passes":
+                                # Y_{l-1} streams through this contraction anyway: the layer below gets its reductions here
+                                both = _chain_wgrad_red(dY, l, Ys, stats, slopes, dprev, training, direction())
+                            if both is not None:
+                                dW, red_next = both
+                            else:
+                                dW = _chain_wgrad(dY, l, A0, acts, Ys, stats, slopes, direction())
+                            grads[3 * l] = dW[:, :cins[l]].reshape(wshapes[l])
                         dcur = dprev
                         if l == 0:
                             dA0 = dprev
@@ -612,7 +646,7 @@ class _MLPChain(torch.autograd.Function):
                     if kind == "narrow":
                         # the first layer of grouped rows (a handful of input channels, nobody reads their gradient): the
                         # reduction pass, then dW straight from (Y, dA, A0) -- dY is never written
-                        red = reduce_pass(l, dcur)
+                        red = red_have if red_have is not None else reduce_pass(l, dcur)
                         grads[3 * l + 1], grads[3 * l + 2] = red[1], red[0]
                         dW = torch.empty((C, Kp), dtype=torch.float32, device=dev)
                         nws = _lib.workspace("gemm_tn_narrow", 4 * h.tp3d_gemm_tn_bn_narrow_workspace_floats(M, C, Kp), dev)
@@ -686,6 +720,8 @@ CHAIN_BWD_POOLED = True  # ... also for the max-pooled last layer of a set-abstr
 ROW_ORDER_ALTERNATE = True  # consecutive big kernels of a chain walk the rows in opposite directions (`reverse`, tp3d_hip.h)
 WGRAD_NARROW = True  # first layer of grouped rows (<= 16 input channels, no input gradient wanted): dW from (Y, dA, A0) in one
                      # streaming kernel (tp3d_gemm_tn_bn_narrow_f32) instead of the dY pass + the 64-column MFMA tile kernel
+WGRAD_RED = True     # a hidden layer's weight-gradient kernel also runs the BatchNorm-backward reductions of the layer below
+                     # (tp3d_gemm_tn_x3_act_red_f32: Y of that layer streams through its loader waves anyway)
 FWD_NARROW = True    # ... and its forward contraction (tp3d_gemm_rows_narrow_f32) instead of the MFMA tile kernel
 CHAIN_BWD_LOADER = True  # the chain's input-gradient GEMMs form dY in their loader waves (else: apply pass + library GEMM)
 CHAIN_LOADER = True    # hidden layers' BatchNorm + activation in the loader waves of the split-role GEMM, activated rows as
