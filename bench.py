@@ -162,21 +162,21 @@ def algorithmic_bytes(name, a):
         return B * (m * C1 * 4 + n * 36 + n * C2 * 4 + n * ld * 4)
     if name == "tp3d_idw_weights_f32":  # rows
         return a[0] * 24
-    if name in ("tp3d_gemm_tn_f32", "tp3d_gemm_tn_x3_f32", "tp3d_gemm_tn_x3_act_f32", "tp3d_gemm_rows_f32", "tp3d_gemm_rows_bnact_f32"):  # M, N, K
+    if name in ("tp3d_gemm_tn_f32", "tp3d_gemm_tn_x3_f32", "tp3d_gemm_tn_x3_act_f32", "tp3d_gemm_rows_f32", "tp3d_gemm_rows_narrow_f32"):  # M, N, K
         M, N, K = a[:3]
         return (M * (N + K) + N * K) * 4
+    if name == "tp3d_gemm_tn_bn_narrow_f32":  # M, N, K: Y and dA (M, N) in, A (M, K) in, (N, K) out
+        M, N, K = a[:3]
+        return (2 * M * N + M * K + N * K) * 4
+    if name == "tp3d_gemm_tn_x3_act_red_f32":  # training, M, N, K: dY (M, N), Yp and dA (M, K) in, (N, K) out
+        _, M, N, K = a[:4]
+        return (M * (N + 2 * K) + N * K) * 4
     if name in ("tp3d_gemm_rows_bnact_sp_f32", "tp3d_gemm_rows_bnact_x3_f32"):  # M, N, K (the side output of the training launches, M * K more, not counted)
         M, N, K = a[:3]
         return (M * (N + K) + N * K) * 4
     if name == "tp3d_gemm_rows_bnbwd_sp_f32":  # M, N, K, ldc, pad_lo, pad_hi, ns: Y and dA (dense, or pooled + winners) in, dY and C out
         M, N, K, _, _, _, ns = a[:7]
         return (2 * M * K + (M // ns) * K * (1 if ns == 1 else 2) + M * N + N * K) * 4
-    if name == "tp3d_gemm_rows_bnbwd_f32":  # ns, M, N, K: Y and dA (dense, or pooled M/ns rows + argmax) in, C out
-        ns, M, N, K = a[:4]
-        return (M * K + (M // ns) * K * (1 if ns == 1 else 2) + M * N + N * K) * 4
-    if name == "tp3d_gemm_tn_bn_f32":  # ns, M, N, K: Y, dA, A in; (N, K) out
-        ns, M, N, K = a[:4]
-        return (M * N + (M // ns) * N * (1 if ns == 1 else 2) + M * K + N * K) * 4
     if name == "tp3d_bn_bwd_reduce_f32":  # M, ns, C, training: Y + dA read (pooled: the arg-max rows only)
         M, ns, C = a[:3]
         return 2 * M * C * 4 if ns == 1 else (M // ns) * C * 12
@@ -219,11 +219,12 @@ def algorithmic_bytes(name, a):
 
 
 def algorithmic_flops(name, a):
-    if name in ("tp3d_gemm_tn_f32", "tp3d_gemm_tn_x3_f32", "tp3d_gemm_tn_x3_act_f32", "tp3d_gemm_rows_f32", "tp3d_gemm_rows_bnact_f32"):  # M, N, K
+    if name in ("tp3d_gemm_tn_f32", "tp3d_gemm_tn_x3_f32", "tp3d_gemm_tn_x3_act_f32", "tp3d_gemm_rows_f32", "tp3d_gemm_rows_narrow_f32",
+                "tp3d_gemm_tn_bn_narrow_f32"):  # M, N, K
         M, N, K = a[:3]
         return 2 * M * N * K
-    if name in ("tp3d_gemm_rows_bnbwd_f32", "tp3d_gemm_tn_bn_f32"):  # ns, M, N, K
-        ns, M, N, K = a[:4]
+    if name == "tp3d_gemm_tn_x3_act_red_f32":  # training, M, N, K
+        _, M, N, K = a[:4]
         return 2 * M * N * K
     if name in ("tp3d_gemm_rows_bnact_sp_f32", "tp3d_gemm_rows_bnact_x3_f32", "tp3d_gemm_rows_bnbwd_sp_f32"):  # M, N, K
         M, N, K = a[:3]

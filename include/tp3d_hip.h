@@ -35,7 +35,7 @@ extern "C" {
 #define TP3D_E_UNSORTED (-3) /* reserved: batch vector not sorted (checked by the host wrapper) */
 #define TP3D_E_TOOBIG (-4)   /* size exceeds what the kernel's index arithmetic supports */
 
-#define TP3D_ABI_VERSION 34
+#define TP3D_ABI_VERSION 35
 
 int tp3d_abi_version(void);
 const char *tp3d_strerror(int code);
@@ -177,7 +177,7 @@ int tp3d_bn_act_bwd_f32(const float *dA, const int *argmax, const float *Y, cons
                         const float *mean, const float *invstd, float slope, int64_t M, int ns, int C, int training,
                         float *dbeta, float *dgamma, float *dY, float *workspace, void *stream);
 /* Only the reductions of that backward pass: dbeta, dgamma (C) and the two per-channel terms the fused GEMMs
- * (tp3d_gemm_rows_bnbwd_f32, tp3d_gemm_tn_bn_f32) subtract while they form dY:  c1 = dbeta / M,  c2 = invstd * dgamma / M
+ * (tp3d_gemm_rows_bnbwd_sp_f32, tp3d_gemm_tn_bn_narrow_f32) subtract while they form dY:  c1 = dbeta / M,  c2 = invstd * dgamma / M
  * (both zero with training == 0).  Same arguments and workspace as tp3d_bn_act_bwd_f32, no dY. */
 int tp3d_bn_bwd_reduce_f32(const float *dA, const int *argmax, const float *Y, const float *scale, const float *shift,
                            const float *mean, const float *invstd, float slope, int64_t M, int ns, int C, int training,
@@ -207,12 +207,6 @@ int tp3d_gemm_rows_stat_chunks(int64_t M, int N);
 size_t tp3d_gemm_rows_workspace_floats(int64_t M, int N, int K);
 int tp3d_gemm_rows_f32(const float *A, const float *Bt, int64_t M, int N, int K, float *C, float *stat_partial,
                        float *workspace, void *stream);
-/* The same contraction with the BatchNorm + activation of the PREVIOUS layer applied to the A operand while it is
- * staged (core/common_modules/dense_modules.py:25-29: layer l+1 consumes LeakyReLU(BatchNorm(Y_l))): Y (M,K) is that
- * layer's pre-BatchNorm output, mean / scale / beta (K) its statistics rows; the activated tensor is never written.
- * K <= 1536. */
-int tp3d_gemm_rows_bnact_f32(const float *Y, const float *mean, const float *scale, const float *beta, float slope,
-                             const float *Bt, int64_t M, int N, int K, float *C, float *stat_partial, void *stream);
 /* The same fused contraction on the split-role kernel (csrc/gemm_rows_sp.hip: four MFMA waves fed by four loader waves
  * that apply the prologue on their way into LDS, so it costs the MFMA waves nothing).  act_out != NULL additionally
  * receives the activated rows (M,K) the backward pass of the next layer contracts with (training); stat_partial as for
@@ -249,14 +243,6 @@ int tp3d_gemm_rows_bnbwd_sp_f32(const float *Y, const float *dA, const float *me
                                 const float *c1, const float *c2, float slope, const float *Bt, int64_t M, int N, int K,
                                 float *C, int ldc, int pad_lo, int pad_hi, float *dY_out, const int *argmax, int ns,
                                 int reverse, void *stream);
-/* Input-gradient GEMM of a layer with its BatchNorm + activation BACKWARD applied to the A operand while it is staged:
- *   C[M,N] = dY[M,K] * Bt[N,K]^T,  dY = scale*(dZ - c1 - (Y - mean)*c2),  dZ = dA * act'((Y - mean)*scale + beta)
- * Y (M,K) pre-BatchNorm output of the layer, dA (M,K) gradient of its activated output -- or, with argmax != NULL, the
- * gradient (M/ns, K) of its max-pooled output and the winning rows; c1, c2 (K) from tp3d_bn_bwd_reduce_f32.
- * Bt (N,K) = W^T of the layer (N = its input width).  dY is never written.  K <= 1536. */
-int tp3d_gemm_rows_bnbwd_f32(const float *Y, const float *dA, const int *argmax, int ns, const float *mean,
-                             const float *scale, const float *beta, const float *c1, const float *c2, float slope,
-                             const float *Bt, int64_t M, int N, int K, float *C, void *stream);
 /* `partial` is consumed: with more than 64 chunks they are first folded, in place, into 32 slices. */
 int tp3d_bn_finalize_f32(float *partial, int chunks, int64_t M, int C, float eps, float momentum, const float *gamma,
                          const float *beta, float *running_mean, float *running_var, int64_t *num_batches_tracked,
@@ -318,18 +304,6 @@ int tp3d_gemm_tn_x3_act_red_f32(const float *dY, const float *Yp, const float *m
                                 const float *beta_k, const float *invstd_k, float slope_k, const float *dA_k, int training,
                                 int64_t M, int N, int K, int terms, float *out, float *workspace, float *red_out,
                                 float *red_workspace, int reverse, void *stream);
-/* The same weight gradient with both operands formed while they are staged, so that neither the BatchNorm-backward
- * result dY nor the activated layer input has to exist in HBM (autograd of dense_modules.py:25-29):
- *   dY = scale_n*(dZ - c1_n - (Y - mean_n)*c2_n), dZ = dA * act'((Y - mean_n)*scale_n + beta_n)
- *        Y (M,N) pre-BatchNorm output, dA (M,N) -- or (M/ns,N) with argmax (M/ns,N) != NULL for a max-pooled output;
- *        dA == NULL: Y is dY itself (only the A operand is formed on the fly);
- *   A  = LeakyReLU_slope_k((A - mean_k)*scale_k + beta_k) when mean_k != NULL (A = the previous layer's pre-BatchNorm
- *        output), else A as it is.
- * N % 4 == 0, K % 4 == 0; workspace as for tp3d_gemm_tn_f32. */
-int tp3d_gemm_tn_bn_f32(const float *Y, const float *dA, const int *argmax, int ns, const float *mean_n,
-                        const float *scale_n, const float *beta_n, const float *c1_n, const float *c2_n, float slope_n,
-                        const float *A, const float *mean_k, const float *scale_k, const float *beta_k, float slope_k,
-                        int64_t M, int N, int K, float *out, float *workspace, void *stream);
 
 /* KPConv rigid convolution, stage 1 (reference modules/KPConv/convolution_ops.py:19-98):
  *   weighted[q, k, :] = sum_n h(|(support[nbr[q,n]] - query[q]) - k_points[k]|) * features[nbr[q,n], :]

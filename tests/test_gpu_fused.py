@@ -466,12 +466,10 @@ def test_rows_mlp_with_linear_bias_matches_modules(train):
 
 
 @pytest.mark.parametrize("pool_ns", [0, 16])
-@pytest.mark.parametrize("widths,M,loader", [([8, 64, 64, 128], 4000, False), ([132, 128, 128, 256], 4000, False),
-                                             ([12, 32, 96, 196], 4000, False), ([260, 64], 4000, False),
-                                             ([8, 64, 64, 128], 4000, True), ([132, 128, 128, 256], 4000, True),
-                                             ([12, 64, 128, 256, 132, 128], 66000, True)])
+@pytest.mark.parametrize("widths,M", [([8, 64, 64, 128], 4000), ([132, 128, 128, 256], 4000), ([12, 32, 96, 196], 4000),
+                                      ([260, 64], 4000), ([12, 64, 128, 256, 132, 128], 66000)])
 @pytest.mark.parametrize("train", [True, False])
-def test_mlp_chain_matches_layerwise_path(widths, M, loader, pool_ns, train):
+def test_mlp_chain_matches_layerwise_path(widths, M, pool_ns, train):
     """The fused layer chain (BatchNorm / activation folded into the GEMM prologues, statistics in the epilogues,
     dY and the activated inputs never written) against the layer-by-layer kernels it replaces: same outputs, same
     gradients for the input rows and every parameter, same running statistics."""
@@ -490,20 +488,20 @@ def test_mlp_chain_matches_layerwise_path(widths, M, loader, pool_ns, train):
     twin = copy.deepcopy(mlp)
     mlp.train(train)
     twin.train(train)
-    # loader: hidden BatchNorm + activation in the loader waves of the split-role GEMM (the 66000-row case is large enough
-    # for that kernel: 128-, 256- and 128-column outputs on it, the 64- and 132-column ones on the separate pass)
+    # (the 66000-row case is large enough for the split-role kernels: 128-, 256- and 128-column outputs on them, the 64- and
+    # 132-column ones on the separate pass; the 4000-row cases exercise the chain's fall-back passes)
     rows = torch.randn(M, widths[0], generator=torch.Generator().manual_seed(5)).to(DEV)
     ra, rb = rows.clone().requires_grad_(True), rows.clone().requires_grad_(True)
     cot = torch.randn((M // pool_ns) if pool_ns else M, widths[-1], generator=torch.Generator().manual_seed(6)).to(DEV)
-    old = fused.CHAIN_MIN_ROWS, fused.USE_MLP_CHAIN, fused.CHAIN_LOADER
+    old = fused.CHAIN_MIN_ROWS, fused.USE_MLP_CHAIN
     try:
-        fused.CHAIN_MIN_ROWS, fused.USE_MLP_CHAIN, fused.CHAIN_LOADER = 0, True, loader
+        fused.CHAIN_MIN_ROWS, fused.USE_MLP_CHAIN = 0, True
         assert fused._chain_ok(ra, fused.mlp_parts(mlp))
         out = fused.run_mlp(ra, fused.mlp_parts(mlp), pool_ns)
         fused.USE_MLP_CHAIN = False
         want = fused.run_mlp(rb, fused.mlp_parts(twin), pool_ns)
     finally:
-        fused.CHAIN_MIN_ROWS, fused.USE_MLP_CHAIN, fused.CHAIN_LOADER = old
+        fused.CHAIN_MIN_ROWS, fused.USE_MLP_CHAIN = old
     torch.testing.assert_close(out, want, rtol=1e-5, atol=1e-5)
     out.backward(cot)
     want.backward(cot)

@@ -67,8 +67,12 @@ GROUPS = {  # entry point -> (kernel name fragments, fragment that counts entry-
     "tp3d_bn_act_bwd_f32": (["colreduce_partial_kernel<4, 1>", "colreduce_partial_kernel<1, 1>", "bn_bwd_finalize_kernel",
                              "bn_act_bwd_apply_kernel", "bn_pool_bwd"], "bn_bwd_finalize_kernel"),
     "tp3d_gemm_tn_f32": (["gemm_tn_partial_kernel"], "gemm_tn_partial_kernel"),
-    "tp3d_gemm_tn_x3_f32": (["gemm_tn_x3_kernel"], "gemm_tn_x3_kernel"),
-    "tp3d_gemm_tn_x3_act_f32": (["gemm_tn_x3_kernel"], "gemm_tn_x3_kernel"),
+    # gemm_tn_x3_kernel<WM, WN, STRIP, BR, TERMS, RED>: the plain and activated-operand forms share the instantiations
+    "tp3d_gemm_tn_x3_f32": (["6, false>", "9, false>"], "gemm_tn_x3_kernel"),
+    "tp3d_gemm_tn_x3_act_f32": (["6, false>", "9, false>"], "gemm_tn_x3_kernel"),
+    "tp3d_gemm_tn_x3_act_red_f32": (["6, true>"], "gemm_tn_x3_kernel"),
+    "tp3d_gemm_rows_narrow_f32": (["gemm_rows_narrow_kernel"], None),
+    "tp3d_gemm_tn_bn_narrow_f32": (["gemm_tn_narrow_bn_kernel"], None),
     # gemm_rows_sp_kernel<STATS, PRO, BN>: PRO 1 = forward (previous BatchNorm + activation), 2 / 3 = input gradient
     "tp3d_gemm_rows_bnbwd_sp_f32": (["gemm_rows_sp_kernel<0, 2,", "gemm_rows_sp_kernel<0, 3,"], None),
     "tp3d_gemm_rows_bnact_sp_f32": (["gemm_rows_sp_kernel<2, 1,", "gemm_rows_sp_kernel<0, 1,"], None),

@@ -1,14 +1,8 @@
-// Tall-skinny fp32 GEMM of the shared MLPs, with the neighbouring BatchNorm / activation passes folded into it:
-//     C[M,N] = op(A)[M,K] * Bt[N,K]^T       M = B*npoint*nsample rows (up to ~1e6), N, K <= ~1500, K contiguous in both
-//
-// op (the A-operand PROLOGUE, applied while a tile is staged into LDS -- the transformed matrix never exists in HBM):
-//     PRO_NONE    a = A[m,k]
-//     PRO_BNACT   a = LeakyReLU((Y[m,k] - mean[k]) * scale[k] + beta[k])        forward: A is the previous layer's
-//                                                                               pre-BatchNorm output Y
-//     PRO_BNBWD   a = scale[k] * (dz - c1[k] - (Y[m,k] - mean[k]) * c2[k]),     input-gradient GEMM: the BatchNorm +
-//                 dz = dA[m,k] * act'((Y[m,k] - mean[k]) * scale[k] + beta[k])  activation backward of the layer whose
-//     PRO_BNBWD_POOL  same with dA[m,k] = (argmax[g,k] == m - g*ns) ? dP[g,k] : 0, g = m / ns  (max-pooled output)
-//                                                                               gradient dY this GEMM contracts
+// Tall-skinny fp32 GEMM of the shared MLPs, with the BatchNorm statistics of its output folded into it:
+//     C[M,N] = A[M,K] * Bt[N,K]^T       M = B*npoint*nsample rows (up to ~1e6), N, K <= ~1500, K contiguous in both
+// (the forms that apply the neighbouring BatchNorm / activation passes to the A operand while it is staged live in
+//  gemm_rows_sp.hip / gemm_rows_x3.hip, where dedicated loader waves do that work; the first design -- prologues in the
+//  MFMA waves of this kernel, 230-256 VGPRs -- was measured slower, DESIGN.md section 5, and is gone)
 // EPILOGUE (STATS): per column, shifted sums of C in `chunks` partial rows -> tp3d_bn_finalize_f32
 //     (one chunk per (128-row block, wave row); launches that fill the persistent grid keep one running chunk per
 //     (workgroup, wave row) instead: wave_rows*1024/tiles_n chunks whatever M is, so the finalize pass stays small)
@@ -36,37 +30,22 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int GR_BLOCK_T = 256;
 constexpr int GR_BM = 128, GR_BK = 32;
 constexpr int GR_LD = GR_BK + 4;  // 36-float pitch
-constexpr int GR_PRO_KMAX = 1536;  // widest contraction a prologue's per-channel constants are staged for
-
-enum { PRO_NONE = 0, PRO_BNACT = 1, PRO_BNBWD = 2, PRO_BNBWD_POOL = 3 };
-
-// what a prologue reads besides A (all per channel k of the contraction; layouts as tp3d_bn_* produce them)
-struct GemmPrologue {
-    const float *mean, *scale, *beta;  // BatchNorm statistics rows of the layer A belongs to
-    const float *c1, *c2;              // PRO_BNBWD*: dbeta / M and invstd * dgamma / M (zeros in eval mode)
-    const float *dA;                   // PRO_BNBWD: gradient wrt the activation (M, K); PRO_BNBWD_POOL: dP (M/ns, K)
-    const int *argmax;                 // PRO_BNBWD_POOL: (M/ns, K) winning row of each group
-    float slope;
-    int ns;
-};
 
 // WIDE: 128 x 128 tile, else 128 x 64.  STATS: 0 none, 1 one statistics chunk per (128-row block, wave row), 2 one per
 // (workgroup, wave row) (needs gridDim.x % (8*tiles_n) == 0: every item of a workgroup then lies in one column tile)
-template <bool WIDE, int PRO, int STATS>
-__global__ __launch_bounds__(GR_BLOCK_T, (WIDE && PRO != PRO_NONE) ? 2 : 1) void gemm_rows_kernel(const float *__restrict__ A, const float *__restrict__ Bt,
+template <bool WIDE, int STATS>
+__global__ __launch_bounds__(GR_BLOCK_T, 1) void gemm_rows_kernel(const float *__restrict__ A, const float *__restrict__ Bt,
                                                                 int64_t M, int N, int K, int kchunk, int tiles_n,
                                                                 int64_t items, float *__restrict__ C,
-                                                                float *__restrict__ partial, GemmPrologue pro)
+                                                                float *__restrict__ partial)
 {
     constexpr int BN = WIDE ? 128 : 64;
     constexpr int WR = WIDE ? 2 : 4;          // wave rows of the workgroup tile
     constexpr int WM = WIDE ? 2 : 1;          // 32-row MFMA tiles per wave
     constexpr int WN = 2;                     // 32-column MFMA tiles per wave
     constexpr int PB = BN * (GR_BK / 4) / GR_BLOCK_T;  // float4 slots of the B tile per thread (4 or 2)
-    constexpr int NCONST = PRO == PRO_NONE ? 0 : (PRO == PRO_BNACT ? 3 : 5);
     __shared__ __attribute__((aligned(16))) float sA[GR_BM * GR_LD];
     __shared__ __attribute__((aligned(16))) float sB[BN * GR_LD];
-    __shared__ __attribute__((aligned(16))) float sK[NCONST > 0 ? NCONST * GR_PRO_KMAX : 4];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = WIDE ? wave >> 1 : wave, wc = WIDE ? wave & 1 : 0;
@@ -74,20 +53,6 @@ __global__ __launch_bounds__(GR_BLOCK_T, (WIDE && PRO != PRO_NONE) ? 2 : 1) void
     const int kbeg = blockIdx.y * kchunk, kend = min(K, kbeg + kchunk);
     const int ksteps = (kend - kbeg + GR_BK - 1) / GR_BK;
     if (blockIdx.y > 0) C += (size_t)blockIdx.y * (size_t)M * N;  // K-split: one partial slab per K-range
-
-    if (PRO != PRO_NONE) {  // the contraction's per-channel constants, once per workgroup (zero past K)
-        for (int k = tid; k < GR_PRO_KMAX; k += GR_BLOCK_T) {
-            const bool in = k < K;
-            sK[0 * GR_PRO_KMAX + k] = in ? pro.mean[k] : 0.0f;
-            sK[1 * GR_PRO_KMAX + k] = in ? pro.scale[k] : 0.0f;
-            sK[2 * GR_PRO_KMAX + k] = in ? pro.beta[k] : 0.0f;
-            if (PRO >= PRO_BNBWD) {
-                sK[3 * GR_PRO_KMAX + k] = in ? pro.c1[k] : 0.0f;
-                sK[4 * GR_PRO_KMAX + k] = in ? pro.c2[k] : 0.0f;
-            }
-        }
-        __syncthreads();
-    }
 
     // Work items = (row block, column tile) in an XCD-aware order: the column tiles of one row block are 8 ids
     // apart, i.e. on the same XCD (shared L2 for A).  Workgroups are PERSISTENT: each walks items id, id + G, ...
@@ -101,12 +66,11 @@ __global__ __launch_bounds__(GR_BLOCK_T, (WIDE && PRO != PRO_NONE) ? 2 : 1) void
         n0 = (rem >> 3) * BN;
     };
 
-    // staging registers: the A tile is 128 rows x 32 k = 1024 float4 (4 per thread), raw as loaded; the prologue is
-    // applied when they are written to LDS one K-step later (the loads have had a whole MFMA phase to land by then)
+    // staging registers: the A tile is 128 rows x 32 k = 1024 float4 (4 per thread), written to LDS one K-step later (the
+    // loads have had a whole MFMA phase to land by then)
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    float4 ra[4] = {zero4, zero4, zero4, zero4}, ra2[4] = {zero4, zero4, zero4, zero4};
+    float4 ra[4] = {zero4, zero4, zero4, zero4};
     float4 rb0 = zero4, rb1 = zero4, rb2 = zero4, rb3 = zero4;  // B tile staging (named: an array of them ended up in scratch)
-    int4 rarg[4] = {make_int4(0, 0, 0, 0), make_int4(0, 0, 0, 0), make_int4(0, 0, 0, 0), make_int4(0, 0, 0, 0)};
     const int k4 = (tid & 7) * 4;  // this thread's k offset inside a K-step (tid + i*256: the same for all four slots)
     auto fetch = [&](int64_t m0, int n0, int k0) __attribute__((always_inline)) {
         const bool kin = k0 + k4 < kend;
@@ -116,12 +80,6 @@ __global__ __launch_bounds__(GR_BLOCK_T, (WIDE && PRO != PRO_NONE) ? 2 : 1) void
             const int64_t m = m0 + row;
             const bool in = m < M && kin;
             ra[i] = in ? *reinterpret_cast<const float4 *>(A + m * K + k0 + k4) : zero4;
-            if (PRO == PRO_BNBWD) ra2[i] = in ? *reinterpret_cast<const float4 *>(pro.dA + m * K + k0 + k4) : zero4;
-            if (PRO == PRO_BNBWD_POOL) {
-                const int64_t g = m / pro.ns;
-                ra2[i] = in ? *reinterpret_cast<const float4 *>(pro.dA + g * K + k0 + k4) : zero4;
-                rarg[i] = in ? *reinterpret_cast<const int4 *>(pro.argmax + g * K + k0 + k4) : make_int4(-1, -1, -1, -1);
-            }
         }
         auto loadB = [&](int i) __attribute__((always_inline)) -> float4 {
             const int n = n0 + (tid >> 3) + i * 32;
@@ -134,32 +92,6 @@ __global__ __launch_bounds__(GR_BLOCK_T, (WIDE && PRO != PRO_NONE) ? 2 : 1) void
             rb3 = loadB(3);
         }
     };
-    // the prologue on one staged float4 (k = kk .. kk+3); out-of-range rows / k were loaded as zeros and MUST stay zero
-    auto bn_forward = [&](const float4 raw, int kk) __attribute__((always_inline)) -> float4 {
-        const float4 mu = *reinterpret_cast<const float4 *>(&sK[0 * GR_PRO_KMAX + kk]);
-        const float4 sc = *reinterpret_cast<const float4 *>(&sK[1 * GR_PRO_KMAX + kk]);
-        const float4 be = *reinterpret_cast<const float4 *>(&sK[2 * GR_PRO_KMAX + kk]);
-        const float z0 = (raw.x - mu.x) * sc.x + be.x, z1 = (raw.y - mu.y) * sc.y + be.y;
-        const float z2 = (raw.z - mu.z) * sc.z + be.z, z3 = (raw.w - mu.w) * sc.w + be.w;
-        return make_float4(z0 > 0.0f ? z0 : z0 * pro.slope, z1 > 0.0f ? z1 : z1 * pro.slope,
-                           z2 > 0.0f ? z2 : z2 * pro.slope, z3 > 0.0f ? z3 : z3 * pro.slope);
-    };
-    auto bn_backward = [&](const float4 raw, const float4 d, int kk) __attribute__((always_inline)) -> float4 {
-        const float4 mu = *reinterpret_cast<const float4 *>(&sK[0 * GR_PRO_KMAX + kk]);
-        const float4 sc = *reinterpret_cast<const float4 *>(&sK[1 * GR_PRO_KMAX + kk]);
-        const float4 be = *reinterpret_cast<const float4 *>(&sK[2 * GR_PRO_KMAX + kk]);
-        const float4 c1 = *reinterpret_cast<const float4 *>(&sK[3 * GR_PRO_KMAX + kk]);
-        const float4 c2 = *reinterpret_cast<const float4 *>(&sK[4 * GR_PRO_KMAX + kk]);
-        auto one = [&](float y, float dd, float m, float s_, float b, float k1, float k2) __attribute__((always_inline)) -> float {
-            const float yc = y - m;
-            const float z = yc * s_ + b;
-            const float dz = dd * (z > 0.0f ? 1.0f : pro.slope);
-            return s_ * ((dz - k1) - yc * k2);
-        };
-        return make_float4(one(raw.x, d.x, mu.x, sc.x, be.x, c1.x, c2.x), one(raw.y, d.y, mu.y, sc.y, be.y, c1.y, c2.y),
-                           one(raw.z, d.z, mu.z, sc.z, be.z, c1.z, c2.z), one(raw.w, d.w, mu.w, sc.w, be.w, c1.w, c2.w));
-    };
-
     int64_t item = blockIdx.x;
     if (item >= items) return;
     int64_t m0, rb;
@@ -186,27 +118,10 @@ __global__ __launch_bounds__(GR_BLOCK_T, (WIDE && PRO != PRO_NONE) ? 2 : 1) void
         if (next_item < items) decode(next_item, nm0, nn0, nrb);
 
         for (int ks = 0; ks < ksteps; ++ks) {
-            const int kk = kbeg + ks * GR_BK + k4;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int row = (tid >> 3) + i * 32;
-                float4 t = ra[i];
-                if constexpr (PRO != PRO_NONE) {
-                    if (m0 + row < M && kk < kend) {
-                        if constexpr (PRO == PRO_BNACT) t = bn_forward(ra[i], kk);
-                        if constexpr (PRO == PRO_BNBWD) t = bn_backward(ra[i], ra2[i], kk);
-                        if constexpr (PRO == PRO_BNBWD_POOL) {
-                            const int64_t m = m0 + row;
-                            const int sl = (int)(m - (m / pro.ns) * pro.ns);
-                            const float4 d = make_float4(rarg[i].x == sl ? ra2[i].x : 0.0f, rarg[i].y == sl ? ra2[i].y : 0.0f,
-                                                         rarg[i].z == sl ? ra2[i].z : 0.0f, rarg[i].w == sl ? ra2[i].w : 0.0f);
-                            t = bn_backward(ra[i], d, kk);
-                        }
-                    } else {
-                        t = zero4;
-                    }
-                }
-                *reinterpret_cast<float4 *>(&sA[row * GR_LD + k4]) = t;
+                *reinterpret_cast<float4 *>(&sA[row * GR_LD + k4]) = ra[i];
             }
             *reinterpret_cast<float4 *>(&sB[((tid >> 3) + 0 * 32) * GR_LD + k4]) = rb0;
             *reinterpret_cast<float4 *>(&sB[((tid >> 3) + 1 * 32) * GR_LD + k4]) = rb1;
@@ -569,12 +484,12 @@ RowsPlan rows_plan(int64_t M, int N, int K = 0, bool allow_split = false)
     return p;
 }
 
-template <bool WIDE, int PRO>
+template <bool WIDE>
 int launch_rows(const RowsPlan &p, const float *A, const float *Bt, int64_t M, int N, int K, float *C, float *stat_partial,
-                const GemmPrologue &pro, hipStream_t s)
+                hipStream_t s)
 {
     const dim3 grid((unsigned)p.blocks, (unsigned)p.ksplit), block(GR_BLOCK_T);
-    if (WIDE && PRO == PRO_NONE && p.ksplit == 1) {  // the dedicated plain 128 x 128 kernel
+    if (WIDE && p.ksplit == 1) {  // the dedicated plain 128 x 128 kernel
         if (stat_partial && p.per_workgroup)
             hipLaunchKernelGGL(gemm_rows_wide_kernel<2>, grid, block, 0, s, A, Bt, M, N, K, p.tiles_n, p.items, C, stat_partial);
         else if (stat_partial)
@@ -584,23 +499,22 @@ int launch_rows(const RowsPlan &p, const float *A, const float *Bt, int64_t M, i
         return check_launch();
     }
     if (stat_partial && p.per_workgroup)
-        hipLaunchKernelGGL((gemm_rows_kernel<WIDE, PRO, 2>), grid, block, 0, s, A, Bt, M, N, K, p.kchunk, p.tiles_n, p.items,
-                           C, stat_partial, pro);
+        hipLaunchKernelGGL((gemm_rows_kernel<WIDE, 2>), grid, block, 0, s, A, Bt, M, N, K, p.kchunk, p.tiles_n, p.items,
+                           C, stat_partial);
     else if (stat_partial)
-        hipLaunchKernelGGL((gemm_rows_kernel<WIDE, PRO, 1>), grid, block, 0, s, A, Bt, M, N, K, p.kchunk, p.tiles_n, p.items,
-                           C, stat_partial, pro);
+        hipLaunchKernelGGL((gemm_rows_kernel<WIDE, 1>), grid, block, 0, s, A, Bt, M, N, K, p.kchunk, p.tiles_n, p.items,
+                           C, stat_partial);
     else
-        hipLaunchKernelGGL((gemm_rows_kernel<WIDE, PRO, 0>), grid, block, 0, s, A, Bt, M, N, K, p.kchunk, p.tiles_n, p.items,
-                           C, stat_partial, pro);
+        hipLaunchKernelGGL((gemm_rows_kernel<WIDE, 0>), grid, block, 0, s, A, Bt, M, N, K, p.kchunk, p.tiles_n, p.items,
+                           C, stat_partial);
     return check_launch();
 }
 
-template <int PRO>
 int launch_rows_any(const RowsPlan &p, const float *A, const float *Bt, int64_t M, int N, int K, float *C,
-                    float *stat_partial, const GemmPrologue &pro, hipStream_t s)
+                    float *stat_partial, hipStream_t s)
 {
-    return p.wide ? launch_rows<true, PRO>(p, A, Bt, M, N, K, C, stat_partial, pro, s)
-                  : launch_rows<false, PRO>(p, A, Bt, M, N, K, C, stat_partial, pro, s);
+    return p.wide ? launch_rows<true>(p, A, Bt, M, N, K, C, stat_partial, s)
+                  : launch_rows<false>(p, A, Bt, M, N, K, C, stat_partial, s);
 }
 }  // namespace
 
@@ -655,47 +569,12 @@ TP3D_EXPORT int tp3d_gemm_rows_f32(const float *A, const float *Bt, int64_t M, i
     if (M == 0) return TP3D_OK;
     if (!A || !Bt || !C) return TP3D_E_BADARG;
     hipStream_t s = (hipStream_t)stream;
-    GemmPrologue none = {};
     // K-split only without fused statistics (they need the finished column values) and with slabs to write to
     const RowsPlan p = rows_plan(M, N, K, !stat_partial && workspace && ((M * (int64_t)N) & 3) == 0);
-    if (p.ksplit == 1) return launch_rows_any<PRO_NONE>(p, A, Bt, M, N, K, C, stat_partial, none, s);
-    if (int rc = launch_rows_any<PRO_NONE>(p, A, Bt, M, N, K, workspace, nullptr, none, s)) return rc;
+    if (p.ksplit == 1) return launch_rows_any(p, A, Bt, M, N, K, C, stat_partial, s);
+    if (int rc = launch_rows_any(p, A, Bt, M, N, K, workspace, nullptr, s)) return rc;
     const int64_t mn4 = M * (int64_t)N / 4;
     hipLaunchKernelGGL(gemm_rows_sum_slabs_kernel, dim3((unsigned)std::min<int64_t>((mn4 + 255) / 256, 4096)), dim3(256), 0, s,
                        workspace, p.ksplit, mn4, C);
     return check_launch();
-}
-
-// C = act(BN(Y)) * Bt^T: the forward GEMM of a layer whose input is the previous layer's pre-BatchNorm output Y (M, K)
-// with that layer's statistics rows mean / scale / beta (K each); the activated input is formed while staging.
-TP3D_EXPORT int tp3d_gemm_rows_bnact_f32(const float *Y, const float *mean, const float *scale, const float *beta,
-                                         float slope, const float *Bt, int64_t M, int N, int K, float *C,
-                                         float *stat_partial, void *stream)
-{
-    if (M < 0 || N <= 0 || K <= 0 || (K & 3) || K > GR_PRO_KMAX) return TP3D_E_BADARG;
-    if (M == 0) return TP3D_OK;
-    if (!Y || !mean || !scale || !beta || !Bt || !C) return TP3D_E_BADARG;
-    GemmPrologue pro = {};
-    pro.mean = mean, pro.scale = scale, pro.beta = beta, pro.slope = slope, pro.ns = 1;
-    return launch_rows_any<PRO_BNACT>(rows_plan(M, N, K), Y, Bt, M, N, K, C, stat_partial, pro, (hipStream_t)stream);
-}
-
-// Input-gradient GEMM with the BatchNorm + activation backward folded in:  C[M,N] = dY[M,K] * Bt[N,K]^T  where
-//   dY = scale * (dZ - c1 - (Y - mean) * c2),  dZ = dA * act'((Y - mean) * scale + beta)
-// is formed from Y (M, K) and dA while staging: dA is (M, K), or with argmax != NULL the gradient (M/ns, K) of the
-// max-pooled output with its winning rows.  c1 = dbeta / M, c2 = invstd * dgamma / M (tp3d_bn_bwd_reduce_f32; zeros
-// in eval mode).  Bt = W^T (N = the layer's input width, K = its output width).
-TP3D_EXPORT int tp3d_gemm_rows_bnbwd_f32(const float *Y, const float *dA, const int *argmax, int ns, const float *mean,
-                                         const float *scale, const float *beta, const float *c1, const float *c2,
-                                         float slope, const float *Bt, int64_t M, int N, int K, float *C, void *stream)
-{
-    if (M < 0 || N <= 0 || K <= 0 || (K & 3) || K > GR_PRO_KMAX || ns <= 0) return TP3D_E_BADARG;
-    if (M == 0) return TP3D_OK;
-    if (!Y || !dA || !mean || !scale || !beta || !c1 || !c2 || !Bt || !C || (argmax && M % ns)) return TP3D_E_BADARG;
-    GemmPrologue pro = {};
-    pro.mean = mean, pro.scale = scale, pro.beta = beta, pro.c1 = c1, pro.c2 = c2, pro.dA = dA, pro.argmax = argmax;
-    pro.slope = slope, pro.ns = ns;
-    const RowsPlan p = rows_plan(M, N, K);
-    return argmax ? launch_rows_any<PRO_BNBWD_POOL>(p, Y, Bt, M, N, K, C, nullptr, pro, (hipStream_t)stream)
-                  : launch_rows_any<PRO_BNBWD>(p, Y, Bt, M, N, K, C, nullptr, pro, (hipStream_t)stream);
 }

@@ -6,12 +6,9 @@
 // (v_mfma_f32_32x32x2_f32: exact fp32, 64 FLOP/clk/SIMD), and a second pass sums the splits in fixed order
 // (no atomics: bitwise reproducible).
 //
-// Both operands can be formed on the fly while they are staged (the FUSED instantiations), so that neither the
-// BatchNorm-backward result dY nor the activated layer input A has to exist in HBM:
-//     dY = scale_n * (dZ - c1_n - (Y - mean_n) * c2_n),  dZ = dA * act'((Y - mean_n) * scale_n + beta_n)
-//          from the layer's pre-BatchNorm output Y (M, N) and the gradient dA of its activated output (dense (M, N), or
-//          the gradient (M/ns, N) of its max-pooled output with the winning rows)
-//     A  = LeakyReLU((Yp - mean_k) * scale_k + beta_k)   from the previous layer's pre-BatchNorm output Yp (M, K)
+// (The large layers run on the bf16 matrix pipe -- gemm_tn_x3.hip, which also forms the activated operand in its loader
+// waves; the first layer of grouped rows on gemm_tn_narrow.hip.  A form of THIS kernel that built both operands while
+// staging them, in the waves that also issue the MFMAs, was the first design and measured slower: DESIGN.md section 5.)
 //
 // Reference semantics: the weight gradient of Conv2d 1x1 (bias=False) inside MLP2D
 // (torch_points3d/core/common_modules/dense_modules.py:5-12,25-29) -- computed by autograd in the reference.
@@ -26,28 +23,14 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int TN_BLOCK = 256;  // 4 waves as 2 x 2
 constexpr int TN_BR_MAX = 64;  // most rows staged per step (narrow tiles stage more rows per barrier)
 
-// operand prologues of the FUSED instantiations (null pointers = plain operand)
-struct TnPrologue {
-    // dY operand: Y in `dY`, plus
-    const float *dA;      // gradient of the activated output: (M, N), or (M/ns, N) when argmax != null
-    const int *argmax;    // (M/ns, N) winning rows of the pooled groups, or null
-    const float *mean_n, *scale_n, *beta_n, *c1_n, *c2_n;
-    float slope_n;
-    int ns;
-    // A operand: Yp in `A`, plus
-    const float *mean_k, *scale_k, *beta_k;
-    float slope_k;
-};
-
 // Each wave owns WM x WN MFMA tiles of 32x32; the four waves form a GN x (4/GN) grid, so the workgroup tile is
 // (GN*WM*32) x ((4/GN)*WN*32): 2 x 2 waves normally, 1 x 4 for a handful of output rows (the class-score layer: N = 10
 // would fill 10 of 64 tile rows otherwise, and the contraction is then bound by wasted MFMA work, not by HBM).
-template <int WM, int WN, bool VECY, bool VECA, bool FUSED, int GN = 2>
+template <int WM, int WN, bool VECY, bool VECA, int GN = 2>
 __global__ __launch_bounds__(TN_BLOCK) void gemm_tn_partial_kernel(const float *__restrict__ dY,
                                                                     const float *__restrict__ A, int64_t M, int N,
                                                                     int K, int64_t rows_per_split, int tiles_k,
-                                                                    float *__restrict__ partial /*[S][N][K]*/,
-                                                                    TnPrologue pro)
+                                                                    float *__restrict__ partial /*[S][N][K]*/)
 {
     constexpr int GK = 4 / GN;
     constexpr int TN = GN * WM * 32, TK = GK * WN * 32;
@@ -57,8 +40,6 @@ __global__ __launch_bounds__(TN_BLOCK) void gemm_tn_partial_kernel(const float *
     constexpr int LDN = TN + 4, LDK = TK + 4;  // +4 floats: keeps float4 stores aligned, spreads rows over banks
     __shared__ __attribute__((aligned(16))) float sY[TN_BR * LDN];
     __shared__ __attribute__((aligned(16))) float sA[TN_BR * LDK];
-    __shared__ __attribute__((aligned(16))) float sCn[FUSED ? 5 * TN : 4];  // mean, scale, beta, c1, c2 of the tile's columns
-    __shared__ __attribute__((aligned(16))) float sCk[FUSED ? 3 * TK : 4];  // mean, scale, beta
 
     const int tile = blockIdx.x;
     const int n0 = (tile / tiles_k) * TN, k0 = (tile % tiles_k) * TK;
@@ -68,27 +49,6 @@ __global__ __launch_bounds__(TN_BLOCK) void gemm_tn_partial_kernel(const float *
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave / GK, wc = wave % GK;
     const int l31 = lane & 31, lh = lane >> 5;
-    const bool proY = FUSED && pro.dA != nullptr, proA = FUSED && pro.mean_k != nullptr;
-    const bool pooled = FUSED && pro.argmax != nullptr;
-
-    if (FUSED) {
-        for (int c = tid; c < TN; c += TN_BLOCK) {
-            const bool in = proY && n0 + c < N;
-            sCn[0 * TN + c] = in ? pro.mean_n[n0 + c] : 0.0f;
-            sCn[1 * TN + c] = in ? pro.scale_n[n0 + c] : 0.0f;
-            sCn[2 * TN + c] = in ? pro.beta_n[n0 + c] : 0.0f;
-            sCn[3 * TN + c] = in ? pro.c1_n[n0 + c] : 0.0f;
-            sCn[4 * TN + c] = in ? pro.c2_n[n0 + c] : 0.0f;
-        }
-        for (int c = tid; c < TK; c += TN_BLOCK) {
-            const bool in = proA && k0 + c < K;
-            sCk[0 * TK + c] = in ? pro.mean_k[k0 + c] : 0.0f;
-            sCk[1 * TK + c] = in ? pro.scale_k[k0 + c] : 0.0f;
-            sCk[2 * TK + c] = in ? pro.beta_k[k0 + c] : 0.0f;
-        }
-        __syncthreads();
-    }
-
     f32x16 acc[WM][WN];
 #pragma unroll
     for (int i = 0; i < WM; ++i)
@@ -121,8 +81,7 @@ __global__ __launch_bounds__(TN_BLOCK) void gemm_tn_partial_kernel(const float *
     constexpr int PY = TN_BR * (TN / 4) / TN_BLOCK, PA = TN_BR * (TK / 4) / TN_BLOCK;  // float4 slots per thread
     static_assert(PY >= 1 && PA >= 1 && PY * TN_BLOCK == TN_BR * (TN / 4) && PA * TN_BLOCK == TN_BR * (TK / 4),
                   "staged tile must be a whole number of float4 slots per thread");
-    float4 ry[PY], ra[PA], rd[FUSED ? PY : 1];
-    int4 rg[FUSED ? PY : 1];
+    float4 ry[PY], ra[PA];
     auto fetch = [&](int64_t r0) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < PY; ++i) {
@@ -130,16 +89,6 @@ __global__ __launch_bounds__(TN_BLOCK) void gemm_tn_partial_kernel(const float *
             const int64_t r = r0 + e / (TN / 4);
             const int c = n0 + (e % (TN / 4)) * 4;
             ry[i] = load4(dY, r, c, N, std::integral_constant<bool, VECY>());
-            if (FUSED && proY) {
-                if (pooled) {
-                    const int64_t g = r / pro.ns;
-                    rd[i] = load4(pro.dA, g, c, N, std::true_type());
-                    rg[i] = (r < r_end && c < N) ? *reinterpret_cast<const int4 *>(pro.argmax + g * N + c)
-                                                 : make_int4(-1, -1, -1, -1);
-                } else {
-                    rd[i] = load4(pro.dA, r, c, N, std::true_type());
-                }
-            }
         }
 #pragma unroll
         for (int i = 0; i < PA; ++i) {
@@ -147,61 +96,17 @@ __global__ __launch_bounds__(TN_BLOCK) void gemm_tn_partial_kernel(const float *
             ra[i] = load4(A, r0 + e / (TK / 4), k0 + (e % (TK / 4)) * 4, K, std::integral_constant<bool, VECA>());
         }
     };
-    // prologues, applied when the staged values go to LDS; rows past the range / columns past the edge stay zero
-    auto make_dy = [&](int i, int64_t r0) __attribute__((always_inline)) -> float4 {
-        if (!(FUSED && proY)) return ry[i];
-        const int e = tid + i * TN_BLOCK;
-        const int64_t r = r0 + e / (TN / 4);
-        const int cl = (e % (TN / 4)) * 4;  // column inside the tile
-        if (r >= r_end) return make_float4(0.f, 0.f, 0.f, 0.f);
-        const float y[4] = {ry[i].x, ry[i].y, ry[i].z, ry[i].w};
-        float d[4] = {rd[i].x, rd[i].y, rd[i].z, rd[i].w};
-        if (pooled) {
-            const int s = (int)(r - (r / pro.ns) * pro.ns);
-            const int a_[4] = {rg[i].x, rg[i].y, rg[i].z, rg[i].w};
-#pragma unroll
-            for (int v = 0; v < 4; ++v) d[v] = a_[v] == s ? d[v] : 0.0f;
-        }
-        float o[4];
-#pragma unroll
-        for (int v = 0; v < 4; ++v) {
-            const int c = cl + v;
-            const float sc = sCn[1 * TN + c];  // zero past N: the whole expression is then zero
-            const float yc = y[v] - sCn[0 * TN + c];
-            const float z = yc * sc + sCn[2 * TN + c];
-            const float dz = d[v] * (z > 0.0f ? 1.0f : pro.slope_n);
-            o[v] = sc * ((dz - sCn[3 * TN + c]) - yc * sCn[4 * TN + c]);
-        }
-        return make_float4(o[0], o[1], o[2], o[3]);
-    };
-    auto make_a = [&](int i, int64_t r0) __attribute__((always_inline)) -> float4 {
-        if (!(FUSED && proA)) return ra[i];
-        const int e = tid + i * TN_BLOCK;
-        const int64_t r = r0 + e / (TK / 4);
-        const int cl = (e % (TK / 4)) * 4;
-        if (r >= r_end) return make_float4(0.f, 0.f, 0.f, 0.f);
-        const float y[4] = {ra[i].x, ra[i].y, ra[i].z, ra[i].w};
-        float o[4];
-#pragma unroll
-        for (int v = 0; v < 4; ++v) {
-            const int c = cl + v;
-            const float z = (y[v] - sCk[0 * TK + c]) * sCk[1 * TK + c] + sCk[2 * TK + c];
-            o[v] = (k0 + c < K) ? (z > 0.0f ? z : z * pro.slope_k) : 0.0f;
-        }
-        return make_float4(o[0], o[1], o[2], o[3]);
-    };
-
     if (r_begin < r_end) fetch(r_begin);
     for (int64_t r0 = r_begin; r0 < r_end; r0 += TN_BR) {
 #pragma unroll
         for (int i = 0; i < PY; ++i) {
             const int e = tid + i * TN_BLOCK;
-            *reinterpret_cast<float4 *>(&sY[(e / (TN / 4)) * LDN + (e % (TN / 4)) * 4]) = make_dy(i, r0);
+            *reinterpret_cast<float4 *>(&sY[(e / (TN / 4)) * LDN + (e % (TN / 4)) * 4]) = ry[i];
         }
 #pragma unroll
         for (int i = 0; i < PA; ++i) {
             const int e = tid + i * TN_BLOCK;
-            *reinterpret_cast<float4 *>(&sA[(e / (TK / 4)) * LDK + (e % (TK / 4)) * 4]) = make_a(i, r0);
+            *reinterpret_cast<float4 *>(&sA[(e / (TK / 4)) * LDK + (e % (TK / 4)) * 4]) = ra[i];
         }
         __syncthreads();
         if (r0 + TN_BR < r_end) fetch(r0 + TN_BR);
@@ -303,36 +208,31 @@ static TnPlan plan_tn(int64_t M, int N, int K)
     return p;
 }
 
-static int launch_tn(const float *dY, const float *A, int64_t M, int N, int K, float *out, float *workspace,
-                     const TnPrologue *pro, hipStream_t s)
+static int launch_tn(const float *dY, const float *A, int64_t M, int N, int K, float *out, float *workspace, hipStream_t s)
 {
     const TnPlan p = plan_tn(M, N, K);
     if (p.splits > 65535) return TP3D_E_TOOBIG;
     dim3 grid(p.tiles_n * p.tiles_k, p.splits);
     const bool vy = (N & 3) == 0, va = (K & 3) == 0;
-    if (pro && !(vy && va)) return TP3D_E_BADARG;  // the fused operands need 16-byte aligned rows
-    const TnPrologue none = {};
-#define TP3D_TN_LAUNCH(WM_, WN_, VY_, VA_, FU_)                                                                     \
-    hipLaunchKernelGGL((gemm_tn_partial_kernel<WM_, WN_, VY_, VA_, FU_>), grid, dim3(TN_BLOCK), 0, s, dY, A, M, N, K,   \
-                       p.rows_per_split, p.tiles_k, workspace, pro ? *pro : none)
+#define TP3D_TN_LAUNCH(WM_, WN_, VY_, VA_)                                                                          \
+    hipLaunchKernelGGL((gemm_tn_partial_kernel<WM_, WN_, VY_, VA_>), grid, dim3(TN_BLOCK), 0, s, dY, A, M, N, K,        \
+                       p.rows_per_split, p.tiles_k, workspace)
 #define TP3D_TN_ALIGN(WM_, WN_)                                                                                     \
     do {                                                                                                            \
-        if (pro) TP3D_TN_LAUNCH(WM_, WN_, true, true, true);                                                        \
-        else if (vy && va) TP3D_TN_LAUNCH(WM_, WN_, true, true, false);                                             \
-        else if (vy) TP3D_TN_LAUNCH(WM_, WN_, true, false, false);                                                  \
-        else if (va) TP3D_TN_LAUNCH(WM_, WN_, false, true, false);                                                  \
-        else TP3D_TN_LAUNCH(WM_, WN_, false, false, false);                                                         \
+        if (vy && va) TP3D_TN_LAUNCH(WM_, WN_, true, true);                                                         \
+        else if (vy) TP3D_TN_LAUNCH(WM_, WN_, true, false);                                                         \
+        else if (va) TP3D_TN_LAUNCH(WM_, WN_, false, true);                                                         \
+        else TP3D_TN_LAUNCH(WM_, WN_, false, false);                                                                \
     } while (0)
     if (p.gn == 1) {
-        if (pro) return TP3D_E_BADARG;  // (the fused operands are not instantiated for the 1 x 4 wave grid)
-        if (vy && va) hipLaunchKernelGGL((gemm_tn_partial_kernel<1, 1, true, true, false, 1>), grid, dim3(TN_BLOCK), 0, s, dY, A, M, N,
-                                         K, p.rows_per_split, p.tiles_k, workspace, none);
-        else if (va) hipLaunchKernelGGL((gemm_tn_partial_kernel<1, 1, false, true, false, 1>), grid, dim3(TN_BLOCK), 0, s, dY, A, M,
-                                        N, K, p.rows_per_split, p.tiles_k, workspace, none);
-        else if (vy) hipLaunchKernelGGL((gemm_tn_partial_kernel<1, 1, true, false, false, 1>), grid, dim3(TN_BLOCK), 0, s, dY, A, M,
-                                        N, K, p.rows_per_split, p.tiles_k, workspace, none);
-        else hipLaunchKernelGGL((gemm_tn_partial_kernel<1, 1, false, false, false, 1>), grid, dim3(TN_BLOCK), 0, s, dY, A, M, N, K,
-                                p.rows_per_split, p.tiles_k, workspace, none);
+        if (vy && va) hipLaunchKernelGGL((gemm_tn_partial_kernel<1, 1, true, true, 1>), grid, dim3(TN_BLOCK), 0, s, dY, A, M, N, K,
+                                         p.rows_per_split, p.tiles_k, workspace);
+        else if (va) hipLaunchKernelGGL((gemm_tn_partial_kernel<1, 1, false, true, 1>), grid, dim3(TN_BLOCK), 0, s, dY, A, M, N, K,
+                                        p.rows_per_split, p.tiles_k, workspace);
+        else if (vy) hipLaunchKernelGGL((gemm_tn_partial_kernel<1, 1, true, false, 1>), grid, dim3(TN_BLOCK), 0, s, dY, A, M, N, K,
+                                        p.rows_per_split, p.tiles_k, workspace);
+        else hipLaunchKernelGGL((gemm_tn_partial_kernel<1, 1, false, false, 1>), grid, dim3(TN_BLOCK), 0, s, dY, A, M, N, K,
+                                p.rows_per_split, p.tiles_k, workspace);
     } else if (p.wm == 2 && p.wn == 3) TP3D_TN_ALIGN(2, 3);
     else if (p.wn == 3) TP3D_TN_ALIGN(1, 3);
     else if (p.wm == 2 && p.wn == 2) TP3D_TN_ALIGN(2, 2);
@@ -380,29 +280,5 @@ TP3D_EXPORT int tp3d_gemm_tn_f32(const float *dY, const float *A, int64_t M, int
     hipStream_t s = (hipStream_t)stream;
     if (M == 0) return zero_async(out, (size_t)N * K * sizeof(float), s);
     if (!dY || !A || !workspace) return TP3D_E_BADARG;
-    return launch_tn(dY, A, M, N, K, out, workspace, nullptr, s);
-}
-
-// The same contraction with both operands formed while they are staged (see the file header):
-//   Y (M,N), dA ((M,N), or (M/ns,N) with argmax), statistics rows of the layer (N each), c1 / c2 from
-//   tp3d_bn_bwd_reduce_f32;  A operand: either plain rows A (M,K) (mean_k == NULL) or the previous layer's pre-BatchNorm
-//   output with its statistics rows (K each).  N % 4 == 0 and K % 4 == 0.
-TP3D_EXPORT int tp3d_gemm_tn_bn_f32(const float *Y, const float *dA, const int *argmax, int ns, const float *mean_n,
-                                    const float *scale_n, const float *beta_n, const float *c1_n, const float *c2_n,
-                                    float slope_n, const float *A, const float *mean_k, const float *scale_k,
-                                    const float *beta_k, float slope_k, int64_t M, int N, int K, float *out,
-                                    float *workspace, void *stream)
-{
-    if (M < 0 || N <= 0 || K <= 0 || !out || ns <= 0) return TP3D_E_BADARG;
-    hipStream_t s = (hipStream_t)stream;
-    if (M == 0) return zero_async(out, (size_t)N * K * sizeof(float), s);
-    if (!Y || !A || !workspace) return TP3D_E_BADARG;
-    if (dA && (!mean_n || !scale_n || !beta_n || !c1_n || !c2_n)) return TP3D_E_BADARG;  // dA == NULL: Y is dY itself
-    if (mean_k && (!scale_k || !beta_k)) return TP3D_E_BADARG;
-    if (argmax && (!dA || M % ns)) return TP3D_E_BADARG;
-    TnPrologue pro = {};
-    pro.dA = dA, pro.argmax = argmax, pro.mean_n = mean_n, pro.scale_n = scale_n, pro.beta_n = beta_n, pro.c1_n = c1_n;
-    pro.c2_n = c2_n, pro.slope_n = slope_n, pro.ns = ns;
-    pro.mean_k = mean_k, pro.scale_k = scale_k, pro.beta_k = beta_k, pro.slope_k = slope_k;
-    return launch_tn(Y, A, M, N, K, out, workspace, &pro, s);
+    return launch_tn(dY, A, M, N, K, out, workspace, s);
 }

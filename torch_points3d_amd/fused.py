@@ -424,15 +424,18 @@ class _MLPChain(torch.autograd.Function):
     row matrix, with every BatchNorm / activation pass folded into the GEMM that consumes its result
     (core/common_modules/dense_modules.py:25-29 forward, autograd backward):
 
-      forward   Y_0 = A_0 W_0^T;  Y_l = act(BN(Y_{l-1})) W_l^T  -- the activated tensor is formed in the GEMM's prologue
-                from Y_{l-1}, never written; BatchNorm statistics come out of each GEMM's epilogue
-      backward  per layer one reduction pass (dbeta, dgamma), then
-                dW_l     = dY_l^T act(BN(Y_{l-1}))   both operands formed on the fly (tp3d_gemm_tn_bn_f32)
-                dA_{l-1} = dY_l W_l                  dY_l formed on the fly       (tp3d_gemm_rows_bnbwd_f32)
+      forward   Y_0 = A_0 W_0^T;  Y_l = act(BN(Y_{l-1})) W_l^T  -- the activated tensor is formed by the GEMM's loader waves
+                from Y_{l-1} (tp3d_gemm_rows_bnact_x3_f32 / _sp_f32), never written; BatchNorm statistics come out of each
+                GEMM's epilogue
+      backward  per layer the reductions (dbeta, dgamma -- a pass of their own, or riding on the weight-gradient kernel of
+                the layer above, tp3d_gemm_tn_x3_act_red_f32), then
+                dA_{l-1} = dY_l W_l                  dY_l formed by the loader waves, written once as a side output
+                                                     (tp3d_gemm_rows_bnbwd_sp_f32)
+                dW_l     = dY_l^T act(BN(Y_{l-1}))   the activated operand formed by the loader waves (tp3d_gemm_tn_x3_act_f32)
                 with dY_l = BatchNorm+activation backward of (dA_l, Y_l)
 
-    Per hidden layer the activation-sized traffic drops from 4 passes to 2 forward and from 9 to 7 backward, and only
-    the pre-BatchNorm outputs Y_l are kept for the backward pass."""
+    Only the pre-BatchNorm outputs Y_l are kept for the backward pass (plus the activated rows of the layers whose weight
+    gradient the bf16-pipe kernel does not serve)."""
 
     @staticmethod
     def forward(ctx, A0, pool_ns, layers, grad_cols, *params):
@@ -446,7 +449,7 @@ class _MLPChain(torch.autograd.Function):
         Ys, stats, W2s, cins, acts = [], [], [], [], []
         training = layers[0][0].training
         # under torch.no_grad() the parameters still report requires_grad: no side outputs for a backward that cannot come
-        keep_acts = CHAIN_LOADER and _outer_grad and any(ctx.needs_input_grad)
+        keep_acts = _outer_grad and any(ctx.needs_input_grad)
         h = _lib.load()
         prev_rev = 0  # the producer of A0 wrote front to back
         with _lib.on_device(dev):
@@ -464,7 +467,7 @@ class _MLPChain(torch.autograd.Function):
                 # that shape its loader waves form them again from Y_{l-1} (tp3d_gemm_tn_x3_act_f32) and nothing is kept
                 keep_act = keep_acts and not (WGRAD_X3 and WGRAD_X3_ACT and l > 0 and ctx.needs_input_grad[4 + 3 * l]
                                               and h.tp3d_gemm_tn_x3_serves(M, Cout, Kp))
-                sp_chunks = h.tp3d_gemm_rows_sp_chunks(M, Cout, Kp, int(keep_act)) if (l > 0 and CHAIN_LOADER) else 0
+                sp_chunks = h.tp3d_gemm_rows_sp_chunks(M, Cout, Kp, int(keep_act)) if l > 0 else 0
                 sp_entry = "tp3d_gemm_rows_bnact_sp_f32"
                 if sp_chunks and FWD_X3 and h.tp3d_gemm_rows_x3_chunks(M, Cout, Kp, int(keep_act)):
                     sp_chunks = h.tp3d_gemm_rows_x3_chunks(M, Cout, Kp, int(keep_act))
@@ -474,7 +477,7 @@ class _MLPChain(torch.autograd.Function):
                 rev = int(ROW_ORDER_ALTERNATE and not prev_rev)  # (used by the kernels that take a direction; the others walk
                 prev_rev = rev                                   # front to back -- corrected below)
                 chunks = None
-                x3_first = h.tp3d_gemm_rows_x3_chunks(M, Cout, Kp, 0) if (l == 0 and FWD_X3 and CHAIN_LOADER) else 0
+                x3_first = h.tp3d_gemm_rows_x3_chunks(M, Cout, Kp, 0) if (l == 0 and FWD_X3) else 0
                 if x3_first:
                     # the first layer on the bf16 pipe as well: the same kernel with the identity as its prologue
                     # ((y - 0) * 1 + 0, slope 1) -- 524288 x 128 x 132: 229 us on the fp32 rows kernel
@@ -502,7 +505,7 @@ class _MLPChain(torch.autograd.Function):
                               layers[l - 1][1], _lib.ptr(W2), M, Cout, Kp, _lib.ptr(Y), _lib.ptr(part), _lib.ptr(act), rev, st)
                     chunks = sp_chunks
                     acts.append(act)
-                elif CHAIN_LOADER:
+                else:
                     # a width the split-role kernel does not serve: the separate pass, then the plain rows GEMM
                     ps = stats[-1]
                     act = torch.empty((M, Kp), dtype=torch.float32, device=dev)
@@ -511,12 +514,6 @@ class _MLPChain(torch.autograd.Function):
                     part = _lib.workspace("gemm_rows_stats", 4 * h.tp3d_gemm_rows_stat_floats(M, Cout), dev) if training else None
                     _lib.call("tp3d_gemm_rows_f32", _lib.ptr(act), _lib.ptr(W2), M, Cout, Kp, _lib.ptr(Y), _lib.ptr(part), None, st)
                     acts.append(act if keep_act else None)
-                    prev_rev = 0
-                else:
-                    ps = stats[-1]
-                    part = _lib.workspace("gemm_rows_stats", 4 * h.tp3d_gemm_rows_stat_floats(M, Cout), dev) if training else None
-                    _lib.call("tp3d_gemm_rows_bnact_f32", _lib.ptr(Ys[-1]), _lib.ptr(ps[0]), _lib.ptr(ps[2]), _lib.ptr(ps[3]),
-                              layers[l - 1][1], _lib.ptr(W2), M, Cout, Kp, _lib.ptr(Y), _lib.ptr(part), st)
                     prev_rev = 0
                 if training:
                     stats.append(_finalize_stats(part, M, Cout, gamma, beta, bn, dev, st, chunks))
@@ -556,152 +553,119 @@ class _MLPChain(torch.autograd.Function):
         dcur = grad_out.contiguous()
         grads = [None] * (3 * L)
         dA0 = None
-        if ctx.layerwise:
-            # the activated rows were kept (side outputs of the forward kernels): the layer-wise backward passes
-            acts = saved[2 + 3 * L:2 + 3 * L + (L - 1)]
-            h = _lib.load()
+        if not ctx.layerwise:  # (the forward pass saw no gradient request: it kept no operands for this)
+            raise RuntimeError("_MLPChain.backward: the forward pass ran without a gradient request (call through fused._apply)")
+        # the activated rows were kept (side outputs of the forward kernels): the layer-wise backward passes
+        acts = saved[2 + 3 * L:2 + 3 * L + (L - 1)]
+        h = _lib.load()
 
-            def route(l):
-                """how layer l's backward runs: (kind, columns of the input gradient that are contracted)"""
-                C_, Kp_ = W2s[l].shape
-                pooled_ = bool(pool_ns) and l == L - 1
-                want_prev_ = l > 0 or ctx.needs_input_grad[0]
-                # the grouped rows' producer reads the gradient of the feature columns only: contract just those
-                cols_ = ctx.grad_cols if (l == 0 and ctx.grad_cols is not None and ctx.grad_cols[1] >= ROWS_GEMM_MIN_COLS) else None
-                ncol_ = cols_[1] if cols_ else Kp_
-                pow2 = pooled_ and pool_ns >= 64 and (pool_ns & (pool_ns - 1)) == 0
-                if (CHAIN_BWD_LOADER and (not pooled_ or (CHAIN_BWD_POOLED and pow2)) and want_prev_
-                        and h.tp3d_gemm_rows_bnbwd_sp_serves(M, ncol_, C_)):
-                    return "loader", cols_
-                if (WGRAD_NARROW and not pooled_ and not want_prev_ and ctx.needs_input_grad[4 + 3 * l] and l == 0
-                        and h.tp3d_gemm_tn_bn_narrow_serves(M, C_, Kp_)):
-                    return "narrow", cols_
-                return "passes", cols_
+        def route(l):
+            """how layer l's backward runs: (kind, columns of the input gradient that are contracted)"""
+            C_, Kp_ = W2s[l].shape
+            pooled_ = bool(pool_ns) and l == L - 1
+            want_prev_ = l > 0 or ctx.needs_input_grad[0]
+            # the grouped rows' producer reads the gradient of the feature columns only: contract just those
+            cols_ = ctx.grad_cols if (l == 0 and ctx.grad_cols is not None and ctx.grad_cols[1] >= ROWS_GEMM_MIN_COLS) else None
+            ncol_ = cols_[1] if cols_ else Kp_
+            pow2 = pooled_ and pool_ns >= 64 and (pool_ns & (pool_ns - 1)) == 0
+            if (CHAIN_BWD_LOADER and (not pooled_ or (CHAIN_BWD_POOLED and pow2)) and want_prev_
+                    and h.tp3d_gemm_rows_bnbwd_sp_serves(M, ncol_, C_)):
+                return "loader", cols_
+            if (WGRAD_NARROW and not pooled_ and not want_prev_ and ctx.needs_input_grad[4 + 3 * l] and l == 0
+                    and h.tp3d_gemm_tn_bn_narrow_serves(M, C_, Kp_)):
+                return "narrow", cols_
+            return "passes", cols_
 
-            # consecutive big kernels walk the rows in opposite directions: each starts on the rows its predecessor touched
-            # last, which the memory-side cache (256 MB against 268 MB per activation matrix) still holds
-            turn = [True]  # the producer of grad_out wrote front to back
+        # consecutive big kernels walk the rows in opposite directions: each starts on the rows its predecessor touched
+        # last, which the memory-side cache (256 MB against 268 MB per activation matrix) still holds
+        turn = [True]  # the producer of grad_out wrote front to back
 
-            def direction():
-                rev_ = int(ROW_ORDER_ALTERNATE and turn[0])
-                turn[0] = not turn[0]
-                return rev_
+        def direction():
+            rev_ = int(ROW_ORDER_ALTERNATE and turn[0])
+            turn[0] = not turn[0]
+            return rev_
 
-            def reduce_pass(l, dA_l):
-                """dbeta, dgamma, c1, c2 of layer l from the gradient of its activated (or pooled) output"""
-                C_ = W2s[l].shape[0]
-                pooled_ = bool(pool_ns) and l == L - 1
-                a_ptr_, ns_ = (_lib.ptr(arg), pool_ns) if pooled_ else (None, 1)
-                red_ = torch.empty((4, C_), dtype=torch.float32, device=dev)
-                ls_ = stats[l]
-                _lib.call("tp3d_bn_bwd_reduce_f32", _lib.ptr(dA_l), a_ptr_, _lib.ptr(Ys[l]), _lib.ptr(ls_[2]), _lib.ptr(ls_[3]),
-                          _lib.ptr(ls_[0]), _lib.ptr(ls_[1]), slopes[l], M, ns_, C_, int(training), _lib.ptr(red_[0]),
-                          _lib.ptr(red_[1]), _lib.ptr(red_[2]), _lib.ptr(red_[3]), _lib.ptr(_lib.bn_workspace(M, C_, dev)), direction(), st)
-                return red_
+        def reduce_pass(l, dA_l):
+            """dbeta, dgamma, c1, c2 of layer l from the gradient of its activated (or pooled) output"""
+            C_ = W2s[l].shape[0]
+            pooled_ = bool(pool_ns) and l == L - 1
+            a_ptr_, ns_ = (_lib.ptr(arg), pool_ns) if pooled_ else (None, 1)
+            red_ = torch.empty((4, C_), dtype=torch.float32, device=dev)
+            ls_ = stats[l]
+            _lib.call("tp3d_bn_bwd_reduce_f32", _lib.ptr(dA_l), a_ptr_, _lib.ptr(Ys[l]), _lib.ptr(ls_[2]), _lib.ptr(ls_[3]),
+                      _lib.ptr(ls_[0]), _lib.ptr(ls_[1]), slopes[l], M, ns_, C_, int(training), _lib.ptr(red_[0]),
+                      _lib.ptr(red_[1]), _lib.ptr(red_[2]), _lib.ptr(red_[3]), _lib.ptr(_lib.bn_workspace(M, C_, dev)), direction(), st)
+            return red_
 
-            red_next = None  # reductions of the next layer down, when the weight-gradient kernel above it produced them
-            with _lib.on_device(dev):
-                for l in range(L - 1, -1, -1):
-                    Y, ls, W2, slope = Ys[l], stats[l], W2s[l], slopes[l]
-                    C, Kp = W2.shape
-                    pooled = bool(pool_ns) and l == L - 1
-                    kind, cols = route(l)
-                    ncol = cols[1] if cols else Kp
-                    red_have, red_next = red_next, None
-                    if kind == "loader":
-                        # reduction pass, then the input-gradient GEMM whose loader waves form dY (side output for dW)
-                        dY = torch.empty_like(Y)
-                        a_ptr, ns = (_lib.ptr(arg), pool_ns) if pooled else (None, 1)
-                        red = red_have if red_have is not None else reduce_pass(l, dcur)
-                        grads[3 * l + 1], grads[3 * l + 2] = red[1], red[0]
-                        # dA_{l-1}[M,Kp] = dY_l[M,C] (W^T)[Kp,C]^T (a transposed copy of the weight: reading it as stored, four
-                        # strided scalars per slot, made the loader waves the bottleneck -- 8.55 vs 8.32 ms/step)
-                        dprev = torch.empty((M, Kp), dtype=torch.float32, device=dev)
-                        c0 = cols[0] if cols else 0
-                        pad_hi = Kp - c0 - ncol
-                        Wt = W2.t()[c0:c0 + ncol].contiguous()
-                        if c0 > 32 or pad_hi > 32:  # (never with grouped / interpolated rows: 3 and <= 3 columns)
-                            dprev.zero_()
-                            pad_lo_k = pad_hi_k = 0
-                        else:
-                            pad_lo_k, pad_hi_k = c0, pad_hi
-                        _lib.call("tp3d_gemm_rows_bnbwd_sp_f32", _lib.ptr(Y), _lib.ptr(dcur), _lib.ptr(ls[0]), _lib.ptr(ls[2]),
-                                  _lib.ptr(ls[3]), _lib.ptr(red[2]), _lib.ptr(red[3]), slope, _lib.ptr(Wt), M, ncol, C,
-                                  _lib.ptr(dprev) + 4 * c0, Kp, pad_lo_k, pad_hi_k,
-                                  _lib.ptr(dY) if ctx.needs_input_grad[4 + 3 * l] else None, a_ptr, ns, direction(), st)
-                        if ctx.needs_input_grad[4 + 3 * l]:
-                            both = None
-                            if WGRAD_RED and l > 0 and acts[l - 1] is None and route(l - 1)[0] != "passes":
-                                # Y_{l-1} streams through this contraction anyway: the layer below gets its reductions here
-                                both = _chain_wgrad_red(dY, l, Ys, stats, slopes, dprev, training, direction())
-                            if both is not None:
-                                dW, red_next = both
-                            else:
-                                dW = _chain_wgrad(dY, l, A0, acts, Ys, stats, slopes, direction())
-                            grads[3 * l] = dW[:, :cins[l]].reshape(wshapes[l])
-                        dcur = dprev
-                        if l == 0:
-                            dA0 = dprev
-                        continue
-                    if kind == "narrow":
-                        # the first layer of grouped rows (a handful of input channels, nobody reads their gradient): the
-                        # reduction pass, then dW straight from (Y, dA, A0) -- dY is never written
-                        red = red_have if red_have is not None else reduce_pass(l, dcur)
-                        grads[3 * l + 1], grads[3 * l + 2] = red[1], red[0]
-                        dW = torch.empty((C, Kp), dtype=torch.float32, device=dev)
-                        nws = _lib.workspace("gemm_tn_narrow", 4 * h.tp3d_gemm_tn_bn_narrow_workspace_floats(M, C, Kp), dev)
-                        _lib.call("tp3d_gemm_tn_bn_narrow_f32", _lib.ptr(Y), _lib.ptr(dcur), _lib.ptr(ls[0]), _lib.ptr(ls[2]),
-                                  _lib.ptr(ls[3]), _lib.ptr(red[2]), _lib.ptr(red[3]), slope, _lib.ptr(A0), M, C, Kp, _lib.ptr(dW),
-                                  _lib.ptr(nws), direction(), st)
-                        grads[3 * l] = dW[:, :cins[l]].reshape(wshapes[l])
-                        continue
-                    dY = torch.empty_like(Y)
-                    ws = _lib.bn_workspace(M, C, dev)
-                    dgb = torch.empty((2, C), dtype=torch.float32, device=dev)  # dbeta, dgamma
-                    _lib.call("tp3d_bn_act_bwd_f32", _lib.ptr(dcur), _lib.ptr(arg) if pooled else None, _lib.ptr(Y), _lib.ptr(ls[2]),
-                              _lib.ptr(ls[3]), _lib.ptr(ls[0]), _lib.ptr(ls[1]), slope, M, pool_ns if pooled else 1, C,
-                              int(training), _lib.ptr(dgb[0]), _lib.ptr(dgb[1]), _lib.ptr(dY), _lib.ptr(ws), st)
-                    grads[3 * l + 1], grads[3 * l + 2] = dgb[1], dgb[0]
-                    if ctx.needs_input_grad[4 + 3 * l]:
-                        grads[3 * l] = _chain_wgrad(dY, l, A0, acts, Ys, stats, slopes)[:, :cins[l]].reshape(wshapes[l])
-                    if l > 0 or ctx.needs_input_grad[0]:
-                        dcur = torch.mm(dY, W2)
-                        if l == 0:
-                            dA0 = dcur
-            return (dA0, None, None, None) + tuple(grads)
+        red_next = None  # reductions of the next layer down, when the weight-gradient kernel above it produced them
         with _lib.on_device(dev):
             for l in range(L - 1, -1, -1):
                 Y, ls, W2, slope = Ys[l], stats[l], W2s[l], slopes[l]
                 C, Kp = W2.shape
                 pooled = bool(pool_ns) and l == L - 1
-                a_ptr, ns = (_lib.ptr(arg), pool_ns) if pooled else (None, 1)
-                red = torch.empty((4, C), dtype=torch.float32, device=dev)  # dbeta, dgamma, c1, c2
-                ws = _lib.bn_workspace(M, C, dev)
-                _lib.call("tp3d_bn_bwd_reduce_f32", _lib.ptr(dcur), a_ptr, _lib.ptr(Y), _lib.ptr(ls[2]), _lib.ptr(ls[3]),
-                          _lib.ptr(ls[0]), _lib.ptr(ls[1]), slope, M, ns, C, int(training), _lib.ptr(red[0]), _lib.ptr(red[1]),
-                          _lib.ptr(red[2]), _lib.ptr(red[3]), _lib.ptr(ws), 0, st)
-                grads[3 * l + 1], grads[3 * l + 2] = red[1], red[0]
-                if ctx.needs_input_grad[4 + 3 * l]:
-                    dW = torch.empty((C, Kp), dtype=torch.float32, device=dev)
-                    tws = _lib.gemm_tn_workspace(M, C, Kp, dev)
-                    if l == 0:
-                        a_src, km, ks_, kb, kslope = A0, None, None, None, 1.0
-                    else:
-                        ps = stats[l - 1]
-                        a_src, km, ks_, kb, kslope = Ys[l - 1], _lib.ptr(ps[0]), _lib.ptr(ps[2]), _lib.ptr(ps[3]), slopes[l - 1]
-                    _lib.call("tp3d_gemm_tn_bn_f32", _lib.ptr(Y), _lib.ptr(dcur), a_ptr, ns, _lib.ptr(ls[0]), _lib.ptr(ls[2]),
-                              _lib.ptr(ls[3]), _lib.ptr(red[2]), _lib.ptr(red[3]), slope, _lib.ptr(a_src), km, ks_, kb, kslope,
-                              M, C, Kp, _lib.ptr(dW), _lib.ptr(tws), st)
-                    grads[3 * l] = dW[:, :cins[l]].reshape(wshapes[l])
-                if l > 0 or ctx.needs_input_grad[0]:
-                    Wt = W2.t().contiguous()  # (Kp, C): dA_{l-1}[M,Kp] = dY_l[M,C] (W^T)[Kp,C]^T
+                kind, cols = route(l)
+                ncol = cols[1] if cols else Kp
+                red_have, red_next = red_next, None
+                if kind == "loader":
+                    # reduction pass, then the input-gradient GEMM whose loader waves form dY (side output for dW)
+                    dY = torch.empty_like(Y)
+                    a_ptr, ns = (_lib.ptr(arg), pool_ns) if pooled else (None, 1)
+                    red = red_have if red_have is not None else reduce_pass(l, dcur)
+                    grads[3 * l + 1], grads[3 * l + 2] = red[1], red[0]
+                    # dA_{l-1}[M,Kp] = dY_l[M,C] (W^T)[Kp,C]^T (a transposed copy of the weight: reading it as stored, four
+                    # strided scalars per slot, made the loader waves the bottleneck -- 8.55 vs 8.32 ms/step)
                     dprev = torch.empty((M, Kp), dtype=torch.float32, device=dev)
-                    _lib.call("tp3d_gemm_rows_bnbwd_f32", _lib.ptr(Y), _lib.ptr(dcur), a_ptr, ns, _lib.ptr(ls[0]),
-                              _lib.ptr(ls[2]), _lib.ptr(ls[3]), _lib.ptr(red[2]), _lib.ptr(red[3]), slope, _lib.ptr(Wt), M, Kp, C,
-                              _lib.ptr(dprev), st)
+                    c0 = cols[0] if cols else 0
+                    pad_hi = Kp - c0 - ncol
+                    Wt = W2.t()[c0:c0 + ncol].contiguous()
+                    if c0 > 32 or pad_hi > 32:  # (never with grouped / interpolated rows: 3 and <= 3 columns)
+                        dprev.zero_()
+                        pad_lo_k = pad_hi_k = 0
+                    else:
+                        pad_lo_k, pad_hi_k = c0, pad_hi
+                    _lib.call("tp3d_gemm_rows_bnbwd_sp_f32", _lib.ptr(Y), _lib.ptr(dcur), _lib.ptr(ls[0]), _lib.ptr(ls[2]),
+                              _lib.ptr(ls[3]), _lib.ptr(red[2]), _lib.ptr(red[3]), slope, _lib.ptr(Wt), M, ncol, C,
+                              _lib.ptr(dprev) + 4 * c0, Kp, pad_lo_k, pad_hi_k,
+                              _lib.ptr(dY) if ctx.needs_input_grad[4 + 3 * l] else None, a_ptr, ns, direction(), st)
+                    if ctx.needs_input_grad[4 + 3 * l]:
+                        both = None
+                        if WGRAD_RED and l > 0 and acts[l - 1] is None and route(l - 1)[0] != "passes":
+                            # Y_{l-1} streams through this contraction anyway: the layer below gets its reductions here
+                            both = _chain_wgrad_red(dY, l, Ys, stats, slopes, dprev, training, direction())
+                        if both is not None:
+                            dW, red_next = both
+                        else:
+                            dW = _chain_wgrad(dY, l, A0, acts, Ys, stats, slopes, direction())
+                        grads[3 * l] = dW[:, :cins[l]].reshape(wshapes[l])
                     dcur = dprev
                     if l == 0:
                         dA0 = dprev
+                    continue
+                if kind == "narrow":
+                    # the first layer of grouped rows (a handful of input channels, nobody reads their gradient): the
+                    # reduction pass, then dW straight from (Y, dA, A0) -- dY is never written
+                    red = red_have if red_have is not None else reduce_pass(l, dcur)
+                    grads[3 * l + 1], grads[3 * l + 2] = red[1], red[0]
+                    dW = torch.empty((C, Kp), dtype=torch.float32, device=dev)
+                    nws = _lib.workspace("gemm_tn_narrow", 4 * h.tp3d_gemm_tn_bn_narrow_workspace_floats(M, C, Kp), dev)
+                    _lib.call("tp3d_gemm_tn_bn_narrow_f32", _lib.ptr(Y), _lib.ptr(dcur), _lib.ptr(ls[0]), _lib.ptr(ls[2]),
+                              _lib.ptr(ls[3]), _lib.ptr(red[2]), _lib.ptr(red[3]), slope, _lib.ptr(A0), M, C, Kp, _lib.ptr(dW),
+                              _lib.ptr(nws), direction(), st)
+                    grads[3 * l] = dW[:, :cins[l]].reshape(wshapes[l])
+                    continue
+                dY = torch.empty_like(Y)
+                ws = _lib.bn_workspace(M, C, dev)
+                dgb = torch.empty((2, C), dtype=torch.float32, device=dev)  # dbeta, dgamma
+                _lib.call("tp3d_bn_act_bwd_f32", _lib.ptr(dcur), _lib.ptr(arg) if pooled else None, _lib.ptr(Y), _lib.ptr(ls[2]),
+                          _lib.ptr(ls[3]), _lib.ptr(ls[0]), _lib.ptr(ls[1]), slope, M, pool_ns if pooled else 1, C,
+                          int(training), _lib.ptr(dgb[0]), _lib.ptr(dgb[1]), _lib.ptr(dY), _lib.ptr(ws), st)
+                grads[3 * l + 1], grads[3 * l + 2] = dgb[1], dgb[0]
+                if ctx.needs_input_grad[4 + 3 * l]:
+                    grads[3 * l] = _chain_wgrad(dY, l, A0, acts, Ys, stats, slopes)[:, :cins[l]].reshape(wshapes[l])
+                if l > 0 or ctx.needs_input_grad[0]:
+                    dcur = torch.mm(dY, W2)
+                    if l == 0:
+                        dA0 = dcur
         return (dA0, None, None, None) + tuple(grads)
 
 
@@ -716,20 +680,18 @@ def _chain_ok(rows, parts):
     return True
 
 
-CHAIN_BWD_POOLED = True  # ... also for the max-pooled last layer of a set-abstraction MLP (groups of 64, 128 ... rows)
+# The switches of the chain (each the A/B handle of a measured step, `bench.py --set NAME=0|1`; DESIGN.md section 5 has
+# the numbers).  The first design -- prologues in the MFMA waves of the plain rows / weight-gradient kernels, the backward
+# pass fused the same way (12.0 vs 10.3 ms/step) -- left the tree in round 3 together with its three entry points.
+USE_MLP_CHAIN = True        # whole shared MLPs as one autograd node on the split-role / bf16-pipe kernels (else layer by layer)
+CHAIN_BWD_LOADER = True     # input-gradient GEMMs form dY in their loader waves (else: apply pass + library GEMM)
+CHAIN_BWD_POOLED = True     # ... also for the max-pooled last layer of a set-abstraction MLP (groups of 64, 128 ... rows)
 ROW_ORDER_ALTERNATE = True  # consecutive big kernels of a chain walk the rows in opposite directions (`reverse`, tp3d_hip.h)
 WGRAD_NARROW = True  # first layer of grouped rows (<= 16 input channels, no input gradient wanted): dW from (Y, dA, A0) in one
                      # streaming kernel (tp3d_gemm_tn_bn_narrow_f32) instead of the dY pass + the 64-column MFMA tile kernel
+FWD_NARROW = True    # ... and its forward contraction (tp3d_gemm_rows_narrow_f32) instead of the MFMA tile kernel
 WGRAD_RED = True     # a hidden layer's weight-gradient kernel also runs the BatchNorm-backward reductions of the layer below
                      # (tp3d_gemm_tn_x3_act_red_f32: Y of that layer streams through its loader waves anyway)
-FWD_NARROW = True    # ... and its forward contraction (tp3d_gemm_rows_narrow_f32) instead of the MFMA tile kernel
-CHAIN_BWD_LOADER = True  # the chain's input-gradient GEMMs form dY in their loader waves (else: apply pass + library GEMM)
-CHAIN_LOADER = True    # hidden layers' BatchNorm + activation in the loader waves of the split-role GEMM, activated rows as
-                       # its side output, layer-wise backward (else: the prologue / backward-fused variants in the MFMA waves)
-USE_MLP_CHAIN = True   # loader mode measured (tools/exp_r02c.sh): 8.88 vs 9.08 ms/step, forward 3.61 vs 3.86 ms.  With
-                       # CHAIN_LOADER off the chain is the first design (prologues in the MFMA waves, backward fused as well):
-                       # 12.0 vs 10.3 ms/step -- the prologue arithmetic and the second operand stream push those GEMMs to one
-                       # wave per SIMD; kept for the experiments DESIGN.md records
 
 
 class _BNAct(torch.autograd.Function):
