@@ -90,8 +90,6 @@ class ShardedStep(object):
         loss = self.loss_fn()
         # fresh gradient tensors (no per-parameter "+=" kernels), packed into the flat buffer by one concatenation
         grads = torch.autograd.grad(loss, self.params, allow_unused=True)
-        if self._fused is not None:
-            self._fused.join_wgrad_stream()  # weight-gradient GEMMs issued on the side stream (fused.OVERLAP_WGRAD)
         pieces = []
         for g, p, pad in zip(grads, self.params, self._pads):
             # a parameter the loss does not reach gets a zero gradient (DDP: find_unused_parameters)

@@ -243,8 +243,6 @@ def note_graph_replay():
 
 ROWS_GEMM_MIN_COLS = 32   # narrower outputs (class scores, edge MLPs) stay on the library / skinny kernels
 ROWS_GEMM_NARROW = True   # widths served by the 128 x 64 tiles (N % 128 in 1..64) on the rows kernel (else library GEMM)
-ROWS_GEMM_DX = False      # input-gradient contractions on the rows kernel; measured 0.22 ms/step slower than the
-                          # library GEMM on the BASELINE step (tools/exp_r02.sh), so off
 CHAIN_MIN_ROWS = 32768    # the fused layer chain serves the large row matrices (grouped / per-point activations)
 
 
@@ -252,30 +250,6 @@ def _rows_gemm_serves(cout):
     if not USE_ROWS_GEMM or cout < ROWS_GEMM_MIN_COLS:
         return False
     return ROWS_GEMM_NARROW or not (0 < cout % 128 <= 64)
-
-
-# Weight-gradient GEMMs on a second stream.  dW_l = dY_l^T A_l is needed only by the optimizer, while the backward chain
-# continues with dA_{l-1} and the HBM-bound BatchNorm backward of the next layer: an MFMA-bound kernel beside a
-# bandwidth-bound one.  Opt-in (a stepper that calls join_wgrad_stream() before it reads the gradients -- dp.ShardedStep
-# does): plain loss.backward() users keep everything on one stream.
-OVERLAP_WGRAD = False
-WGRAD_MIN_ROWS = 65536
-_wgrad_side = {}  # device index -> [side stream, work pending]
-
-
-def _wgrad_stream(dev):
-    slot = _wgrad_side.get(dev.index)
-    if slot is None:
-        slot = _wgrad_side[dev.index] = [torch.cuda.Stream(device=dev), False]
-    return slot
-
-
-def join_wgrad_stream(device=None):
-    """the current stream waits for the weight-gradient GEMMs that were issued on the side stream (no-op otherwise)"""
-    for idx, slot in _wgrad_side.items():
-        if slot[1] and (device is None or device.index in (None, idx)):
-            torch.cuda.current_stream(slot[0].device).wait_stream(slot[0])
-            slot[1] = False
 
 
 def _long_k(M, N, K):
@@ -393,23 +367,14 @@ class _LinearBNAct(torch.autograd.Function):
                       _lib.stream_ptr(dev))
         dW = None
         if ctx.needs_input_grad[1]:
-            if OVERLAP_WGRAD and M >= WGRAD_MIN_ROWS:
-                slot = _wgrad_stream(dev)
-                slot[0].wait_stream(torch.cuda.current_stream(dev))  # dY is complete on the main stream here
-                with torch.cuda.stream(slot[0]):
-                    dW = gemm_tn(dY, A)[:, :Cin].reshape(wshape)
-                dY.record_stream(slot[0])  # the allocator must not recycle the operands before the side stream is done
-                A.record_stream(slot[0])
-                slot[1] = True
-            else:
-                dW = gemm_tn(dY, A)[:, :Cin].reshape(wshape)
+            dW = gemm_tn(dY, A)[:, :Cin].reshape(wshape)
         dA = None
         if ctx.needs_input_grad[0]:
             if _is_skinny(M, W2.shape[1], Cout):
                 dA = gemm_skinny(dY, W2.t())
-            elif ROWS_GEMM_DX and _rows_gemm_serves(W2.shape[1]) and Cout % 4 == 0:
-                dA = gemm_rows(dY, W2.t())[0]  # dA[M,Kp] = dY[M,N] (W^T)[Kp,N]^T on the same rows kernel
             else:
+                # (the library GEMM: the rows kernel was measured 0.22 ms/step slower on these input-gradient shapes, and
+                #  issuing the weight gradients on a second stream 0.3 ms slower -- round 2)
                 dA = torch.mm(dY, W2)
         dbias = None
         if has_bias and ctx.needs_input_grad[7]:
