@@ -232,6 +232,18 @@ def algorithmic_flops(name, a):
     return 0
 
 
+def shape_table(summ, steps):
+    """per (entry point, launch shape): launches, average ms, algorithmic MB and GB/s -- the `kernels` list of the side file"""
+    rows = []
+    for (name, a), (launches, total_ms) in sorted(summ.items(), key=lambda kv: -kv[1][1]):
+        avg_ms = total_ms / launches
+        nbytes = algorithmic_bytes(name, a)
+        rows.append({"entry": name, "sizes": list(a), "launches": launches, "avg_ms": round(avg_ms, 4),
+                     "ms_per_step": round(total_ms / steps, 4), "algorithmic_MB": round(nbytes / 1e6, 3),
+                     "GBps": round(nbytes / 1e9 / (avg_ms / 1e3), 2) if avg_ms > 0 else None})
+    return rows
+
+
 def entry_sums(summ):
     """{entry point: ms, launches, algorithmic bytes, flops} over all its launch shapes (KernelTimer.summary() in)."""
     per_entry = {}
@@ -621,7 +633,7 @@ def run_kpconv(args):
                                "neighbours, 13 classes), one cloud of 65536 points (BASELINE configs[3]); sampling and "
                                "searches inside the timed region", "launch": "eager"},
         "roofline": roof, "cpu_baseline": base},
-        {"entry_points": entry_table(per_entry, args.steps)}, args)
+        {"entry_points": entry_table(per_entry, args.steps), "kernels": shape_table(timer.summary(), args.steps)}, args)
 
 
 def run_knn(args):
@@ -873,15 +885,7 @@ def main():
 
     if rank == 0:
         summ = timer.summary()
-        kernels = []
-        for (name, a), (launches, total_ms) in sorted(summ.items(), key=lambda kv: -kv[1][1]):
-            avg_ms = total_ms / launches
-            nbytes = algorithmic_bytes(name, a)
-            kernels.append({
-                "entry": name, "sizes": list(a), "launches": launches, "avg_ms": round(avg_ms, 4),
-                "ms_per_step": round(total_ms / args.steps, 4), "algorithmic_MB": round(nbytes / 1e6, 3),
-                "GBps": round(nbytes / 1e9 / (avg_ms / 1e3), 2) if avg_ms > 0 else None,
-            })
+        kernels = shape_table(summ, args.steps)
         per_entry = entry_sums(summ)
         roofline = dominant_roofline(per_entry, args.steps)
         entries = entry_table(per_entry, args.steps)

@@ -170,6 +170,123 @@ __global__ __launch_bounds__(KP_BLOCK) void kpconv_weighted_kernel(
     }
 }
 
+
+// The same product on the matrix pipe (sum aggregation, <= 64 neighbours): per query the weighted features are a small GEMM,
+//   wf[k][c] = sum_n w[n][k] * f[n][c]          (16 kernel points x Mn neighbours x Cin channels),
+// and the kernel above spends its time broadcasting w out of LDS (one ds_read_b128 per four weights and per 64 channel
+// lanes: 128 reads = 1024 LDS cycles per query wave, 125 us over 65536 queries whatever Cin is) and on 512 wave-wide FMAs.
+// v_mfma_f32_16x16x4_f32 takes A = w[kernel point = lane & 15][neighbour = 4 s + (lane >> 4)] -- exactly the layout phase A
+// computes the influence weights in, so they stay in registers -- and B = f[neighbour][channel = lane & 15], a gather of
+// four 64-byte row segments per load instruction; exact fp32 multiply-adds, the 16 x 16 result per channel block in four
+// registers per lane.  LDS holds only the neighbours' ids and centred positions (1.3 KB per wave).
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr int KPM_NMAX = 64;   // neighbours per query (one lane each in step (a))
+constexpr int KPM_CB = 4;      // 16-channel blocks accumulated together (64 channels per pass)
+
+template <int SMAX>  // most MFMA steps of four neighbours: 8 (Mn <= 32) or 16 (Mn <= 64)
+__global__ __launch_bounds__(KP_BLOCK) void kpconv_weighted_mfma_kernel(
+    const float *__restrict__ query, const float *__restrict__ support, const int64_t *__restrict__ nbr,
+    const float *__restrict__ feat, const float *__restrict__ kpts, int64_t Nq, int64_t M, int Mn, int Cin, int KP,
+    float extent, int influence, int cpass, float *__restrict__ wf)
+{
+    __shared__ __attribute__((aligned(16))) float4 s_rel[KP_BLOCK / 64][KPM_NMAX];
+    __shared__ int s_id[KP_BLOCK / 64][KPM_NMAX];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t q = (int64_t)blockIdx.x * (KP_BLOCK / 64) + wave;
+    if (q >= Nq) return;  // wave-uniform; no workgroup barrier below
+    float4 *rel = s_rel[wave];
+    int *ids = s_id[wave];
+    const float qx = query[q * 3 + 0], qy = query[q * 3 + 1], qz = query[q * 3 + 2];
+    const float sigma = extent * 0.3f;
+    const float gden = 2.0f * sigma * sigma + 1e-9f;
+    const float inv_extent = 1.0f / extent;
+    const int steps = (Mn + 3) / 4;  // MFMA steps of four neighbours (<= SMAX)
+    {   // (a) lane n: neighbour n's id and centred position (rows past Mn and shadow neighbours: id -1, zero weights)
+        const int64_t id = lane < Mn ? nbr[q * Mn + lane] : -1;
+        const bool shadow = id < 0 || id >= M;
+        float4 r = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (!shadow) {
+            r.x = support[id * 3 + 0] - qx;
+            r.y = support[id * 3 + 1] - qy;
+            r.z = support[id * 3 + 2] - qz;
+        }
+        ids[lane] = shadow ? -1 : (int)id;
+        rel[lane] = r;
+    }
+    wave_lds_sync();
+    // (b) influence weights in the A-operand layout: lane = (kernel point k = lane & 15, neighbour 4 s + (lane >> 4))
+    const int k = lane & 15, nsub = lane >> 4, c16 = lane & 15;
+    const bool kreal = k < KP;
+    const float kx = kreal ? kpts[k * 3 + 0] : 0.0f, ky = kreal ? kpts[k * 3 + 1] : 0.0f, kz = kreal ? kpts[k * 3 + 2] : 0.0f;
+    float a[SMAX];
+    unsigned roff[SMAX];  // FLOAT offset of the neighbour row this lane gathers in step s (host: M * Cin < 2^30); a shadow
+                          // neighbour has zero weights and row 0 stands in for it (as in the kernel above)
+#pragma unroll
+    for (int s = 0; s < SMAX; ++s) {
+        a[s] = 0.0f;
+        roff[s] = 0;
+        if (s < steps) {
+            const int n = 4 * s + nsub;
+            const float4 r = rel[n];
+            const int id = ids[n];
+            roff[s] = (unsigned)max(id, 0) * (unsigned)Cin;
+            if (id >= 0 && kreal) {
+                const float dx = r.x - kx, dy = r.y - ky, dz = r.z - kz;
+                const float d2 = (dx * dx + dy * dy) + dz * dz;
+                if (influence == 0) a[s] = 1.0f;
+                else if (influence == 1) a[s] = fmaxf(1.0f - __builtin_amdgcn_sqrtf(d2) * inv_extent, 0.0f);
+                else a[s] = expf(-d2 / gden);
+            }
+        }
+    }
+    // (c) per pass of up to 64 channels: gather the rows (a 16-channel block per load, blocks past Cin skipped by wave-
+    // uniform branches), accumulate on the matrix pipe.  Addresses: a wave-uniform base + a 32-bit lane offset.
+    float *__restrict__ wq = wf + (size_t)q * KP * Cin;  // this query's (KP, Cin) output
+    // (few queries with many channels -- the deep levels of a U-Net -- spread their channel passes over gridDim.y: a wave per
+    //  (query, 64 channels) instead of eight serial passes in 27 waves)
+    const int c_lo = (int)blockIdx.y * cpass, c_hi = min(Cin, c_lo + cpass);
+    for (int c0 = c_lo; c0 < c_hi; c0 += 16 * KPM_CB) {
+        const int nblk = min(KPM_CB, (c_hi - c0 + 15) / 16);  // (wave-uniform)
+        f32x4 acc[KPM_CB];
+#pragma unroll
+        for (int b = 0; b < KPM_CB; ++b) acc[b] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+        const float *__restrict__ fb = feat + c0;
+        unsigned coff[KPM_CB];  // this lane's channel inside the pass, clamped to the row (lanes past Cin are not stored)
+#pragma unroll
+        for (int b = 0; b < KPM_CB; ++b) coff[b] = (unsigned)min(16 * b + c16, Cin - 1 - c0);
+#pragma unroll
+        for (int s0 = 0; s0 < SMAX; s0 += 4) {  // four steps' loads in flight (16 rows x up to 4 blocks)
+            if (s0 < steps) {
+                float v[4][KPM_CB];
+#pragma unroll
+                for (int b = 0; b < KPM_CB; ++b)
+                    if (b < nblk) {
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) v[u][b] = fb[roff[s0 + u] + coff[b]];
+                    }
+#pragma unroll
+                for (int b = 0; b < KPM_CB; ++b)
+                    if (b < nblk) {
+#pragma unroll
+                        for (int u = 0; u < 4; ++u)
+                            acc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s0 + u], v[u][b], acc[b], 0, 0, 0);
+                    }
+            }
+        }
+        // D[kernel point = 4 (lane >> 4) + j][channel = lane & 15]
+#pragma unroll
+        for (int b = 0; b < KPM_CB; ++b)
+            if (b < nblk) {
+                const int c = c0 + 16 * b + c16;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int kp = 4 * nsub + j;
+                    if (kp < KP && c < Cin) wq[(unsigned)(kp * Cin + c)] = acc[b][j];
+                }
+            }
+    }
+}
+
 }  // namespace tp3d
 
 using namespace tp3d;
@@ -190,6 +307,18 @@ TP3D_EXPORT int tp3d_kpconv_weighted_f32(const float *query, const float *suppor
     if (closest)
         hipLaunchKernelGGL(kpconv_weighted_kernel<true>, dim3((unsigned)blocks), dim3(KP_BLOCK), 0, (hipStream_t)stream,
                            query, support, neighbors, features, k_points, Nq, M, Mn, Cin, KP, extent, influence, weighted);
+    else if (Mn <= KPM_NMAX && M * (int64_t)Cin < ((int64_t)1 << 30)) {  // (the reference configs ask for 25 ... 38 neighbours)
+        const int passes = (Cin + 16 * KPM_CB - 1) / (16 * KPM_CB);
+        const bool spread = passes > 1 && Nq <= 4096;  // latency-bound launches: one wave per (query, channel pass)
+        const dim3 grid((unsigned)blocks, spread ? passes : 1);
+        const int cpass = spread ? 16 * KPM_CB : Cin;
+        if (Mn <= 32)
+            hipLaunchKernelGGL(kpconv_weighted_mfma_kernel<8>, grid, dim3(KP_BLOCK), 0, (hipStream_t)stream, query, support,
+                               neighbors, features, k_points, Nq, M, Mn, Cin, KP, extent, influence, cpass, weighted);
+        else
+            hipLaunchKernelGGL(kpconv_weighted_mfma_kernel<16>, grid, dim3(KP_BLOCK), 0, (hipStream_t)stream, query, support,
+                               neighbors, features, k_points, Nq, M, Mn, Cin, KP, extent, influence, cpass, weighted);
+    }
     else
         hipLaunchKernelGGL(kpconv_weighted_kernel<false>, dim3((unsigned)blocks), dim3(KP_BLOCK), 0, (hipStream_t)stream,
                            query, support, neighbors, features, k_points, Nq, M, Mn, Cin, KP, extent, influence, weighted);
