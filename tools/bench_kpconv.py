@@ -41,8 +41,13 @@ def main():
                     help="sampling / neighbour search / interpolation tables computed once by MultiScaleTransform "
                          "(the reference's data-loader precompute, on the device); the timed forward only convolves")
     ap.add_argument("--graph", action="store_true", help="with --precomputed: replay the forward from one HIP graph")
+    ap.add_argument("--set", action="append", default=[], metavar="NAME=VALUE",
+                    help="experiment switch: an attribute of torch_points3d_amd.fused (as bench.py --set)")
     args = ap.parse_args()
-    from torch_points3d_amd import _lib
+    from torch_points3d_amd import _lib, fused
+    for kv in args.set:
+        name, val = kv.split("=")
+        setattr(fused, name, type(getattr(fused, name))(int(val)))
     from torch_points3d_amd.kpconv_blocks import PDData
     from torch_points3d_amd.kpconv_unet import KPConv
     dev = torch.device("cuda:0")

@@ -242,6 +242,10 @@ def note_graph_replay():
 
 
 ROWS_GEMM_MIN_COLS = 32   # narrower outputs (class scores, edge MLPs) stay on the library / skinny kernels
+ROWS_GEMM_WITHOUT_STATS = True  # the rows kernel also where it has no BatchNorm statistics to fold in.  False: library GEMM
+                                # there -- the choice for inference replayed from a HIP graph (KPConv unet_4 forward 1.46 ->
+                                # 1.10 ms); launched eagerly the library's host side makes the forward slower (1.96 -> 2.24 ms).
+                                # One setting for both, so that a captured step stays bit-identical to its eager twin
 ROWS_GEMM_NARROW = True   # widths served by the 128 x 64 tiles (N % 128 in 1..64) on the rows kernel (else library GEMM)
 CHAIN_MIN_ROWS = 32768    # the fused layer chain serves the large row matrices (grouped / per-point activations)
 
@@ -319,8 +323,15 @@ class _LinearBNAct(torch.autograd.Function):
         # (93 -> 27 + 12 us on the 4096-row global layer); longer contractions go K-split for their summation order
         if own_gemm and ((M + 127) // 128) * ((Cout + 127) // 128) < 128 and 512 <= Kp < 1024:
             own_gemm = False
+        want_stats = training and not _long_k(M, Cout, Kp)
+        if own_gemm and not want_stats and not ROWS_GEMM_WITHOUT_STATS:
+            # nothing to fold into the epilogue (eval mode; K-split shapes): the library GEMM's KERNEL is faster on every
+            # such shape of the KPConv / PointNet++ networks (tools/probes/small_gemm.py: 65536 x 64 x 256 24 vs 40 us,
+            # 27 x 2048 x 1024 18 vs 63 us) but its host side costs more than this library's launch: KPConv unet_4 forward
+            # replayed from a HIP graph 1.46 -> 1.10 ms with it, launched eagerly 1.96 -> 2.24 ms
+            own_gemm = False
         if own_gemm:
-            Y, part = gemm_rows(A, W2, want_stats=training and not _long_k(M, Cout, Kp))
+            Y, part = gemm_rows(A, W2, want_stats=want_stats)
         elif _is_skinny(M, Kp, Cout):
             Y = gemm_skinny(A, W2)  # edge-wise MLPs of a few channels: a pure stream, one row per lane
             part = None
