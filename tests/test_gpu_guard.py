@@ -15,7 +15,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 @pytest.mark.gpu
 def test_kernel_parity_tests_under_the_guard_allocator():
     # the kernel-level and fused-path tests (the graph-capturing ones cannot run on a pluggable allocator)
-    sel = ["tests/test_gpu_parity.py", "tests/test_gpu_fused.py", "-m", "gpu", "-k",
+    sel = ["tests/test_gpu_parity.py", "tests/test_gpu_fused.py", "tests/test_gpu_kpconv.py", "-m", "gpu", "-k",
            "not trajectory and not graph and not c3_full_batch"]
     env = dict(os.environ)
     env.setdefault("MIOPEN_DEBUG_CONV_IMPLICIT_GEMM", "0")
