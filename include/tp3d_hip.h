@@ -297,7 +297,7 @@ int tp3d_gemm_tn_x3_act_f32(const float *dY, const float *Yp, const float *mean_
  * gradient of that layer's activated output, invstd_k (K) its statistics row; red_out (4,K) = dbeta, dgamma,
  * c1 = dbeta / M, c2 = invstd * dgamma / M (zero with training == 0) -- what tp3d_bn_bwd_reduce_f32(dA_k, Yp) returns,
  * without that pass (its 8 M K bytes become 4 M K here: Yp is already streaming through this kernel's loader waves).
- * tp3d_gemm_tn_x3_red_chunks(M,N,K): 0 = shape not served (needs one tile column: K <= 128, N > 64), else the chunks of
+ * tp3d_gemm_tn_x3_red_chunks(M,N,K): 0 = shape not served (needs one tile column, K <= 128, and a 128 x 128, 128 x 64 or 64 x 64 tile), else the chunks of
  * [2][K] floats red_workspace must hold.  terms == 6. */
 int tp3d_gemm_tn_x3_red_chunks(int64_t M, int N, int K);
 int tp3d_gemm_tn_x3_act_red_f32(const float *dY, const float *Yp, const float *mean_k, const float *scale_k,

@@ -815,7 +815,7 @@ def test_narrow_first_layer_forward_contraction_and_its_statistics(M, N, K):
     torch.testing.assert_close(stats[1].double(), 1.0 / torch.sqrt(o64.var(0, unbiased=False) + bn.eps), rtol=2e-5, atol=0)
 
 
-@pytest.mark.parametrize("M,N,K", [(131072, 128, 128), (140001, 128, 64), (262144, 256, 128), (150016, 128, 112)])
+@pytest.mark.parametrize("M,N,K", [(131072, 128, 128), (140001, 128, 64), (262144, 256, 128), (150016, 128, 112), (140033, 64, 64)])
 @pytest.mark.parametrize("reverse", [0, 1])
 def test_weight_gradient_kernel_also_reduces_the_layer_below(M, N, K, reverse):
     """tp3d_gemm_tn_x3_act_red_f32: dW bit for bit the plain activated-operand form's; dbeta / dgamma / c1 / c2 of the
@@ -823,7 +823,7 @@ def test_weight_gradient_kernel_also_reduces_the_layer_below(M, N, K, reverse):
     from torch_points3d_amd import _lib, fused
     h = _lib.load()
     chunks = h.tp3d_gemm_tn_x3_red_chunks(M, N, K)
-    assert chunks > 0 and h.tp3d_gemm_tn_x3_red_chunks(M, N, 160) == 0 and h.tp3d_gemm_tn_x3_red_chunks(M, 64, 128) == 0
+    assert chunks > 0 and h.tp3d_gemm_tn_x3_red_chunks(M, 128, 160) == 0 and h.tp3d_gemm_tn_x3_red_chunks(M, 64, 128) == 0
     g = torch.Generator().manual_seed(M + N + K)
     dY = torch.randn(M, N, generator=g).to(DEV)
     Yp = (torch.randn(M, K, generator=g) * 1.5 + 0.2).to(DEV)
@@ -1087,7 +1087,7 @@ def test_no_grad_forward_keeps_no_side_outputs():
 
 
 @pytest.mark.parametrize("M,N,K", [(131072, 128, 128), (140001, 128, 132), (262144, 256, 128), (131072, 128, 64),
-                                   (150000, 64, 128), (131072, 128, 112), (131073, 128, 160), (200000, 256, 132)])
+                                   (150000, 64, 128), (131072, 128, 112), (131073, 128, 160), (200000, 256, 132), (140033, 64, 64)])
 @pytest.mark.parametrize("terms", [9, 6])
 def test_gemm_tn_x3_matches_fp64(M, N, K, terms):
     """The weight-gradient contraction on the bf16 matrix pipe (csrc/gemm_tn_x3.hip: every fp32 value split exactly into
@@ -1123,7 +1123,7 @@ def test_gemm_tn_x3_matches_fp64(M, N, K, terms):
     assert float((a[fin].double() - b[fin].double()).abs().max()) <= 1e-5 * float(b[fin].abs().max())
 
 
-@pytest.mark.parametrize("M,N,K", [(131072, 128, 128), (140000, 128, 132), (131072, 128, 64), (150001, 256, 160)])
+@pytest.mark.parametrize("M,N,K", [(131072, 128, 128), (140000, 128, 132), (131072, 128, 64), (150001, 256, 160), (140033, 64, 64)])
 def test_gemm_tn_x3_forms_the_activated_operand_bit_exactly(M, N, K):
     """tp3d_gemm_tn_x3_act_f32: A = LeakyReLU((Yp - mean) * scale + beta) formed by the loader waves == the plain contraction on
     the rows tp3d_bn_act_f32 writes (the forward kernels' expression and order), so dropping the forward pass's activated side

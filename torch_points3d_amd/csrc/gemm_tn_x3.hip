@@ -382,9 +382,10 @@ static X3Plan x3_plan(int64_t M, int N, int K);
 
 static bool x3_serves(int64_t M, int N, int K)
 {
-    // (64 x 64 outputs stay on the fp32 kernel: it already runs at the rate HBM delivers those rows; below ~10^5 rows one
-    //  workgroup per CU has too few steps to hide its prologue -- 40000 x 128 x 160: 65 vs 42 us)
-    if (!(M >= 131072 && N >= 64 && K >= 64 && (N > 64 || K > 64) && (N & 3) == 0 && (K & 3) == 0 &&
+    // (below ~10^5 rows one workgroup per CU has too few steps to hide its prologue -- 40000 x 128 x 160: 65 vs 42 us.  64 x 64
+    //  outputs: the plain form only matches the fp32 kernel, which runs at the rate HBM delivers those rows, but the forms
+    //  that build the activated operand and the reductions of the layer below save a side output and a pass)
+    if (!(M >= 131072 && N >= 64 && K >= 64 && (N & 3) == 0 && (K & 3) == 0 &&
           M * (int64_t)(N > K ? N : K) < ((int64_t)1 << 30)))
         return false;
     // every tile column re-reads dY and every tile row re-reads A, and a padded tile splits and multiplies zeros: the
@@ -515,7 +516,7 @@ static bool x3_red_serves(int64_t M, int N, int K)
 {
     if (!x3_serves(M, N, K)) return false;
     const X3Plan p = x3_plan(M, N, K);
-    return p.tiles_k == 1 && !p.strip && p.wm == 2;
+    return p.tiles_k == 1 && !p.strip && (p.wm == 2 || p.wn == 1);  // <2,2>, <2,1>, <1,1> tiles
 }
 
 TP3D_EXPORT int tp3d_gemm_tn_x3_red_chunks(int64_t M, int N, int K)
@@ -536,8 +537,9 @@ TP3D_EXPORT int tp3d_gemm_tn_x3_act_red_f32(const float *dY, const float *Yp, co
     const X3Plan p = x3_plan(M, N, K);
     if (p.splits > 65535) return TP3D_E_TOOBIG;
     const X3Prologue pro = {mean_k, scale_k, beta_k, slope_k, reverse, dA_k, invstd_k, red_workspace};
-    if (p.wn == 2) x3_launch<2, 2, false, 32, 6, true>(p, dY, Yp, M, N, K, workspace, pro, s);
-    else x3_launch<2, 1, false, 32, 6, true>(p, dY, Yp, M, N, K, workspace, pro, s);
+    if (p.wm == 2 && p.wn == 2) x3_launch<2, 2, false, 32, 6, true>(p, dY, Yp, M, N, K, workspace, pro, s);
+    else if (p.wm == 2) x3_launch<2, 1, false, 32, 6, true>(p, dY, Yp, M, N, K, workspace, pro, s);
+    else x3_launch<1, 1, false, 64, 6, true>(p, dY, Yp, M, N, K, workspace, pro, s);
     if (int rc = check_launch()) return rc;
     if (int rc = tn_reduce_splits(workspace, p.splits, (int64_t)N * K, out, s)) return rc;
     return bn_bwd_finalize_launch(red_workspace, p.tiles_n * p.splits, K, red_out, red_out + K, invstd_k, M, training,
