@@ -6,7 +6,7 @@ cd "$GRAFT_REPO_ROOT"
 export TMPDIR=/tmp
 timeout -k 10 500 python -m pytest tests -m gpu -q -rf > $out/tests.log 2>&1; tail -3 $out/tests.log
 cp gpurun_out/parity_report.json $out/parity_report.json
-timeout -k 10 300 python bench.py --steps 20 --warmup 5 --details-out $out/bench_detail.json > $out/bench.json 2> $out/bench.err; tail -1 $out/bench.err
+timeout -k 10 300 python bench.py --details-out $out/bench_detail.json > $out/bench.json 2> $out/bench.err; tail -1 $out/bench.err
 timeout -k 10 200 python bench.py --workload forward --steps 20 --warmup 3 --details-out $out/bench_forward_detail.json > $out/bench_forward.json 2> $out/bench_forward.err
 timeout -k 10 300 python bench.py --workload msg_c3 --steps 20 --warmup 3 --details-out $out/bench_msg_c3_detail.json > $out/bench_msg_c3.json 2> $out/bench_msg_c3.err
 timeout -k 10 300 python bench.py --model unet_4_ss --steps 10 --warmup 3 --details-out $out/bench_unet_4_ss_detail.json > $out/bench_unet_4_ss.json 2> $out/bench_unet_4_ss.err
