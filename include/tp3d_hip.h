@@ -35,7 +35,7 @@ extern "C" {
 #define TP3D_E_UNSORTED (-3) /* reserved: batch vector not sorted (checked by the host wrapper) */
 #define TP3D_E_TOOBIG (-4)   /* size exceeds what the kernel's index arithmetic supports */
 
-#define TP3D_ABI_VERSION 35
+#define TP3D_ABI_VERSION 36
 
 int tp3d_abi_version(void);
 const char *tp3d_strerror(int code);
@@ -207,6 +207,13 @@ int tp3d_gemm_rows_stat_chunks(int64_t M, int N);
 size_t tp3d_gemm_rows_workspace_floats(int64_t M, int N, int K);
 int tp3d_gemm_rows_f32(const float *A, const float *Bt, int64_t M, int N, int K, float *C, float *stat_partial,
                        float *workspace, void *stream);
+/* The same contraction with the eval-mode BatchNorm + LeakyReLU of its OUTPUT applied to the accumulators:
+ *   C = LeakyReLU((A Bt^T - mean[n]) * scale[n] + beta[n])      (mean / scale / beta: N floats, as tp3d_bn_stats_f32 leaves them)
+ * -- one launch per Linear -> BatchNorm (running statistics) -> activation layer of an inference pass
+ * (core/common_modules/base_modules.py: FastBatchNorm1d + activation after nn.Linear).  workspace as for
+ * tp3d_gemm_rows_f32 without statistics (K-split slabs; the epilogue then runs in the slab sum, which needs N % 4 == 0). */
+int tp3d_gemm_rows_epi_f32(const float *A, const float *Bt, int64_t M, int N, int K, const float *mean, const float *scale,
+                           const float *beta, float slope, float *C, float *workspace, void *stream);
 /* The same fused contraction on the split-role kernel (csrc/gemm_rows_sp.hip: four MFMA waves fed by four loader waves
  * that apply the prologue on their way into LDS, so it costs the MFMA waves nothing).  act_out != NULL additionally
  * receives the activated rows (M,K) the backward pass of the next layer contracts with (training); stat_partial as for

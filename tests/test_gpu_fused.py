@@ -865,6 +865,31 @@ def test_weight_gradient_kernel_also_reduces_the_layer_below(M, N, K, reverse):
     assert float(red[2:].abs().max()) == 0.0 and torch.equal(out, plain)
 
 
+@pytest.mark.parametrize("M,N,K", [(65536, 64, 256), (1331, 256, 1024), (27, 2048, 1024), (216, 512, 3072), (9261, 64, 256), (5000, 36, 64),
+                                   (70000, 128, 132)])
+def test_rows_gemm_epilogue_applies_eval_batchnorm_and_activation(M, N, K):
+    """tp3d_gemm_rows_epi_f32 == tp3d_gemm_rows_f32 followed by tp3d_bn_act_f32 (plain tiles: bit for bit; K-split launches: the
+    epilogue runs in the slab sum), wide / narrow tiles, ragged rows, widths that are not a multiple of the tile."""
+    from torch_points3d_amd import _lib, fused
+    h = _lib.load()
+    g = torch.Generator().manual_seed(M + N + K)
+    A = torch.randn(M, K, generator=g).to(DEV)
+    W = (torch.randn(N, K, generator=g) * 0.1).to(DEV)
+    mean, scale, beta = (torch.randn(N, generator=g) * 0.2).to(DEV), (torch.rand(N, generator=g) + 0.5).to(DEV), \
+        (torch.randn(N, generator=g) * 0.3).to(DEV)
+    st = _lib.stream_ptr(A.device)
+    Y = fused.gemm_rows(A, W)[0]
+    want = torch.empty_like(Y)
+    _lib.call("tp3d_bn_act_f32", _lib.ptr(Y), _lib.ptr(mean), _lib.ptr(scale), _lib.ptr(beta), 0.1, M, N, _lib.ptr(want), st)
+    n = h.tp3d_gemm_rows_workspace_floats(M, N, K)
+    ws = torch.empty(max(n, 1), device=DEV)
+    out = torch.full((M, N), float("nan"), device=DEV)
+    _lib.call("tp3d_gemm_rows_epi_f32", _lib.ptr(A), _lib.ptr(W), M, N, K, _lib.ptr(mean), _lib.ptr(scale), _lib.ptr(beta), 0.1,
+              _lib.ptr(out), _lib.ptr(ws) if n else None, st)
+    torch.cuda.synchronize()
+    assert torch.equal(out, want)
+
+
 def test_chain_contracts_only_the_feature_columns_of_grouped_rows():
     """Grouped rows are [relative position (3), features (C), padding]; their producer reads the gradient of the feature
     columns only, and the chain's first input-gradient GEMM computes just those (the rest stays zero): the gradient that

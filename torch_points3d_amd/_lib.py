@@ -44,6 +44,7 @@ SIGNATURES = {
     "tp3d_gemm_tn_bn_narrow_f32": [_p, _p, _p, _p, _p, _p, _p, _f, _p, _l, _i, _i, _p, _p, _i, _p],
     "tp3d_bn_bwd_reduce_f32": [_p, _p, _p, _p, _p, _p, _p, _f, _l, _i, _i, _i, _p, _p, _p, _p, _p, _i, _p],
     "tp3d_gemm_rows_f32": [_p, _p, _l, _i, _i, _p, _p, _p, _p],
+    "tp3d_gemm_rows_epi_f32": [_p, _p, _l, _i, _i, _p, _p, _p, _f, _p, _p, _p],
     "tp3d_gemm_rows_bnact_sp_f32": [_p, _p, _p, _p, _f, _p, _l, _i, _i, _p, _p, _p, _i, _p],
     "tp3d_gemm_rows_bnact_x3_f32": [_p, _p, _p, _p, _f, _p, _l, _i, _i, _p, _p, _p, _i, _p],
     "tp3d_gemm_rows_bnbwd_sp_f32": [_p, _p, _p, _p, _p, _p, _p, _f, _p, _l, _i, _i, _p, _i, _i, _i, _p, _p, _i, _i, _p],
@@ -76,7 +77,7 @@ SIGNATURES = {
 MISC = ("tp3d_abi_version", "tp3d_strerror", "tp3d_last_hip_error", "tp3d_scatter_workspace_bytes",
         "tp3d_bn_workspace_floats", "tp3d_gemm_tn_workspace_floats", "tp3d_gemm_tn_x3_workspace_floats", "tp3d_gemm_tn_x3_serves", "tp3d_gemm_tn_x3_red_chunks", "tp3d_ball_query_workspace_bytes",
         "tp3d_gemm_rows_stat_floats", "tp3d_gemm_rows_stat_chunks", "tp3d_gemm_rows_sp_chunks", "tp3d_gemm_rows_x3_chunks", "tp3d_gemm_rows_bnbwd_sp_serves", "tp3d_gemm_tn_bn_narrow_serves", "tp3d_gemm_rows_narrow_chunks", "tp3d_gemm_tn_bn_narrow_workspace_floats", "tp3d_gemm_rows_workspace_floats", "tp3d_kpconv_bwd_workspace_bytes", "tp3d_voxel_workspace_bytes", "tp3d_knn_workspace_bytes", "tp3d_kpconv_grad_workspace_bytes")
-ABI_VERSION = 35
+ABI_VERSION = 36
 
 _handle = None
 

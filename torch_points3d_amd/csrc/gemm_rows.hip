@@ -31,13 +31,21 @@ constexpr int GR_BLOCK_T = 256;
 constexpr int GR_BM = 128, GR_BK = 32;
 constexpr int GR_LD = GR_BK + 4;  // 36-float pitch
 
+// Output EPILOGUE of the eval-mode layers (mean == nullptr: none): C = LeakyReLU((acc - mean[n]) * scale[n] + beta[n]) --
+// BatchNorm on running statistics + activation applied to the accumulators, so that an inference pass has one launch per
+// Linear -> BatchNorm -> LeakyReLU layer instead of two (core/common_modules/base_modules.py FastBatchNorm1d + activation)
+struct RowsEpilogue {
+    const float *mean, *scale, *beta;
+    float slope;
+};
+
 // WIDE: 128 x 128 tile, else 128 x 64.  STATS: 0 none, 1 one statistics chunk per (128-row block, wave row), 2 one per
 // (workgroup, wave row) (needs gridDim.x % (8*tiles_n) == 0: every item of a workgroup then lies in one column tile)
 template <bool WIDE, int STATS>
 __global__ __launch_bounds__(GR_BLOCK_T, 1) void gemm_rows_kernel(const float *__restrict__ A, const float *__restrict__ Bt,
                                                                 int64_t M, int N, int K, int kchunk, int tiles_n,
                                                                 int64_t items, float *__restrict__ C,
-                                                                float *__restrict__ partial)
+                                                                float *__restrict__ partial, RowsEpilogue epi)
 {
     constexpr int BN = WIDE ? 128 : 64;
     constexpr int WR = WIDE ? 2 : 4;          // wave rows of the workgroup tile
@@ -161,10 +169,17 @@ __global__ __launch_bounds__(GR_BLOCK_T, 1) void gemm_rows_kernel(const float *_
 #pragma unroll
             for (int j = 0; j < WN; ++j) {
                 const int n = n0 + (wc * WN + j) * 32 + l31;
+                float emu = 0.0f, esc = 1.0f, ebe = 0.0f;
+                if (epi.mean && n < N) emu = epi.mean[n], esc = epi.scale[n], ebe = epi.beta[n];
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
                     const int64_t m = m0 + (wr * WM + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-                    if (m < M && n < N) C[m * N + n] = acc[i][j][e];
+                    float v = acc[i][j][e];
+                    if (epi.mean) {  // (wave-uniform)
+                        v = (v - emu) * esc + ebe;
+                        v = v > 0.0f ? v : v * epi.slope;
+                    }
+                    if (m < M && n < N) C[m * N + n] = v;
                 }
             }
         if (STATS != 0) {
@@ -240,7 +255,8 @@ __global__ __launch_bounds__(GR_BLOCK_T, 1) void gemm_rows_kernel(const float *_
 template <int STATS>
 __global__ __launch_bounds__(GR_BLOCK_T, 2) void gemm_rows_wide_kernel(const float *__restrict__ A, const float *__restrict__ Bt,
                                                                 int64_t M, int N, int K, int tiles_n, int64_t items,
-                                                                float *__restrict__ C, float *__restrict__ partial)
+                                                                float *__restrict__ C, float *__restrict__ partial,
+                                                                RowsEpilogue epi)
 {
     __shared__ __attribute__((aligned(16))) float sA[GR_BM * GR_LD];
     __shared__ __attribute__((aligned(16))) float sB[128 * GR_LD];
@@ -348,10 +364,17 @@ __global__ __launch_bounds__(GR_BLOCK_T, 2) void gemm_rows_wide_kernel(const flo
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const int n = n0 + (wc * 2 + j) * 32 + l31;
+                float emu = 0.0f, esc = 1.0f, ebe = 0.0f;
+                if (epi.mean && n < N) emu = epi.mean[n], esc = epi.scale[n], ebe = epi.beta[n];
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
                     const int64_t m = m0 + (wr * 2 + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-                    if (m < M && n < N) C[m * N + n] = acc[i][j][e];
+                    float v = acc[i][j][e];
+                    if (epi.mean) {  // (wave-uniform)
+                        v = (v - emu) * esc + ebe;
+                        v = v > 0.0f ? v : v * epi.slope;
+                    }
+                    if (m < M && n < N) C[m * N + n] = v;
                 }
             }
         if (STATS != 0) {
@@ -423,7 +446,7 @@ __global__ __launch_bounds__(GR_BLOCK_T, 2) void gemm_rows_wide_kernel(const flo
 
 // out[e] = sum_s slab[s][e], s ascending (fixed order => reproducible); one float4 per thread
 __global__ __launch_bounds__(256) void gemm_rows_sum_slabs_kernel(const float *__restrict__ slabs, int S, int64_t MN4,
-                                                                   float *__restrict__ out)
+                                                                   float *__restrict__ out, int N, RowsEpilogue epi)
 {
     for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < MN4; e += (int64_t)gridDim.x * 256) {
         float4 t = reinterpret_cast<const float4 *>(slabs)[e];
@@ -433,6 +456,15 @@ __global__ __launch_bounds__(256) void gemm_rows_sum_slabs_kernel(const float *_
             t.y += v.y;
             t.z += v.z;
             t.w += v.w;
+        }
+        if (epi.mean) {  // (N % 4 == 0 on this path: the four values share a row)
+            const int n = (int)((e * 4) % N);
+            const float4 mu = *reinterpret_cast<const float4 *>(epi.mean + n), sc = *reinterpret_cast<const float4 *>(epi.scale + n);
+            const float4 be = *reinterpret_cast<const float4 *>(epi.beta + n);
+            t.x = (t.x - mu.x) * sc.x + be.x, t.y = (t.y - mu.y) * sc.y + be.y;
+            t.z = (t.z - mu.z) * sc.z + be.z, t.w = (t.w - mu.w) * sc.w + be.w;
+            t.x = t.x > 0.0f ? t.x : t.x * epi.slope, t.y = t.y > 0.0f ? t.y : t.y * epi.slope;
+            t.z = t.z > 0.0f ? t.z : t.z * epi.slope, t.w = t.w > 0.0f ? t.w : t.w * epi.slope;
         }
         reinterpret_cast<float4 *>(out)[e] = t;
     }
@@ -486,35 +518,50 @@ RowsPlan rows_plan(int64_t M, int N, int K = 0, bool allow_split = false)
 
 template <bool WIDE>
 int launch_rows(const RowsPlan &p, const float *A, const float *Bt, int64_t M, int N, int K, float *C, float *stat_partial,
-                hipStream_t s)
+                const RowsEpilogue &epi, hipStream_t s)
 {
     const dim3 grid((unsigned)p.blocks, (unsigned)p.ksplit), block(GR_BLOCK_T);
     if (WIDE && p.ksplit == 1) {  // the dedicated plain 128 x 128 kernel
         if (stat_partial && p.per_workgroup)
-            hipLaunchKernelGGL(gemm_rows_wide_kernel<2>, grid, block, 0, s, A, Bt, M, N, K, p.tiles_n, p.items, C, stat_partial);
+            hipLaunchKernelGGL(gemm_rows_wide_kernel<2>, grid, block, 0, s, A, Bt, M, N, K, p.tiles_n, p.items, C, stat_partial, epi);
         else if (stat_partial)
-            hipLaunchKernelGGL(gemm_rows_wide_kernel<1>, grid, block, 0, s, A, Bt, M, N, K, p.tiles_n, p.items, C, stat_partial);
+            hipLaunchKernelGGL(gemm_rows_wide_kernel<1>, grid, block, 0, s, A, Bt, M, N, K, p.tiles_n, p.items, C, stat_partial, epi);
         else
-            hipLaunchKernelGGL(gemm_rows_wide_kernel<0>, grid, block, 0, s, A, Bt, M, N, K, p.tiles_n, p.items, C, stat_partial);
+            hipLaunchKernelGGL(gemm_rows_wide_kernel<0>, grid, block, 0, s, A, Bt, M, N, K, p.tiles_n, p.items, C, stat_partial, epi);
         return check_launch();
     }
     if (stat_partial && p.per_workgroup)
         hipLaunchKernelGGL((gemm_rows_kernel<WIDE, 2>), grid, block, 0, s, A, Bt, M, N, K, p.kchunk, p.tiles_n, p.items,
-                           C, stat_partial);
+                           C, stat_partial, epi);
     else if (stat_partial)
         hipLaunchKernelGGL((gemm_rows_kernel<WIDE, 1>), grid, block, 0, s, A, Bt, M, N, K, p.kchunk, p.tiles_n, p.items,
-                           C, stat_partial);
+                           C, stat_partial, epi);
     else
         hipLaunchKernelGGL((gemm_rows_kernel<WIDE, 0>), grid, block, 0, s, A, Bt, M, N, K, p.kchunk, p.tiles_n, p.items,
-                           C, stat_partial);
+                           C, stat_partial, epi);
     return check_launch();
 }
 
 int launch_rows_any(const RowsPlan &p, const float *A, const float *Bt, int64_t M, int N, int K, float *C,
-                    float *stat_partial, hipStream_t s)
+                    float *stat_partial, const RowsEpilogue &epi, hipStream_t s)
 {
-    return p.wide ? launch_rows<true>(p, A, Bt, M, N, K, C, stat_partial, s)
-                  : launch_rows<false>(p, A, Bt, M, N, K, C, stat_partial, s);
+    return p.wide ? launch_rows<true>(p, A, Bt, M, N, K, C, stat_partial, epi, s)
+                  : launch_rows<false>(p, A, Bt, M, N, K, C, stat_partial, epi, s);
+}
+
+// the contraction, optionally K-split into slabs + their sum, with an optional output epilogue
+int rows_gemm(const float *A, const float *Bt, int64_t M, int N, int K, float *C, float *stat_partial, float *workspace,
+              const RowsEpilogue &epi, hipStream_t s)
+{
+    const RowsEpilogue none = {nullptr, nullptr, nullptr, 1.0f};
+    // K-split only without fused statistics (they need the finished column values) and with slabs to write to
+    const RowsPlan p = rows_plan(M, N, K, !stat_partial && workspace && ((M * (int64_t)N) & 3) == 0 && (!epi.mean || (N & 3) == 0));
+    if (p.ksplit == 1) return launch_rows_any(p, A, Bt, M, N, K, C, stat_partial, epi, s);
+    if (int rc = launch_rows_any(p, A, Bt, M, N, K, workspace, nullptr, none, s)) return rc;
+    const int64_t mn4 = M * (int64_t)N / 4;
+    hipLaunchKernelGGL(gemm_rows_sum_slabs_kernel, dim3((unsigned)std::min<int64_t>((mn4 + 255) / 256, 4096)), dim3(256), 0, s,
+                       workspace, p.ksplit, mn4, C, N, epi);
+    return check_launch();
 }
 }  // namespace
 
@@ -568,13 +615,21 @@ TP3D_EXPORT int tp3d_gemm_rows_f32(const float *A, const float *Bt, int64_t M, i
     if (M < 0 || N <= 0 || K <= 0 || (K & 3)) return TP3D_E_BADARG;  // operand rows must be 16-byte aligned
     if (M == 0) return TP3D_OK;
     if (!A || !Bt || !C) return TP3D_E_BADARG;
-    hipStream_t s = (hipStream_t)stream;
-    // K-split only without fused statistics (they need the finished column values) and with slabs to write to
-    const RowsPlan p = rows_plan(M, N, K, !stat_partial && workspace && ((M * (int64_t)N) & 3) == 0);
-    if (p.ksplit == 1) return launch_rows_any(p, A, Bt, M, N, K, C, stat_partial, s);
-    if (int rc = launch_rows_any(p, A, Bt, M, N, K, workspace, nullptr, s)) return rc;
-    const int64_t mn4 = M * (int64_t)N / 4;
-    hipLaunchKernelGGL(gemm_rows_sum_slabs_kernel, dim3((unsigned)std::min<int64_t>((mn4 + 255) / 256, 4096)), dim3(256), 0, s,
-                       workspace, p.ksplit, mn4, C);
-    return check_launch();
+    const RowsEpilogue none = {nullptr, nullptr, nullptr, 1.0f};
+    return rows_gemm(A, Bt, M, N, K, C, stat_partial, workspace, none, (hipStream_t)stream);
+}
+
+// The same contraction with the eval-mode BatchNorm + LeakyReLU of its OUTPUT applied to the accumulators:
+//   C = LeakyReLU((A Bt^T - mean[n]) * scale[n] + beta[n])        (mean / scale / beta: N floats each)
+// -- one launch per Linear -> BatchNorm (running statistics) -> activation layer of an inference pass.  workspace as for
+// tp3d_gemm_rows_f32 (K-split slabs; the epilogue then runs in the slab sum).
+TP3D_EXPORT int tp3d_gemm_rows_epi_f32(const float *A, const float *Bt, int64_t M, int N, int K, const float *mean,
+                                       const float *scale, const float *beta, float slope, float *C, float *workspace,
+                                       void *stream)
+{
+    if (M < 0 || N <= 0 || K <= 0 || (K & 3)) return TP3D_E_BADARG;
+    if (M == 0) return TP3D_OK;
+    if (!A || !Bt || !C || !mean || !scale || !beta) return TP3D_E_BADARG;
+    const RowsEpilogue epi = {mean, scale, beta, slope};
+    return rows_gemm(A, Bt, M, N, K, C, nullptr, workspace, epi, (hipStream_t)stream);
 }

@@ -246,6 +246,7 @@ ROWS_GEMM_WITHOUT_STATS = True  # the rows kernel also where it has no BatchNorm
                                 # there -- the choice for inference replayed from a HIP graph (KPConv unet_4 forward 1.46 ->
                                 # 1.10 ms); launched eagerly the library's host side makes the forward slower (1.96 -> 2.24 ms).
                                 # One setting for both, so that a captured step stays bit-identical to its eager twin
+ROWS_GEMM_EPILOGUE = True  # eval-mode layers without a gradient request: BatchNorm + activation in the rows GEMM's epilogue
 ROWS_GEMM_NARROW = True   # widths served by the 128 x 64 tiles (N % 128 in 1..64) on the rows kernel (else library GEMM)
 CHAIN_MIN_ROWS = 32768    # the fused layer chain serves the large row matrices (grouped / per-point activations)
 
@@ -324,6 +325,17 @@ class _LinearBNAct(torch.autograd.Function):
         if own_gemm and ((M + 127) // 128) * ((Cout + 127) // 128) < 128 and 512 <= Kp < 1024:
             own_gemm = False
         want_stats = training and not _long_k(M, Cout, Kp)
+        if (own_gemm and ROWS_GEMM_EPILOGUE and not training and not pool_ns and ROWS_GEMM_WITHOUT_STATS
+                and not (_outer_grad and any(ctx.needs_input_grad))):
+            # inference: BatchNorm (running statistics) + activation applied to the accumulators -- one launch per layer
+            with _lib.on_device(dev):
+                stats = _bn_stats(A, M, Cout, gamma, beta, bn, False, dev, st, bias)
+                out = torch.empty((M, Cout), dtype=torch.float32, device=dev)
+                n = _lib.load().tp3d_gemm_rows_workspace_floats(M, Cout, Kp)
+                slabs = _lib.workspace("gemm_rows_slabs", 4 * n, dev) if n else None
+                _lib.call("tp3d_gemm_rows_epi_f32", _lib.ptr(A), _lib.ptr(W2.contiguous()), M, Cout, Kp, _lib.ptr(stats[0]),
+                          _lib.ptr(stats[2]), _lib.ptr(stats[3]), slope, _lib.ptr(out), _lib.ptr(slabs), st)
+            return out
         if own_gemm and not want_stats and not ROWS_GEMM_WITHOUT_STATS:
             # nothing to fold into the epilogue (eval mode; K-split shapes): the library GEMM's KERNEL is faster on every
             # such shape of the KPConv / PointNet++ networks (tools/probes/small_gemm.py: 65536 x 64 x 256 24 vs 40 us,
