@@ -890,6 +890,61 @@ def test_rows_gemm_epilogue_applies_eval_batchnorm_and_activation(M, N, K):
     assert torch.equal(out, want)
 
 
+@pytest.mark.parametrize("widths,M,pool_ns", [([132, 128, 128, 256], 140032, 0), ([8, 64, 64, 128], 262144, 64)])
+@pytest.mark.parametrize("train", [True, False])
+def test_large_chain_gradients_with_and_without_the_fused_reductions(widths, M, pool_ns, train):
+    """Row counts at which the bf16-pipe weight-gradient kernel serves (>= 131072): the chain with the BatchNorm-backward
+    reductions riding on the weight-gradient kernels (fused.WGRAD_RED), the narrow first-layer kernels and alternating row
+    directions, against the same chain with those three off -- every gradient within rounding, in train and in eval mode (eval:
+    c1 = c2 = 0 in the reductions the weight-gradient kernel finalizes)."""
+    import copy
+    from torch_points3d_amd import fused
+    from torch_points3d_amd.dense import MLP2D
+    torch.manual_seed(13)
+    mlp = MLP2D(widths).to(DEV)
+    with torch.no_grad():
+        for m in mlp.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.weight.uniform_(0.5, 1.5)
+                m.bias.normal_(0, 0.3)
+                m.running_mean.normal_()
+                m.running_var.uniform_(0.5, 2.0)
+    twin = copy.deepcopy(mlp)
+    mlp.train(train)
+    twin.train(train)
+    rows = torch.randn(M, widths[0], generator=torch.Generator().manual_seed(5)).to(DEV)
+    ra, rb = rows.clone().requires_grad_(widths[0] > 16), rows.clone().requires_grad_(widths[0] > 16)
+    cot = torch.randn((M // pool_ns) if pool_ns else M, widths[-1], generator=torch.Generator().manual_seed(6)).to(DEV)
+    names = ("WGRAD_RED", "WGRAD_NARROW", "FWD_NARROW", "ROW_ORDER_ALTERNATE")
+    old = {n: getattr(fused, n) for n in names}
+    seen = []
+    real_call = fused._lib.call
+    try:
+        fused._lib.call = lambda name, *a: (seen.append(name), real_call(name, *a))[1]
+        out = fused.run_mlp(ra, fused.mlp_parts(mlp), pool_ns)
+        out.backward(cot)
+        fused._lib.call = real_call
+        for n in names:
+            setattr(fused, n, False)
+        want = fused.run_mlp(rb, fused.mlp_parts(twin), pool_ns)
+        want.backward(cot)
+    finally:
+        fused._lib.call = real_call
+        for n, v in old.items():
+            setattr(fused, n, v)
+    assert "tp3d_gemm_tn_x3_act_red_f32" in seen
+    if widths[0] <= 16:
+        assert {"tp3d_gemm_rows_narrow_f32", "tp3d_gemm_tn_bn_narrow_f32"} <= set(seen)
+    torch.testing.assert_close(out.detach(), want.detach(), rtol=1e-5, atol=1e-5 * float(want.detach().abs().max()))
+    # a LeakyReLU mask flips where a last-bit difference of the statistics (another order of the chunks) moves z across
+    # zero -- a handful of the 5e7 hidden activations -- and every flip changes a whole row's contribution: bounded
+    # through the L2 norm as in test_mlp_chain_matches_layerwise_path (a dropped 32-row block would be 1.5e-2)
+    for (k, a), (_, b) in zip(mlp.named_parameters(), twin.named_parameters()):
+        assert float((a.grad - b.grad).norm()) <= 3e-3 * float(b.grad.norm()) + 1e-10, k
+    if ra.requires_grad:
+        assert float((ra.grad - rb.grad).norm()) <= 3e-3 * float(rb.grad.norm())
+
+
 def test_chain_contracts_only_the_feature_columns_of_grouped_rows():
     """Grouped rows are [relative position (3), features (C), padding]; their producer reads the gradient of the feature
     columns only, and the chain's first input-gradient GEMM computes just those (the rest stays zero): the gradient that
